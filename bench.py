@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Benchmark of the tl.infercnv hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one batch of synthetic cells that is already
+resident in HBM: reference mean (float64 column sums, + one RCCL all-reduce when N > 1) ->
+fused centre/clip/pyramid-smooth/median kernel -> per-chunk std -> threshold.  Workload at N=1 =
+BASELINE config 2 (dense fp32 100 000 cells x 20 000 genes on chr1..22, window 100, step 10,
+chunksize 5000); for N > 1 every rank owns 100 000 cells (weak scaling, chunk-aligned shards, the
+only collective is the reference-mean all-reduce).
+
+Prints ONE JSON line on rank 0: metric cells/s (whole job), plus
+  roofline     - the smoothing kernel: algorithmic bytes (4*G + 4*W per cell) / its average
+                 HIP-event duration, against the 8 TB/s HBM peak
+  cpu_baseline - the numpy oracle (a port of the reference algorithm, oracle/) timed on this box's
+                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_on_device(torch, n_cells, n_genes, seed):
+    """gamma(0.3, 1) with entries < 0.5 zeroed (~19 % nnz), SURVEY §8(d) config 2 -- on the GPU."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    out = torch.empty((n_cells, n_genes), dtype=torch.float32, device="cuda")
+    rows = 10_000
+    for r in range(0, n_cells, rows):
+        k = min(rows, n_cells - r)
+        g = torch._standard_gamma(torch.full((k, n_genes), 0.3, device="cuda"), generator=gen)
+        out[r:r + k] = torch.where(g < 0.5, torch.zeros_like(g), g)
+    return out
+
+
+def cpu_baseline(cells_per_worker=250, window=100, step=10):
+    """Oracle (numpy port of the reference algorithm) on the host cores, reference-style fan-out."""
+    import numpy as np
+
+    import cases
+    from oracle import infercnv_oracle as O
+
+    cores = os.cpu_count() or 1
+    n = cells_per_worker * cores
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    X = cases.synthetic_expr(n, 20000, seed=2)
+    ref = X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    t0 = time.perf_counter()
+    O.infercnv(X, v["chromosome"], v["start"], reference=ref, window_size=window, step=step,
+               chunksize=cells_per_worker, n_jobs=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+        "sample": f"{n} cells x 20000 genes dense fp32, window {window} step {step}, {cores} processes x "
+                  f"{cells_per_worker}-cell chunks (ProcessPoolExecutor, per-row np.convolve as the reference), "
+                  f"{dt:.1f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cells", type=int, default=100_000, help="cells per GPU")
+    ap.add_argument("--window", type=int, default=100)
+    ap.add_argument("--step", type=int, default=10)
+    ap.add_argument("--chunksize", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-refmean", action="store_true", help="exclude the reference-mean pass from the step")
+    args = ap.parse_args()
+
+    import torch
+
+    import cases
+    from infercnvpy_amd import _engine
+    from infercnvpy_amd._plan import GenePlan
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+
+    G = 20000
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=args.window, step=args.step)
+    W = plan.n_windows
+    n_local = args.cells
+    X = synth_on_device(torch, n_local, G, seed=2 + rank)
+    dm = _engine.DeviceMatrix(dense=X)
+    out = torch.empty((n_local, W), dtype=torch.float32, device="cuda")
+    sums = torch.zeros((1, G), dtype=torch.float64, device="cuda")
+    fixed_ref = None
+    if args.no_refmean:
+        fixed_ref = (_engine.column_sums(dm)[0] / n_local).float()
+
+    smooth_ms = []
+
+    def one_step():
+        if fixed_ref is None:
+            sums.zero_()
+            _engine.column_sums(dm, None, 1, sums)
+            if dist is not None:
+                dist.all_reduce(sums)  # the only collective of the path: [G] float64 over RCCL/xGMI
+            ref = (sums[0] / (n_local * n_gpus)).float()
+        else:
+            ref = fixed_ref
+        res = _engine.run_hot_path(plan, dm, ref, lfc_clip=3.0, dynamic_threshold=1.5, chunksize=args.chunksize,
+                                   out=out, profile=True)
+        smooth_ms.append(res.profile.smooth_ms)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    smooth_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    cells_total = n_local * n_gpus
+    value = cells_total / (dt / args.steps)
+
+    bytes_per_cell = 4 * G + 4 * W  # 87 208 B/cell at window 100 / step 10
+    avg_smooth_ms = sum(smooth_ms) / max(len(smooth_ms), 1)
+    achieved = bytes_per_cell * n_local / (avg_smooth_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get("k_smooth_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "cells/sec through tl.infercnv (window=100)" if args.window == 100 else
+                  f"cells/sec through tl.infercnv (window={args.window})",
+        "value": value,
+        "unit": "cells/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 in / f64 accumulate",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE config 2: dense fp32 {n_local} cells/GPU x {G} genes (chr1..22, random var order), "
+                        f"window {args.window}, step {args.step}, chunksize {args.chunksize}, lfc_clip 3, "
+                        f"dynamic_threshold 1.5, reference = all-cell mean"
+                        + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)"),
+            "cells_total": cells_total,
+            "n_windows": W,
+            "parallelism": f"row shards x{n_gpus}, all-reduce of the [G] float64 reference sums only",
+        },
+        "roofline": {
+            "kernel": "k_smooth<float,dense>",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "bytes_per_cell": bytes_per_cell,
+            "kernel_ms": avg_smooth_ms,
+        },
+    }
+    if rank == 0:
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(window=args.window, step=args.step)
+            except Exception as e:  # the GPU number must still be reported
+                result["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

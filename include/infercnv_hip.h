@@ -1,0 +1,171 @@
+/*
+ * infercnv_hip.h -- C ABI of the MI355X (gfx950) CNV-inference engine.
+ *
+ * This is the drop-in boundary for ONE hot path of icbi-lab/infercnvpy:
+ * the per-chunk numeric kernel `_infercnv_chunk` (reference
+ * src/infercnvpy/tl/_infercnv.py:411-457) together with the pieces of the
+ * `infercnv` driver that touch every matrix element (reference mean,
+ * :359-408; chunk fan-out/vstack, :120-139) and the `cnv_score` reduction
+ * (src/infercnvpy/tl/_scores.py:65-68).
+ *
+ * The reference has no FFI; its seam is a Python function called once per
+ * 5000-cell chunk from a ProcessPoolExecutor worker.  A maintainer binds this
+ * library with ctypes and calls it from `infercnv()` in
+ * place of `process_map(_infercnv_chunk, ...)`.
+ *
+ * Conventions
+ *   - plain C types only; every data pointer is a DEVICE pointer (HBM) unless
+ *     the parameter name starts with `h_` (host);
+ *   - every function returns an icv_status (0 = ok); `icv_last_error()` returns
+ *     a thread-local message for the last failure; no C++ exception crosses;
+ *   - the caller owns all buffers; the only library-owned object is the opaque
+ *     plan (create / destroy);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     are asynchronous on that stream unless stated otherwise.
+ */
+#ifndef INFERCNV_HIP_H
+#define INFERCNV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ICV_OK = 0,
+    ICV_ERR_INVALID = 1,     /* bad argument (maps to Python ValueError)            */
+    ICV_ERR_UNSUPPORTED = 2, /* configuration exceeds an implementation limit       */
+    ICV_ERR_HIP = 3,         /* HIP runtime failure (message has the hipError name) */
+    ICV_ERR_NOMEM = 4
+} icv_status;
+
+enum { ICV_F32 = 0, ICV_F64 = 1 };
+enum { ICV_DENSE = 0, ICV_CSR = 1 };
+
+/* flags for icv_infercnv_* */
+enum {
+    ICV_FLAG_TRUNC_TO_INT = 1, /* bounded centring of an integer matrix keeps the matrix dtype
+                                  (reference :428): centred values are truncated toward zero */
+    ICV_FLAG_ROUND_F32 = 2     /* bounded centring of a float32 matrix against a float64 reference:
+                                  differences are rounded to float32 (same line)              */
+};
+
+/* A cells x genes expression matrix resident in HBM. */
+typedef struct {
+    int32_t format;         /* ICV_DENSE | ICV_CSR                                     */
+    int32_t dtype;          /* ICV_F32 | ICV_F64 (dtype of `values`)                   */
+    int64_t n_rows;         /* cells                                                   */
+    int32_t n_cols;         /* genes = n_cols_all of the plan                          */
+    int32_t _pad;
+    int64_t ld;             /* dense: row stride in elements (>= n_cols)               */
+    const void *values;     /* dense: n_rows x ld row-major; csr: nnz values           */
+    const int64_t *indptr;  /* csr: n_rows + 1                                         */
+    const int32_t *indices; /* csr: nnz column indices (any order within a row)        */
+} icv_matrix;
+
+typedef struct icv_plan_s *icv_plan_t;
+
+typedef struct {
+    int32_t n_cols_all;   /* columns of the input matrix                               */
+    int32_t n_genes_used; /* columns that fall in a window-bearing chromosome          */
+    int32_t n_chr;
+    int32_t window;
+    int32_t step;
+    int32_t n_windows;    /* W = sum_c W_c  (reference :218, :227-236)                  */
+    int32_t block;        /* B: genes per partial-sum block (1 = direct form)          */
+    int32_t n_blocks;     /* padded blocks over all chromosomes                        */
+    int32_t padded_len;   /* LDS row length in elements                                */
+    int32_t lds_bytes_f32;/* dynamic LDS per workgroup for float32 input               */
+    int32_t lds_bytes_f64;
+    int32_t workgroups_per_cu_f32;
+} icv_plan_info;
+
+/* ---- planning (host only, no GPU needed) -------------------------------------------------
+ * Gene/position indexing contract (reference :327, :350-351): the caller sorts the genes of
+ * every window-bearing chromosome by `start` and concatenates chromosomes in natural order.
+ *   h_col_pos[g]      position of input column g in that concatenation, or -1 if the column is
+ *                     masked (no position / excluded chromosome / chrM / non-"chr" contig)
+ *   h_chrom_offsets   n_chr + 1 offsets into the concatenation
+ * The library derives the window table: per chromosome with G_c genes,
+ *   window < G_c : W_c = ceil((G_c - window + 1) / step) pyramid windows  (:205-218)
+ *   otherwise    : one flat window over all G_c genes                     (:227-236)
+ */
+int icv_plan_create(int32_t n_cols_all, const int32_t *h_col_pos, int32_t n_chr,
+                    const int32_t *h_chrom_offsets, int32_t window, int32_t step, icv_plan_t *out);
+void icv_plan_destroy(icv_plan_t plan);
+int icv_plan_get_info(icv_plan_t plan, icv_plan_info *h_info);
+/* first window index of every chromosome = the values of uns["cnv"]["chr_pos"] (:335-337) */
+int icv_plan_chr_pos(icv_plan_t plan, int32_t *h_chr_pos /* n_chr */);
+/* window table in sorted-gene coordinates: window j covers [start, start+len) */
+int icv_plan_window_table(icv_plan_t plan, int32_t *h_start /* W */, int32_t *h_len /* W */);
+
+/* ---- reference profile (reference :385, :400) --------------------------------------------
+ * Per-group column sums in float64.  h/d: `row_group` (device, n_rows int32; -1 = row not in
+ * any group; NULL = every row in group 0).  `sums` (device, n_groups x n_cols float64) is
+ * ACCUMULATED into, so shards / ranks can add up before the caller divides by the counts.
+ * Dense sums are deterministic (fixed reduction tree); CSR sums use float64 atomics.
+ */
+int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, double *sums,
+               void *stream);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * Steps 1-4 of `_infercnv_chunk` (:422-442) for every row of `m`, fused in one kernel:
+ *   centre on the reference (ref_hi == NULL: x - ref_lo; else bounded difference),
+ *   clip to +-lfc_clip in the matrix dtype, pyramid/flat windowed mean per chromosome in
+ *   float64, subtract the per-cell median over all W windows.
+ * Outputs (device):
+ *   out         n_rows x ldo float32, un-thresholded x_res
+ *   cell_median n_rows float64
+ *   cell_stats  n_rows x 2 float64: sum(x_res), sum(x_res^2) of the row (for the chunk std)
+ * `ref_lo`/`ref_hi`: n_cols values of the matrix dtype, in input column order.
+ */
+int icv_infercnv_smooth(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                        double lfc_clip, int32_t flags, float *out, int64_t ldo, double *cell_median,
+                        double *cell_stats, void *stream);
+
+/* Step 5a (:450): thr[k] = dynamic_threshold * population-std over chunk k, where chunk k is rows
+ * [k*chunksize - row_phase, ...) of this shard (row_phase = global index of the shard's first row
+ * modulo chunksize; 0 when shards are chunk-aligned).  `thr` device float64[n_chunks]. */
+int icv_chunk_thresholds(const double *cell_stats, int64_t n_rows, int64_t chunksize, int64_t row_phase,
+                         int32_t n_windows, double dynamic_threshold, double *thr, void *stream);
+
+/* Step 5b (:451): out[|x| < thr[chunk(row)]] = 0, decided in float64: an entry whose float32
+ * value ties with float32(thr) is recomputed from the input in float64 before deciding. */
+int icv_apply_threshold(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                        double lfc_clip, int32_t flags, float *out, int64_t ldo,
+                        const double *cell_median, const double *thr, int64_t chunksize,
+                        int64_t row_phase, void *stream);
+
+/* Timings of the last icv_infercnv_run with profiling enabled (milliseconds, HIP events
+ * recorded on `stream`). */
+typedef struct {
+    float smooth_ms;
+    float thresholds_ms;
+    float apply_ms;
+    float total_ms;
+} icv_profile;
+
+/* Convenience: smooth -> chunk thresholds -> apply, on one stream.  `dynamic_threshold` NaN
+ * disables step 5 (reference: None).  `thr` may be NULL only when step 5 is disabled.
+ * If `h_profile` is non-NULL the call records HIP events around each stage, synchronises the
+ * stream before returning and fills the struct. */
+int icv_infercnv_run(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                     double lfc_clip, double dynamic_threshold, int64_t chunksize, int64_t row_phase,
+                     int32_t flags, float *out, int64_t ldo, double *cell_median, double *cell_stats,
+                     double *thr, icv_profile *h_profile, void *stream);
+
+/* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
+int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
+                    void *stream);
+
+/* ---- misc --------------------------------------------------------------------------------- */
+const char *icv_last_error(void);
+int icv_version(void);
+/* number of visible HIP devices (0 without a GPU); never fails */
+int icv_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFERCNV_HIP_H */

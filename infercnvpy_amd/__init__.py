@@ -1,0 +1,10 @@
+"""MI355X-native CNV inference behind infercnvpy's scanpy-style tool API.
+
+    import infercnvpy_amd as cnv
+    cnv.tl.infercnv(adata, reference_key="cell_type", reference_cat=[...])
+    cnv.tl.cnv_score(adata, "cnv_leiden")
+    cnv.pl.chromosome_heatmap(adata, groupby="cell_type")
+"""
+from . import pl, tl  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,170 @@
+"""Device-side execution of the hot path through the C ABI.
+
+PyTorch is used only as plumbing: HBM allocation, H2D/D2H copies and streams.  Every numeric
+step runs in ``libinfercnv_hip.so``.  There is no CPU fallback: without a GPU (or without the
+built library) the functions here raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._plan import GenePlan
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("infercnvpy_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    return torch
+
+
+def _stream_ptr(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+
+class DeviceMatrix:
+    """A cells x genes matrix resident in HBM (dense row-major or CSR), float32 or float64."""
+
+    def __init__(self, *, dense=None, indptr=None, indices=None, data=None, shape=None):
+        torch = _torch()
+        if dense is not None:
+            assert dense.is_cuda and dense.dim() == 2 and dense.stride(1) == 1
+            assert dense.dtype in (torch.float32, torch.float64)
+            self.format = _lib.ICV_DENSE
+            self.dense = dense
+            self.shape = tuple(dense.shape)
+            self.dtype = dense.dtype
+            self._keep = (dense,)
+        else:
+            assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
+            assert data.dtype in (torch.float32, torch.float64)
+            self.format = _lib.ICV_CSR
+            self.indptr, self.indices, self.data = indptr, indices, data
+            self.shape = tuple(shape)
+            self.dtype = data.dtype
+            self._keep = (indptr, indices, data)
+
+    def c_struct(self, row0=0, row1=None):
+        """icv_matrix for rows [row0, row1)."""
+        torch = _torch()
+        n = self.shape[0]
+        row1 = n if row1 is None else row1
+        m = _lib.Matrix()
+        m.format = self.format
+        m.dtype = _lib.ICV_F32 if self.dtype == torch.float32 else _lib.ICV_F64
+        m.n_rows = row1 - row0
+        m.n_cols = self.shape[1]
+        esz = 4 if self.dtype == torch.float32 else 8
+        if self.format == _lib.ICV_DENSE:
+            m.ld = self.dense.stride(0)
+            m.values = self.dense.data_ptr() + row0 * self.dense.stride(0) * esz
+        else:
+            m.ld = 0
+            m.values = self.data.data_ptr()
+            m.indptr = self.indptr.data_ptr() + 8 * row0  # absolute offsets into indices/values
+            m.indices = self.indices.data_ptr()
+        return m
+
+
+def to_device_matrix(X, dtype=None, device="cuda"):
+    """numpy ndarray / scipy sparse -> DeviceMatrix (host data are copied once)."""
+    torch = _torch()
+    if isinstance(X, DeviceMatrix):
+        return X
+    if isinstance(X, torch.Tensor):
+        if dtype is not None and X.dtype != dtype:
+            X = X.to(dtype)
+        return DeviceMatrix(dense=X.to(device).contiguous())
+    np_dtype = {None: None, torch.float32: np.float32, torch.float64: np.float64}[dtype]
+    if sp.issparse(X):
+        X = X.tocsr()
+        if not X.has_canonical_format:
+            X = X.copy()
+            X.sum_duplicates()
+        data = X.data if np_dtype is None else X.data.astype(np_dtype, copy=False)
+        return DeviceMatrix(
+            indptr=torch.from_numpy(X.indptr.astype(np.int64)).to(device),
+            indices=torch.from_numpy(X.indices.astype(np.int32)).to(device),
+            data=torch.from_numpy(np.ascontiguousarray(data)).to(device),
+            shape=X.shape,
+        )
+    if isinstance(X, np.matrix):
+        X = np.asarray(X)
+    X = np.ascontiguousarray(X if np_dtype is None else X.astype(np_dtype, copy=False))
+    return DeviceMatrix(dense=torch.from_numpy(X).to(device))
+
+
+def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None):
+    """float64 per-group column sums, accumulated into ``sums`` (device n_groups x n_cols)."""
+    torch = _torch()
+    lib = _lib.load()
+    if sums is None:
+        sums = torch.zeros((n_groups, dm.shape[1]), dtype=torch.float64, device="cuda")
+    rg = None
+    if row_group is not None:
+        rg = torch.as_tensor(np.asarray(row_group, dtype=np.int32)).to("cuda")
+    m = dm.c_struct()
+    _lib.check(lib.icv_colsum(C.byref(m), _ptr(rg), n_groups, _ptr(sums), _stream_ptr(torch)))
+    return sums
+
+
+class SmoothResult:
+    def __init__(self, out, cell_median, cell_stats, thr, profile):
+        self.out = out                  # device float32 C x W (thresholded x_res)
+        self.cell_median = cell_median  # device float64 C
+        self.cell_stats = cell_stats    # device float64 C x 2
+        self.thr = thr                  # device float64 n_chunks | None
+        self.profile = profile
+
+
+def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,
+                 chunksize=5000, row_phase=0, flags=0, out=None, profile=False, row0=0, row1=None):
+    """Steps 1-5 of the chunk kernel for rows [row0, row1) of ``dm`` (all device-resident)."""
+    torch = _torch()
+    lib = _lib.load()
+    n = dm.shape[0]
+    row1 = n if row1 is None else row1
+    rows = row1 - row0
+    W = plan.n_windows
+    if out is None:
+        out = torch.empty((rows, W), dtype=torch.float32, device="cuda")
+    assert out.dtype == torch.float32 and out.shape[0] >= rows and out.shape[1] >= W and out.stride(1) == 1
+    med = torch.empty(rows, dtype=torch.float64, device="cuda")
+    stats = torch.empty((rows, 2), dtype=torch.float64, device="cuda")
+    dyn = float("nan") if dynamic_threshold is None else float(dynamic_threshold)
+    thr = None
+    if dynamic_threshold is not None:
+        n_chunks = max(1, math.ceil((rows + row_phase) / chunksize))
+        thr = torch.empty(n_chunks, dtype=torch.float64, device="cuda")
+    assert ref_lo.dtype == dm.dtype and ref_lo.is_cuda and ref_lo.numel() == dm.shape[1]
+    if ref_hi is not None:
+        assert ref_hi.dtype == dm.dtype and ref_hi.is_cuda and ref_hi.numel() == dm.shape[1]
+    m = dm.c_struct(row0, row1)
+    prof = _lib.Profile() if profile else None
+    _lib.check(lib.icv_infercnv_run(
+        plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), dyn, int(chunksize), int(row_phase),
+        int(flags), _ptr(out), out.stride(0), _ptr(med), _ptr(stats), _ptr(thr),
+        C.byref(prof) if prof is not None else None, _stream_ptr(torch)))
+    return SmoothResult(out, med, stats, thr, prof)
+
+
+def row_abs_sum(x_cnv):
+    """per-row sum |x| of a device float32 matrix (cnv_score building block)."""
+    torch = _torch()
+    lib = _lib.load()
+    assert x_cnv.is_cuda and x_cnv.dtype == torch.float32 and x_cnv.stride(1) == 1
+    res = torch.empty(x_cnv.shape[0], dtype=torch.float64, device="cuda")
+    _lib.check(lib.icv_row_abs_sum(_ptr(x_cnv), x_cnv.shape[0], x_cnv.shape[1], x_cnv.stride(0), _ptr(res),
+                                   _stream_ptr(torch)))
+    return res

@@ -1,0 +1,107 @@
+"""ctypes binding of ``libinfercnv_hip.so`` (the C ABI in ``include/infercnv_hip.h``).
+
+The product path has NO CPU fallback: if the shared library is missing, or a compute entry
+point is called without a GPU, this module raises.  ``load()`` itself works on a GPU-less host
+(hipcc cross-compiles; the HIP runtime loads without a device), which lets the planning entry
+points -- pure host code -- be exercised by the CPU test-suite.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libinfercnv_hip.so")
+
+ICV_OK, ICV_ERR_INVALID, ICV_ERR_UNSUPPORTED, ICV_ERR_HIP, ICV_ERR_NOMEM = range(5)
+ICV_F32, ICV_F64 = 0, 1
+ICV_DENSE, ICV_CSR = 0, 1
+ICV_FLAG_TRUNC_TO_INT = 1
+ICV_FLAG_ROUND_F32 = 2
+
+# every symbol include/infercnv_hip.h declares
+EXPORTS = (
+    "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
+    "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
+    "icv_row_abs_sum", "icv_last_error", "icv_version", "icv_device_count",
+)
+
+
+class Matrix(C.Structure):
+    _fields_ = [
+        ("format", C.c_int32), ("dtype", C.c_int32), ("n_rows", C.c_int64), ("n_cols", C.c_int32),
+        ("_pad", C.c_int32), ("ld", C.c_int64), ("values", C.c_void_p), ("indptr", C.c_void_p),
+        ("indices", C.c_void_p),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_cols_all", "n_genes_used", "n_chr", "window", "step", "n_windows", "block", "n_blocks", "padded_len",
+        "lds_bytes_f32", "lds_bytes_f64", "workgroups_per_cu_f32")]
+
+
+class Profile(C.Structure):
+    _fields_ = [("smooth_ms", C.c_float), ("thresholds_ms", C.c_float), ("apply_ms", C.c_float),
+                ("total_ms", C.c_float)]
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises HipExtensionMissing if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -m infercnvpy_amd._build` "
+            "(hipcc --offload-arch=gfx950).  infercnvpy_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    i32, i64, vp, dbl = C.c_int32, C.c_int64, C.c_void_p, C.c_double
+    P = C.POINTER
+    lib.icv_plan_create.argtypes = [i32, vp, i32, vp, i32, i32, P(vp)]
+    lib.icv_plan_destroy.argtypes = [vp]
+    lib.icv_plan_destroy.restype = None
+    lib.icv_plan_get_info.argtypes = [vp, P(PlanInfo)]
+    lib.icv_plan_chr_pos.argtypes = [vp, vp]
+    lib.icv_plan_window_table.argtypes = [vp, vp, vp]
+    lib.icv_colsum.argtypes = [P(Matrix), vp, i32, vp, vp]
+    lib.icv_infercnv_smooth.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, vp]
+    lib.icv_chunk_thresholds.argtypes = [vp, i64, i64, i64, i32, dbl, vp, vp]
+    lib.icv_apply_threshold.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp]
+    lib.icv_infercnv_run.argtypes = [vp, P(Matrix), vp, vp, dbl, dbl, i64, i64, i32, vp, i64, vp, vp, vp,
+                                     P(Profile), vp]
+    lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]
+    lib.icv_last_error.restype = C.c_char_p
+    lib.icv_last_error.argtypes = []
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("icv_plan_destroy", "icv_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    """Map an icv_status to the exception type the reference's Python code raises."""
+    if rc == ICV_OK:
+        return
+    msg = load().icv_last_error().decode("utf-8", "replace")
+    if rc == ICV_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ICV_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ICV_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count() -> int:
+    return int(load().icv_device_count())

@@ -1,0 +1,402 @@
+// C ABI (include/infercnv_hip.h) over the gfx950 kernels.  No torch types, no exceptions across
+// the boundary; all data pointers are device pointers owned by the caller.
+#include "../../include/infercnv_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "icv_kernels.hpp"
+#include "icv_plan.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ICV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorName(e_) + " (" + \
+                                         hipGetErrorString(e_) + ")");                         \
+    } while (0)
+
+}  // namespace
+
+struct icv_plan_s {
+    icv::Plan p;
+    std::mutex mu;
+    int device = -1;
+    int n_cu = 0;
+    int32_t *d_dst = nullptr, *d_src = nullptr, *d_wstart = nullptr, *d_wlen = nullptr;
+    double* d_wdenom = nullptr;
+    void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
+    size_t zrow_elems = 0;
+};
+
+namespace {
+
+int ensure_device(icv_plan_t pl) {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (pl->device == dev) return ICV_OK;
+    if (pl->device >= 0) return fail(ICV_ERR_INVALID, "plan is bound to another device");
+    const icv::Plan& p = pl->p;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    pl->n_cu = prop.multiProcessorCount;
+    auto up = [&](const void* h, size_t bytes, void** d) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    HIP_TRY(up(p.dst.data(), p.dst.size() * 4 + 0, (void**)&pl->d_dst));
+    HIP_TRY(up(p.src.data(), p.src.size() * 4, (void**)&pl->d_src));
+    HIP_TRY(up(p.w_start.data(), p.w_start.size() * 4, (void**)&pl->d_wstart));
+    HIP_TRY(up(p.w_len.data(), p.w_len.size() * 4, (void**)&pl->d_wlen));
+    HIP_TRY(up(p.w_denom.data(), p.w_denom.size() * 8, (void**)&pl->d_wdenom));
+    pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;
+    HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
+    pl->device = dev;
+    return ICV_OK;
+}
+
+int check_matrix(const icv_plan_t pl, const icv_matrix* m) {
+    if (!pl || !m) return fail(ICV_ERR_INVALID, "null plan or matrix");
+    if (m->n_cols != pl->p.n_cols_all)
+        return fail(ICV_ERR_INVALID, "matrix has " + std::to_string(m->n_cols) + " columns, plan expects " +
+                                         std::to_string(pl->p.n_cols_all));
+    if (m->dtype != ICV_F32 && m->dtype != ICV_F64) return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
+    if (m->format != ICV_DENSE && m->format != ICV_CSR) return fail(ICV_ERR_INVALID, "format must be dense or csr");
+    if (m->n_rows < 0) return fail(ICV_ERR_INVALID, "negative n_rows");
+    if (m->n_rows > 0 && !m->values && !(m->format == ICV_CSR)) return fail(ICV_ERR_INVALID, "null values");
+    if (m->format == ICV_DENSE && m->ld < m->n_cols) return fail(ICV_ERR_INVALID, "ld < n_cols");
+    if (m->format == ICV_CSR && (!m->indptr || (!m->indices && m->values)))
+        return fail(ICV_ERR_INVALID, "csr needs indptr and indices");
+    return ICV_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                int32_t flags, float* out, int64_t ldo, double* cell_median, double* cell_stats, icv::KParams& K,
+                const icv::Layout*& lay) {
+    const icv::Plan& p = pl->p;
+    if (!ref_lo) return fail(ICV_ERR_INVALID, "ref_lo is required");
+    if (!(lfc_clip >= 0.0)) return fail(ICV_ERR_INVALID, "lfc_clip must be >= 0");
+    if (!out || ldo < p.W) return fail(ICV_ERR_INVALID, "out is null or ldo < n_windows");
+    lay = (m->dtype == ICV_F32) ? &p.lay32 : &p.lay64;
+    if (!lay->fits)
+        return fail(ICV_ERR_UNSUPPORTED,
+                    "configuration needs " + std::to_string(lay->total) +
+                        " bytes of LDS per workgroup (limit 163840): too many genes/windows for one LDS-resident row");
+    std::memset(&K, 0, sizeof(K));
+    K.values = m->values;
+    K.indptr = m->indptr;
+    K.indices = m->indices;
+    K.n_rows = m->n_rows;
+    K.ld = m->ld;
+    K.n_cols = m->n_cols;
+    const int vn = (m->dtype == ICV_F32) ? 4 : 2;
+    K.vec_ok = (m->format == ICV_DENSE) && aligned16(m->values) && aligned16(ref_lo) &&
+               (!ref_hi || aligned16(ref_hi)) && (m->ld % vn == 0);
+    K.ref_lo = ref_lo;
+    K.ref_hi = ref_hi;
+    K.zrow = pl->d_zrow;
+    K.bounded = ref_hi != nullptr;
+    K.trunc = flags & (ICV_FLAG_TRUNC_TO_INT | ICV_FLAG_ROUND_F32);
+    K.cap = lfc_clip;
+    K.dst = pl->d_dst;
+    K.src = pl->d_src;
+    K.w_start = pl->d_wstart;
+    K.w_len = pl->d_wlen;
+    K.w_denom = pl->d_wdenom;
+    K.B = p.B;
+    K.NB = p.NB;
+    K.Gp = p.Gp;
+    K.W = p.W;
+    K.win_off = lay->win_off;
+    K.scratch_off = lay->scratch_off;
+    K.out = out;
+    K.ldo = ldo;
+    K.cell_median = cell_median;
+    K.cell_stats = cell_stats;
+    return ICV_OK;
+}
+
+template <typename T, bool CSR>
+int launch_smooth_t(icv_plan_t pl, const icv::KParams& K, const icv::Layout& lay, hipStream_t st) {
+    const icv::Plan& p = pl->p;
+    int maxb = 0;
+    if (p.B > 1) {
+        const int need = (p.NB + icv::kThreads - 1) / icv::kThreads;
+        maxb = need <= 4 ? 4 : 8;
+    }
+    void (*kern)(const icv::KParams) = nullptr;
+    if (maxb == 0) kern = icv::k_smooth<T, CSR, 0>;
+    else if (maxb == 4) kern = icv::k_smooth<T, CSR, 4>;
+    else kern = icv::k_smooth<T, CSR, 8>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lay.total));
+    int per_cu = icv::kLdsLimit / lay.total;
+    if (per_cu > 4) per_cu = 4;  // 32 wavefronts per CU / 8 per workgroup
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)pl->n_cu * per_cu;
+    if (grid > K.n_rows) grid = K.n_rows;
+    if (grid < 1) return ICV_OK;
+    if constexpr (CSR) {
+        const int n = (int)pl->zrow_elems;
+        hipLaunchKernelGGL(icv::k_zero_row<T>, dim3((n + 255) / 256), dim3(256), 0, st, K,
+                           static_cast<T*>(pl->d_zrow), n);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lay.total, st, K);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
+                  hipStream_t st) {
+    if (m->dtype == ICV_F32)
+        return m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, lay, st)
+                                      : launch_smooth_t<float, true>(pl, K, lay, st);
+    return m->format == ICV_DENSE ? launch_smooth_t<double, false>(pl, K, lay, st)
+                                  : launch_smooth_t<double, true>(pl, K, lay, st);
+}
+
+int launch_apply(const icv_matrix* m, const icv::KParams& K, const double* thr, int64_t chunksize,
+                 int64_t row_phase, hipStream_t st) {
+    if (K.n_rows < 1) return ICV_OK;
+    dim3 grid((unsigned)K.n_rows), block(256);
+    if (m->dtype == ICV_F32) {
+        if (m->format == ICV_DENSE)
+            hipLaunchKernelGGL((icv::k_apply_thr<float, false>), grid, block, 0, st, K, thr, chunksize, row_phase);
+        else
+            hipLaunchKernelGGL((icv::k_apply_thr<float, true>), grid, block, 0, st, K, thr, chunksize, row_phase);
+    } else {
+        if (m->format == ICV_DENSE)
+            hipLaunchKernelGGL((icv::k_apply_thr<double, false>), grid, block, 0, st, K, thr, chunksize, row_phase);
+        else
+            hipLaunchKernelGGL((icv::k_apply_thr<double, true>), grid, block, 0, st, K, thr, chunksize, row_phase);
+    }
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* icv_last_error(void) { return g_err.c_str(); }
+int icv_version(void) { return 100; }
+
+int icv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int icv_plan_create(int32_t n_cols_all, const int32_t* h_col_pos, int32_t n_chr, const int32_t* h_chrom_offsets,
+                    int32_t window, int32_t step, icv_plan_t* out) {
+    if (!h_col_pos || !h_chrom_offsets || !out) return fail(ICV_ERR_INVALID, "null argument");
+    icv_plan_s* pl = new (std::nothrow) icv_plan_s();
+    if (!pl) return fail(ICV_ERR_NOMEM, "out of host memory");
+    std::string err;
+    try {
+        err = icv::build_plan(pl->p, n_cols_all, h_col_pos, n_chr, h_chrom_offsets, window, step);
+    } catch (const std::bad_alloc&) {
+        delete pl;
+        return fail(ICV_ERR_NOMEM, "out of host memory");
+    }
+    if (!err.empty()) {
+        delete pl;
+        return fail(ICV_ERR_INVALID, err);
+    }
+    *out = pl;
+    return ICV_OK;
+}
+
+void icv_plan_destroy(icv_plan_t pl) {
+    if (!pl) return;
+    if (pl->device >= 0) {
+        (void)hipFree(pl->d_dst);
+        (void)hipFree(pl->d_src);
+        (void)hipFree(pl->d_wstart);
+        (void)hipFree(pl->d_wlen);
+        (void)hipFree(pl->d_wdenom);
+        (void)hipFree(pl->d_zrow);
+    }
+    delete pl;
+}
+
+int icv_plan_get_info(icv_plan_t pl, icv_plan_info* info) {
+    if (!pl || !info) return fail(ICV_ERR_INVALID, "null argument");
+    const icv::Plan& p = pl->p;
+    info->n_cols_all = p.n_cols_all;
+    info->n_genes_used = p.n_used;
+    info->n_chr = p.n_chr;
+    info->window = p.window;
+    info->step = p.step;
+    info->n_windows = p.W;
+    info->block = p.B;
+    info->n_blocks = p.NB;
+    info->padded_len = p.Gp;
+    info->lds_bytes_f32 = p.lay32.total;
+    info->lds_bytes_f64 = p.lay64.total;
+    int per_cu = p.lay32.fits ? icv::kLdsLimit / p.lay32.total : 0;
+    info->workgroups_per_cu_f32 = per_cu > 4 ? 4 : per_cu;
+    return ICV_OK;
+}
+
+int icv_plan_chr_pos(icv_plan_t pl, int32_t* h_chr_pos) {
+    if (!pl || !h_chr_pos) return fail(ICV_ERR_INVALID, "null argument");
+    std::memcpy(h_chr_pos, pl->p.chr_pos.data(), pl->p.chr_pos.size() * sizeof(int32_t));
+    return ICV_OK;
+}
+
+int icv_plan_window_table(icv_plan_t pl, int32_t* h_start, int32_t* h_len) {
+    if (!pl || !h_start || !h_len) return fail(ICV_ERR_INVALID, "null argument");
+    std::memcpy(h_start, pl->p.w_start_sorted.data(), pl->p.W * sizeof(int32_t));
+    std::memcpy(h_len, pl->p.w_len_sorted.data(), pl->p.W * sizeof(int32_t));
+    return ICV_OK;
+}
+
+int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, double* sums, void* stream) {
+    if (!m || !sums || n_groups < 1) return fail(ICV_ERR_INVALID, "bad colsum arguments");
+    if (m->n_rows == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nc = m->n_cols;
+    if (m->format == ICV_CSR) {
+        dim3 grid((unsigned)((m->n_rows + 3) / 4)), block(256);
+        if (m->dtype == ICV_F32)
+            hipLaunchKernelGGL(icv::k_colsum_csr<float>, grid, block, 0, st, (const float*)m->values, m->indptr,
+                               m->indices, m->n_rows, nc, row_group, sums);
+        else
+            hipLaunchKernelGGL(icv::k_colsum_csr<double>, grid, block, 0, st, (const double*)m->values, m->indptr,
+                               m->indices, m->n_rows, nc, row_group, sums);
+        HIP_TRY(hipGetLastError());
+        return ICV_OK;
+    }
+    const int rows_per_slab = 256;
+    const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
+    double* partial = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&partial, (size_t)n_slabs * nc * sizeof(double), st));
+    dim3 grid((nc + 255) / 256, (unsigned)n_slabs), block(256);
+    for (int g = 0; g < n_groups; ++g) {
+        if (m->dtype == ICV_F32)
+            hipLaunchKernelGGL(icv::k_colsum_dense<float>, grid, block, 0, st, (const float*)m->values, m->n_rows,
+                               m->ld, nc, row_group, g, rows_per_slab, partial);
+        else
+            hipLaunchKernelGGL(icv::k_colsum_dense<double>, grid, block, 0, st, (const double*)m->values,
+                               m->n_rows, m->ld, nc, row_group, g, rows_per_slab, partial);
+        hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 255) / 256), block, 0, st, partial, (int)n_slabs, nc,
+                           sums + (int64_t)g * nc);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(partial, st));
+    return ICV_OK;
+}
+
+int icv_infercnv_smooth(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi,
+                        double lfc_clip, int32_t flags, float* out, int64_t ldo, double* cell_median,
+                        double* cell_stats, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    if (!cell_median || !cell_stats) return fail(ICV_ERR_INVALID, "cell_median and cell_stats are required");
+    if ((rc = ensure_device(pl))) return rc;
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
+        return rc;
+    return launch_smooth(pl, m, K, *lay, static_cast<hipStream_t>(stream));
+}
+
+int icv_chunk_thresholds(const double* cell_stats, int64_t n_rows, int64_t chunksize, int64_t row_phase,
+                         int32_t n_windows, double dynamic_threshold, double* thr, void* stream) {
+    if (!cell_stats || !thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize)
+        return fail(ICV_ERR_INVALID, "bad chunk threshold arguments");
+    if (n_rows < 1) return ICV_OK;
+    const int64_t n_chunks = (n_rows + row_phase + chunksize - 1) / chunksize;
+    hipLaunchKernelGGL(icv::k_chunk_thr, dim3((unsigned)n_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       cell_stats, n_rows, chunksize, row_phase, n_windows, dynamic_threshold, thr);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_apply_threshold(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi,
+                        double lfc_clip, int32_t flags, float* out, int64_t ldo, const double* cell_median,
+                        const double* thr, int64_t chunksize, int64_t row_phase, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    if (!cell_median || !thr || chunksize < 1) return fail(ICV_ERR_INVALID, "bad apply_threshold arguments");
+    if ((rc = ensure_device(pl))) return rc;
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, const_cast<double*>(cell_median),
+                          nullptr, K, lay)))
+        return rc;
+    return launch_apply(m, K, thr, chunksize, row_phase, static_cast<hipStream_t>(stream));
+}
+
+int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                     double dynamic_threshold, int64_t chunksize, int64_t row_phase, int32_t flags, float* out,
+                     int64_t ldo, double* cell_median, double* cell_stats, double* thr, icv_profile* prof,
+                     void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    const bool do_thr = !std::isnan(dynamic_threshold);
+    if (!cell_median || !cell_stats) return fail(ICV_ERR_INVALID, "cell_median and cell_stats are required");
+    if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
+        return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");
+    if ((rc = ensure_device(pl))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
+        return rc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (prof) {
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(ev[0], st));
+    }
+    if ((rc = launch_smooth(pl, m, K, *lay, st))) return rc;
+    if (prof) HIP_TRY(hipEventRecord(ev[1], st));
+    if (do_thr) {
+        rc = icv_chunk_thresholds(cell_stats, m->n_rows, chunksize, row_phase, pl->p.W, dynamic_threshold, thr,
+                                  stream);
+        if (rc) return rc;
+    }
+    if (prof) HIP_TRY(hipEventRecord(ev[2], st));
+    if (do_thr && (rc = launch_apply(m, K, thr, chunksize, row_phase, st))) return rc;
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[3], st));
+        HIP_TRY(hipEventSynchronize(ev[3]));
+        HIP_TRY(hipEventElapsedTime(&prof->smooth_ms, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&prof->thresholds_ms, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&prof->apply_ms, ev[2], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&prof->total_ms, ev[0], ev[3]));
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return ICV_OK;
+}
+
+int icv_row_abs_sum(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, double* row_sum, void* stream) {
+    if (!x || !row_sum || n_cols < 0 || ld < n_cols) return fail(ICV_ERR_INVALID, "bad row_abs_sum arguments");
+    if (n_rows < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_row_abs_sum, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld, row_sum);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+}  // extern "C"

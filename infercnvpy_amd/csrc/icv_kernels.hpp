@@ -1,0 +1,644 @@
+// CDNA4 (gfx950) kernels of the CNV-inference hot path.  Wavefront = 64 lanes.
+//
+// k_smooth: one 512-thread workgroup (8 wavefronts) owns one cell at a time and walks the
+// cells of its shard persistently.  Per cell:
+//   L  coalesced 16-byte HBM loads of the cell's expression row (input column order);
+//      centre on the reference + clip in the matrix dtype; scatter through the plan's
+//      column->position table into the LDS row (chromosome-sorted, block-padded order)
+//   S  per block of B consecutive genes: S0 = sum v, S1 = sum r*v (float64, registers),
+//      then stored over the (dead) row                                   [B > 1 only]
+//   W  every window = sum over its blocks of (a_m*S0 +- S1) / sum(weights)  (pyramid),
+//      or sum S0 / G_c (flat small-chromosome window); float64, into LDS
+//   M  per-cell median over all W windows: value-space bisection on the LDS-resident
+//      windows with workgroup-wide counts, exact rank resolution of the last <= 64
+//      candidates
+//   O  x_res = window - median -> float32 coalesced store; per-cell sum / sum of squares
+// The path is HBM-bound (reads 4*G + writes 4*W bytes per cell); no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace icv {
+
+constexpr int NT = 512;
+constexpr int NWAVE = NT / 64;
+
+struct KParams {
+    // input matrix
+    const void* values;
+    const int64_t* indptr;
+    const int32_t* indices;
+    int64_t n_rows;
+    int64_t ld;
+    int32_t n_cols;
+    int32_t vec_ok;  // dense: 16-byte vector loads allowed (alignment + ld)
+    // reference, matrix dtype, input column order; bounded == 0: ref_hi unused
+    const void* ref_lo;
+    const void* ref_hi;
+    const void* zrow;  // CSR: padded row of centre_clip(0) values (matrix dtype)
+    int32_t bounded;
+    int32_t trunc;
+    double cap;
+    // plan tables (device)
+    const int32_t* dst;  // n_cols: padded position or -1
+    const int32_t* src;  // Gp: input column or -1
+    const int32_t* w_start;
+    const int32_t* w_len;
+    const double* w_denom;
+    int32_t B, NB, Gp, W;
+    int32_t win_off, scratch_off;
+    // outputs
+    float* out;
+    int64_t ldo;
+    double* cell_median;
+    double* cell_stats;
+};
+
+struct Scratch {
+    double dred[3][2][NWAVE];  // [stage: 0 min/max, 1 second-middle, 2 moments][slot][wave]
+    int ired[2][NWAVE];
+    int ncand;
+    int flag;
+    double cand[64];
+    double sel;
+};
+static_assert(sizeof(Scratch) <= 1024, "Scratch must fit kScratchBytes");
+
+// ---------------------------------------------------------------------------------------
+// element-wise step 1 + 2 (reference :422-436), in the matrix dtype T
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T centre_clip(T x, T lo, T hi, T cap, int bounded, int trunc_int) {
+    T v;
+    if (!bounded) {
+        v = x - lo;
+    } else {
+        v = T(0);
+        if (x > hi) v = x - hi;
+        else if (x < lo) v = x - lo;
+        if (trunc_int & 1) v = (T)trunc((double)v);
+        if (trunc_int & 2) v = (T)(float)v;
+    }
+    v = v < -cap ? -cap : v;  // np.clip == minimum(maximum(v, -cap), cap); NaN stays NaN
+    v = v > cap ? cap : v;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// canonical float64 evaluation order of one window.  Used by the smoothing kernel (values
+// from LDS) and by the exact tie-break of the threshold kernel (values re-read from HBM):
+// both must produce bit-identical results.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_accumulate(double v, int r, double& s0, double& s1) {
+    s0 = s0 + v;
+    s1 = fma((double)r, v, s1);
+}
+
+template <typename F>  // F(m, &S0, &S1): partial sums of block m of the window
+__device__ __forceinline__ double window_from_blocks(int len, int B, double denom, F blk) {
+    double acc = 0.0;
+    if (len > 0) {
+        const int nb = len / B, hb = nb / 2;
+        for (int m = 0; m < nb; ++m) {
+            double S0, S1;
+            blk(m, S0, S1);
+            if (m < hb) {
+                acc = fma((double)(m * B + 1), S0, acc);
+                acc = acc + S1;
+            } else {
+                acc = fma((double)(len - m * B), S0, acc);
+                acc = acc - S1;
+            }
+        }
+    } else {
+        const int nb = (-len) / B;
+        for (int m = 0; m < nb; ++m) {
+            double S0, S1;
+            blk(m, S0, S1);
+            acc = acc + S0;
+        }
+    }
+    return acc / denom;
+}
+
+template <typename F>  // F(k): clipped value k of the window as double
+__device__ __forceinline__ double window_direct(int len, double denom, F val) {
+    double acc = 0.0;
+    if (len > 0) {
+        for (int k = 0; k < len; ++k) {
+            int w = (k + 1 < len - k) ? (k + 1) : (len - k);
+            acc = fma((double)w, val(k), acc);
+        }
+    } else {
+        for (int k = 0; k < -len; ++k) acc = acc + val(k);
+    }
+    return acc / denom;
+}
+
+// ---------------------------------------------------------------------------------------
+// wavefront / workgroup reductions (64-lane)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// workgroup-wide sum of an int; `par` alternates between consecutive calls (no WAR hazard)
+__device__ __forceinline__ int wg_sum_i(int v, Scratch* sc, int par) {
+    v = wave_sum_i(v);
+    if ((threadIdx.x & 63) == 0) sc->ired[par][threadIdx.x >> 6] = v;
+    __syncthreads();
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVE; ++i) s += sc->ired[par][i];
+    return s;
+}
+
+__device__ __forceinline__ double prev_double(double x) {
+    // largest double strictly below finite x
+    if (x == 0.0) return -4.9406564584124654e-324;
+    long long b = __double_as_longlong(x);
+    b += (x > 0.0) ? -1 : 1;
+    return __longlong_as_double(b);
+}
+__device__ __forceinline__ unsigned long long ordered_key(double x) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double from_ordered_key(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// ---------------------------------------------------------------------------------------
+// the fused smoothing kernel
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; using itype = int4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; using itype = int2; static constexpr int N = 2; };
+
+template <typename T>
+__device__ __forceinline__ T vget(const typename Vec16<T>::type& v, int i);
+template <> __device__ __forceinline__ float vget<float>(const float4& v, int i) {
+    return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+template <> __device__ __forceinline__ double vget<double>(const double2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ int iget(const int4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ int iget(const int2& v, int i) { return i == 0 ? v.x : v.y; }
+
+template <typename T, bool CSR, int MAXB /* 0 = direct form */>
+__global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* row = reinterpret_cast<T*>(smem);
+    double* S01 = reinterpret_cast<double*>(smem);
+    double* win = reinterpret_cast<double*>(smem + P.win_off);
+    Scratch* sc = reinterpret_cast<Scratch*>(smem + P.scratch_off);
+
+    using V = typename Vec16<T>::type;
+    using IV = typename Vec16<T>::itype;
+    constexpr int VN = Vec16<T>::N;
+    constexpr int U = 4;  // 16-byte loads kept in flight per lane per batch
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const T cap = (T)P.cap;
+    const T* ref_lo = static_cast<const T*>(P.ref_lo);
+    const T* ref_hi = P.bounded ? static_cast<const T*>(P.ref_hi) : ref_lo;
+    const int W = P.W, B = P.B, NB = P.NB;
+
+    // pad slots of the row are never written by the scatter: zero them once (direct form, no
+    // aliasing) or after every cell (blocked form, the aliased S01/win overwrite them).
+    for (int i = t; i < P.Gp; i += NT)
+        if (P.src[i] < 0) row[i] = T(0);
+    __syncthreads();
+
+    for (int64_t cell = blockIdx.x; cell < P.n_rows; cell += gridDim.x) {
+        // ---------------- L: load, centre, clip, scatter --------------------------------
+        if constexpr (!CSR) {
+            const T* xrow = static_cast<const T*>(P.values) + cell * P.ld;
+            int done = 0;
+            if (P.vec_ok) {
+                const int nvec = P.n_cols / VN;
+                const V* xv = reinterpret_cast<const V*>(xrow);
+                const IV* dv = reinterpret_cast<const IV*>(P.dst);
+                const V* lov = reinterpret_cast<const V*>(ref_lo);
+                const V* hiv = reinterpret_cast<const V*>(ref_hi);
+                for (int base = 0; base < nvec; base += NT * U) {
+                    V x[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int i = base + u * NT + t;
+                        if (i < nvec) x[u] = xv[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        int i = base + u * NT + t;
+                        if (i < nvec) {
+                            IV d = dv[i];
+                            V lo = lov[i];
+                            V hi = hiv[i];
+#pragma unroll
+                            for (int e = 0; e < VN; ++e) {
+                                int q = iget(d, e);
+                                if (q >= 0)
+                                    row[q] = centre_clip<T>(vget<T>(x[u], e), vget<T>(lo, e), vget<T>(hi, e), cap,
+                                                            P.bounded, P.trunc);
+                            }
+                        }
+                    }
+                }
+                done = nvec * VN;
+            }
+            for (int g = done + t; g < P.n_cols; g += NT) {
+                int q = P.dst[g];
+                if (q >= 0) row[q] = centre_clip<T>(xrow[g], ref_lo[g], ref_hi[g], cap, P.bounded, P.trunc);
+            }
+        } else {
+            // implicit zeros are not zero after centring: start from clip(centre(0)) ...
+            const V* zv = reinterpret_cast<const V*>(P.zrow);
+            V* rv = reinterpret_cast<V*>(row);
+            const int nvec = (P.Gp + VN - 1) / VN;
+            for (int i = t; i < nvec; i += NT) rv[i] = zv[i];
+            __syncthreads();
+            // ... then overwrite the stored entries
+            const int64_t s = P.indptr[cell], e = P.indptr[cell + 1];
+            const T* vals = static_cast<const T*>(P.values);
+            for (int64_t k = s + t; k < e; k += NT) {
+                int g = P.indices[k];
+                int q = P.dst[g];
+                if (q >= 0) row[q] = centre_clip<T>(vals[k], ref_lo[g], ref_hi[g], cap, P.bounded, P.trunc);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- S + W: block partial sums, windows ----------------------------
+        double lmin = __builtin_inf(), lmax = -__builtin_inf();
+        int lnan = 0;
+        if constexpr (MAXB > 0) {
+            double s0[MAXB], s1[MAXB];
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                s0[i] = 0.0;
+                s1[i] = 0.0;
+                const int b = t + i * NT;
+                if (b < NB) {
+                    const T* rp = row + b * B;
+                    for (int r = 0; r < B; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
+                }
+            }
+            __syncthreads();  // every read of the row is done: alias it
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int b = t + i * NT;
+                if (b < NB) {
+                    S01[2 * b] = s0[i];
+                    S01[2 * b + 1] = s1[i];
+                }
+            }
+            __syncthreads();
+            for (int j = t; j < W; j += NT) {
+                const int st = P.w_start[j], ln = P.w_len[j];
+                const double* sp = S01 + 2 * (st / B);
+                double v = window_from_blocks(ln, B, P.w_denom[j], [&](int m, double& a, double& b2) {
+                    a = sp[2 * m];
+                    b2 = sp[2 * m + 1];
+                });
+                win[j] = v;
+                lmin = v < lmin ? v : lmin;
+                lmax = v > lmax ? v : lmax;
+                lnan |= (v != v);
+            }
+        } else {
+            for (int j = t; j < W; j += NT) {
+                const int st = P.w_start[j], ln = P.w_len[j];
+                const T* rp = row + st;
+                double v = window_direct(ln, P.w_denom[j], [&](int k) { return (double)rp[k]; });
+                win[j] = v;
+                lmin = v < lmin ? v : lmin;
+                lmax = v > lmax ? v : lmax;
+                lnan |= (v != v);
+            }
+        }
+        lmin = wave_min(lmin);
+        lmax = wave_max(lmax);
+        if (lane == 0) {
+            sc->dred[0][0][wave] = lmin;
+            sc->dred[0][1][wave] = lmax;
+        }
+        const int anynan = __syncthreads_or(lnan);  // also publishes win[] and dred
+
+        // ---------------- M: median over all W windows (np.median, reference :442) ------
+        double med;
+        if (anynan) {
+            med = __builtin_nan("");
+        } else {
+            double gmin = sc->dred[0][0][0], gmax = sc->dred[0][1][0];
+#pragma unroll
+            for (int i = 1; i < NWAVE; ++i) {
+                double a = sc->dred[0][0][i], b = sc->dred[0][1][i];
+                gmin = a < gmin ? a : gmin;
+                gmax = b > gmax ? b : gmax;
+            }
+            // order statistic k1 (0-based) lies in (lo, hi]; cnt_x = #{win <= x}
+            double lo = prev_double(gmin), hi = gmax;
+            int cnt_lo = 0, cnt_hi = W;
+            const int k1 = (W - 1) / 2;
+            int it = 0;
+            while (cnt_hi - cnt_lo > 64 && it < 120) {
+                double mid;
+                if (it < 48) {
+                    mid = 0.5 * lo + 0.5 * hi;
+                } else {
+                    unsigned long long a = ordered_key(lo), b = ordered_key(hi);
+                    mid = from_ordered_key(a + ((b - a) >> 1));
+                }
+                if (!(mid > lo && mid < hi)) break;  // adjacent doubles: every candidate == hi
+                int c = 0;
+                for (int j = t; j < W; j += NT) c += (win[j] <= mid) ? 1 : 0;
+                c = wg_sum_i(c, sc, it & 1);
+                if (c > k1) { hi = mid; cnt_hi = c; } else { lo = mid; cnt_lo = c; }
+                ++it;
+            }
+            double a;
+            if (cnt_hi - cnt_lo <= 64) {
+                if (t == 0) sc->ncand = 0;
+                __syncthreads();
+                for (int j = t; j < W; j += NT) {
+                    double x = win[j];
+                    if (x > lo && x <= hi) {
+                        int idx = atomicAdd(&sc->ncand, 1);
+                        if (idx < 64) sc->cand[idx] = x;
+                    }
+                }
+                __syncthreads();
+                if (t < 64) {
+                    const int n = sc->ncand < 64 ? sc->ncand : 64;
+                    const double mine = (t < n) ? sc->cand[t] : 0.0;
+                    int rank = 0;
+                    for (int i = 0; i < n; ++i) {
+                        double o = sc->cand[i];
+                        rank += (o < mine || (o == mine && i < t)) ? 1 : 0;
+                    }
+                    if (t < n && rank == k1 - cnt_lo) sc->sel = mine;
+                }
+                __syncthreads();
+                a = sc->sel;
+            } else {
+                a = hi;
+            }
+            med = a;
+            if ((W & 1) == 0) {
+                // second middle element: a again if it is repeated, else the smallest value above a
+                __syncthreads();  // ired[0] may still be read by the last bisection step
+                int c = 0;
+                double mn = __builtin_inf();
+                for (int j = t; j < W; j += NT) {
+                    double x = win[j];
+                    c += (x <= a) ? 1 : 0;
+                    if (x > a) mn = x < mn ? x : mn;
+                }
+                mn = wave_min(mn);
+                c = wave_sum_i(c);
+                if (lane == 0) {
+                    sc->dred[1][0][wave] = mn;
+                    sc->ired[0][wave] = c;
+                }
+                __syncthreads();
+                int ctot = 0;
+                double mtot = __builtin_inf();
+#pragma unroll
+                for (int i = 0; i < NWAVE; ++i) {
+                    ctot += sc->ired[0][i];
+                    double m2 = sc->dred[1][0][i];
+                    mtot = m2 < mtot ? m2 : mtot;
+                }
+                const double b = (ctot > k1 + 1) ? a : mtot;
+                med = (a + b) / 2.0;
+            }
+        }
+
+        // ---------------- O: centre, store, per-cell moments ----------------------------
+        double sum = 0.0, sq = 0.0;
+        float* orow = P.out + cell * P.ldo;
+        for (int j = t; j < W; j += NT) {
+            const double y = win[j] - med;
+            orow[j] = (float)y;
+            sum = sum + y;
+            sq = fma(y, y, sq);
+        }
+        sum = wave_sum(sum);
+        sq = wave_sum(sq);
+        if (lane == 0) {
+            sc->dred[2][0][wave] = sum;
+            sc->dred[2][1][wave] = sq;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int i = 0; i < NWAVE; ++i) {
+                s += sc->dred[2][0][i];
+                q += sc->dred[2][1][i];
+            }
+            P.cell_stats[2 * cell] = s;
+            P.cell_stats[2 * cell + 1] = q;
+            P.cell_median[cell] = med;
+        }
+        // re-zero the pad slots clobbered by the aliased S01 / win arrays
+        if constexpr (MAXB > 0) {
+            __syncthreads();
+            for (int i = t; i < P.Gp; i += NT)
+                if (P.src[i] < 0) row[i] = T(0);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR: padded row of centre_clip(0, ref) (implicit zeros after centring, reference :423)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_zero_row(KParams P, T* zrow, int n_alloc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alloc) return;
+    T v = T(0);
+    if (i < P.Gp) {
+        int g = P.src[i];
+        if (g >= 0) {
+            const T* lo = static_cast<const T*>(P.ref_lo);
+            const T* hi = P.bounded ? static_cast<const T*>(P.ref_hi) : lo;
+            v = centre_clip<T>(T(0), lo[g], hi[g], (T)P.cap, P.bounded, P.trunc);
+        }
+    }
+    zrow[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// step 5a: per-chunk threshold = dynamic_threshold * population std  (reference :450)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_chunk_thr(const double* stats, int64_t n_rows, int64_t chunksize,
+                                                   int64_t row_phase, int n_windows, double dyn, double* thr) {
+    __shared__ double ss[256], sq[256];
+    const int64_t k = blockIdx.x;
+    int64_t r0 = k * chunksize - row_phase, r1 = r0 + chunksize;
+    if (r0 < 0) r0 = 0;
+    if (r1 > n_rows) r1 = n_rows;
+    double s = 0.0, q = 0.0;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        s += stats[2 * r];
+        q += stats[2 * r + 1];
+    }
+    ss[threadIdx.x] = s;
+    sq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            ss[threadIdx.x] += ss[threadIdx.x + o];
+            sq[threadIdx.x] += sq[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)(r1 - r0) * (double)n_windows;
+        const double mean = ss[0] / n;
+        double var = (sq[0] - ss[0] * mean) / n;
+        if (var < 0.0) var = 0.0;
+        thr[k] = dyn * sqrt(var);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// step 5b: zero |x| < thr, decided in float64 (reference :451).  The stored float32 value
+// decides except when it ties with float32(thr): then the window is recomputed from the input
+// with the canonical evaluation order above (bit-identical to k_smooth) and compared in float64.
+// ---------------------------------------------------------------------------------------
+template <typename T, bool CSR>
+__device__ double recompute_window(const KParams& P, int64_t cell, int j) {
+    const T cap = (T)P.cap;
+    const T* ref_lo = static_cast<const T*>(P.ref_lo);
+    const T* ref_hi = P.bounded ? static_cast<const T*>(P.ref_hi) : ref_lo;
+    auto value_at = [&](int pp) -> double {
+        const int g = P.src[pp];
+        if (g < 0) return 0.0;
+        T x = T(0);
+        if constexpr (!CSR) {
+            x = static_cast<const T*>(P.values)[cell * P.ld + g];
+        } else {
+            const T* vals = static_cast<const T*>(P.values);
+            for (int64_t k = P.indptr[cell]; k < P.indptr[cell + 1]; ++k)
+                if (P.indices[k] == g) x = vals[k];
+        }
+        return (double)centre_clip<T>(x, ref_lo[g], ref_hi[g], cap, P.bounded, P.trunc);
+    };
+    const int st = P.w_start[j], ln = P.w_len[j];
+    if (P.B > 1) {
+        const int B = P.B;
+        return window_from_blocks(ln, B, P.w_denom[j], [&](int m, double& s0, double& s1) {
+            s0 = 0.0;
+            s1 = 0.0;
+            for (int r = 0; r < B; ++r) block_accumulate(value_at(st + m * B + r), r, s0, s1);
+        });
+    }
+    return window_direct(ln, P.w_denom[j], [&](int k) { return value_at(st + k); });
+}
+
+template <typename T, bool CSR>
+__global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double* thr, int64_t chunksize,
+                                                   int64_t row_phase) {
+    const int64_t cell = blockIdx.x;
+    const double th = thr[(cell + row_phase) / chunksize];
+    const float thf = (float)th;
+    float* orow = P.out + cell * P.ldo;
+    for (int j = threadIdx.x; j < P.W; j += 256) {
+        const float y = orow[j];
+        const float a = fabsf(y);
+        if (a < thf) {
+            orow[j] = 0.0f;
+        } else if (a == thf) {
+            const double yd = recompute_window<T, CSR>(P, cell, j) - P.cell_median[cell];
+            if (fabs(yd) < th) orow[j] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// reference profile: per-group column sums (reference :385, :400), float64
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_dense(const T* x, int64_t n_rows, int64_t ld, int n_cols,
+                                                      const int32_t* row_group, int group, int rows_per_slab,
+                                                      double* partial /* n_slabs x n_cols */) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    int64_t r1 = r0 + rows_per_slab;
+    if (r1 > n_rows) r1 = n_rows;
+    double acc = 0.0;
+    if (col < n_cols) {
+        if (row_group == nullptr) {
+            int64_t r = r0;
+            for (; r + 8 <= r1; r += 8) {
+                T v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * ld + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (double)v[u];
+            }
+            for (; r < r1; ++r) acc += (double)x[r * ld + col];
+        } else {
+            for (int64_t r = r0; r < r1; ++r)
+                if (row_group[r] == group) acc += (double)x[r * ld + col];
+        }
+        partial[(int64_t)blockIdx.y * n_cols + col] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_colsum_finish(const double* partial, int n_slabs, int n_cols, double* sums) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= n_cols) return;
+    double acc = 0.0;
+    for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * n_cols + col];
+    sums[col] += acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
+                                                    int64_t n_rows, int n_cols, const int32_t* row_group,
+                                                    double* sums) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int g = row_group ? row_group[row] : 0;
+    if (g < 0) return;
+    double* dst = sums + (int64_t)g * n_cols;
+    for (int64_t k = indptr[row] + (threadIdx.x & 63); k < indptr[row + 1]; k += 64)
+        atomicAdd(dst + indices[k], (double)vals[k]);
+}
+
+// cnv_score: per-row sum |x| (tl/_scores.py:66), one wavefront per row, float64
+__global__ void __launch_bounds__(256) k_row_abs_sum(const float* x, int64_t n_rows, int n_cols, int64_t ld,
+                                                     double* row_sum) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* xr = x + row * ld;
+    double acc = 0.0;
+    for (int j = threadIdx.x & 63; j < n_cols; j += 64) acc += (double)fabsf(xr[j]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
+}
+
+}  // namespace icv

@@ -1,0 +1,164 @@
+// Host-side plan: window table, padded LDS row layout, kernel variant selection.
+// Pure host code (no HIP calls here) so that planning can be unit-tested without a GPU.
+//
+// Reference behaviour restated here (icbi-lab/infercnvpy, src/infercnvpy/tl/_infercnv.py):
+//   :205-218  window < G_c  -> pyramid windows at gene offsets 0, step, 2*step, ...
+//   :227-236  window >= G_c -> one flat window (plain mean) over the chromosome
+//   :335-337  chr_pos[c] = cumulative window count
+#pragma once
+#include <cstdint>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace icv {
+
+constexpr int kThreads = 512;          // workgroup size of the smoothing kernel (8 wavefronts)
+constexpr int kMaxBlocksPerThread = 8; // register-buffered partial sums (aliased LDS layout)
+constexpr int kLdsLimit = 160 * 1024;  // gfx950: 160 KiB LDS per CU / per workgroup
+constexpr int kScratchBytes = 1024;    // struct Scratch, rounded up
+
+struct Layout {
+    int elem_bytes = 4;
+    int row_bytes = 0;   // padded row, rounded up to 16
+    int s01_off = 0;     // blocked: partial sums {S0,S1} per block (aliases the row)
+    int win_off = 0;     // float64 window values
+    int scratch_off = 0;
+    int total = 0;
+    bool fits = false;
+};
+
+struct Plan {
+    int n_cols_all = 0, n_used = 0, n_chr = 0, window = 0, step = 0;
+    int B = 1;      // genes per block; 1 = direct form
+    int NB = 0;     // padded blocks (B > 1)
+    int Gp = 0;     // padded row length (elements)
+    int W = 0;      // windows
+    std::vector<int32_t> chrom_off;  // n_chr + 1, sorted coordinates
+    std::vector<int32_t> pad_off;    // n_chr + 1, padded coordinates
+    std::vector<int32_t> chr_pos;    // n_chr, first window
+    std::vector<int32_t> dst;        // n_cols_all: padded position or -1
+    std::vector<int32_t> src;        // Gp: input column or -1 (pad)
+    std::vector<int32_t> w_start;    // W: padded start position
+    std::vector<int32_t> w_len;      // W: >0 pyramid length (genes); <0 flat over -len padded positions
+    std::vector<double> w_denom;     // W: sum of weights / gene count
+    std::vector<int32_t> w_start_sorted, w_len_sorted;  // sorted-gene coordinates, for the API
+    Layout lay32, lay64;
+};
+
+inline int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline Layout make_layout(const Plan& p, int elem_bytes) {
+    Layout l;
+    l.elem_bytes = elem_bytes;
+    l.row_bytes = round_up(p.Gp * elem_bytes, 16);
+    int data;
+    if (p.B > 1) {
+        l.s01_off = 0;
+        l.win_off = 16 * p.NB;
+        int alias = l.win_off + round_up(8 * p.W, 16);
+        data = alias > l.row_bytes ? alias : l.row_bytes;
+    } else {
+        l.win_off = l.row_bytes;
+        data = l.row_bytes + round_up(8 * p.W, 16);
+    }
+    l.scratch_off = round_up(data, 16);
+    l.total = l.scratch_off + kScratchBytes;
+    l.fits = l.total <= kLdsLimit;
+    return l;
+}
+
+// Returns "" on success, an error message otherwise.
+inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, int n_chr,
+                              const int32_t* chrom_off, int window, int step) {
+    if (n_cols_all <= 0) return "n_cols_all must be positive";
+    if (n_chr <= 0) return "no chromosome with genes to smooth (need names starting with 'chr')";
+    if (window < 1 || step < 1) return "window and step must be >= 1";
+    p.n_cols_all = n_cols_all;
+    p.n_chr = n_chr;
+    p.window = window;
+    p.step = step;
+    p.chrom_off.assign(chrom_off, chrom_off + n_chr + 1);
+    if (p.chrom_off[0] != 0) return "chrom_offsets[0] must be 0";
+    for (int c = 0; c < n_chr; ++c)
+        if (p.chrom_off[c + 1] <= p.chrom_off[c]) return "every chromosome needs at least one gene";
+    p.n_used = p.chrom_off[n_chr];
+
+    // col_pos must be a bijection onto [0, n_used)
+    std::vector<int32_t> order(p.n_used, -1);
+    for (int g = 0; g < n_cols_all; ++g) {
+        int q = col_pos[g];
+        if (q < 0) continue;
+        if (q >= p.n_used || order[q] != -1) return "col_pos is not a permutation of the used genes";
+        order[q] = g;
+    }
+    for (int q = 0; q < p.n_used; ++q)
+        if (order[q] < 0) return "col_pos does not cover every used gene";
+
+    // block size: pyramid weights are linear on [0, n/2) and [n/2, n); a block must not straddle
+    // the kink, must tile the window and the step.
+    int B = 1;
+    if (window % 2 == 0) B = gcd_int(step, window / 2);
+    auto count_blocks = [&](int b) {
+        long nb = 0;
+        for (int c = 0; c < n_chr; ++c) nb += (p.chrom_off[c + 1] - p.chrom_off[c] + b - 1) / b;
+        return nb;
+    };
+    if (B > 1 && count_blocks(B) > (long)kThreads * kMaxBlocksPerThread) B = 1;
+    p.B = B;
+
+    // padded layout + window table
+    p.pad_off.assign(n_chr + 1, 0);
+    p.chr_pos.assign(n_chr, 0);
+    p.w_start.clear(); p.w_len.clear(); p.w_denom.clear();
+    p.w_start_sorted.clear(); p.w_len_sorted.clear();
+    int pad = 0, w = 0;
+    for (int c = 0; c < n_chr; ++c) {
+        int gc = p.chrom_off[c + 1] - p.chrom_off[c];
+        int padded = round_up(gc, B);
+        p.pad_off[c] = pad;
+        p.chr_pos[c] = w;
+        if (window < gc) {
+            int nwin = (gc - window + 1 + step - 1) / step;
+            double denom = (window % 2 == 0) ? (double)(window / 2) * (double)(window / 2 + 1)
+                                             : (double)((window + 1) / 2) * (double)((window + 1) / 2);
+            for (int j = 0; j < nwin; ++j) {
+                p.w_start.push_back(pad + j * step);
+                p.w_len.push_back(window);
+                p.w_denom.push_back(denom);
+                p.w_start_sorted.push_back(p.chrom_off[c] + j * step);
+                p.w_len_sorted.push_back(window);
+            }
+            w += nwin;
+        } else {
+            p.w_start.push_back(pad);
+            p.w_len.push_back(-padded);
+            p.w_denom.push_back((double)gc);
+            p.w_start_sorted.push_back(p.chrom_off[c]);
+            p.w_len_sorted.push_back(gc);
+            w += 1;
+        }
+        pad += padded;
+    }
+    p.pad_off[n_chr] = pad;
+    p.Gp = pad;
+    p.NB = (B > 1) ? pad / B : 0;
+    p.W = w;
+
+    p.src.assign(p.Gp, -1);
+    p.dst.assign(n_cols_all, -1);
+    for (int c = 0; c < n_chr; ++c) {
+        int gc = p.chrom_off[c + 1] - p.chrom_off[c];
+        for (int i = 0; i < gc; ++i) {
+            int g = order[p.chrom_off[c] + i];
+            p.src[p.pad_off[c] + i] = g;
+            p.dst[g] = p.pad_off[c] + i;
+        }
+    }
+    p.lay32 = make_layout(p, 4);
+    p.lay64 = make_layout(p, 8);
+    return "";
+}
+
+}  // namespace icv

@@ -1,0 +1,128 @@
+"""``pl.chromosome_heatmap`` / ``pl.chromosome_heatmap_summary``.
+
+Host-side glue with the reference's signatures (icbi-lab/infercnvpy
+``src/infercnvpy/pl/_chromosome_heatmap.py:11-193``).  The reference forwards to
+``scanpy.pl.heatmap``; scanpy is not a dependency of this package, so an equivalent matplotlib
+figure is drawn directly (cells grouped by ``groupby``, colour map centred at 0 with
+``TwoSlopeNorm``, chromosome boundaries as vertical lines, chromosome labels on top).  The returned
+dict has the ``"heatmap_ax"`` entry the reference's callers use.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _sorted_chr_pos(adata, use_rep):
+    # re-sort: saving and loading AnnData does not keep dict order (reference :57-59)
+    items = sorted(adata.uns[use_rep]["chr_pos"].items(), key=lambda kv: kv[1])
+    return [k for k, _ in items], [int(v) for _, v in items]
+
+
+def _draw(matrix, labels, chr_names, chr_pos, *, groupby, cmap, figsize, vmin, vmax, show, save, ymin_lines,
+          dendrogram_order=None, **kwargs):
+    import matplotlib.pyplot as plt
+    from matplotlib.colors import TwoSlopeNorm
+
+    labels = np.asarray(labels)
+    cats = list(dict.fromkeys(labels.tolist())) if dendrogram_order is None else list(dendrogram_order)
+    if hasattr(labels, "categories"):
+        cats = list(labels.categories)
+    try:
+        cats = sorted(cats)
+    except TypeError:
+        pass
+    order = np.concatenate([np.flatnonzero(labels == c) for c in cats]) if len(cats) else np.arange(0)
+    mat = matrix[order]
+    sizes = [int((labels == c).sum()) for c in cats]
+
+    norm = kwargs.pop("norm", None) or TwoSlopeNorm(0, vmin=vmin, vmax=vmax)
+    fig = plt.figure(figsize=figsize)
+    gs = fig.add_gridspec(2, 3, width_ratios=[0.3, 16, 0.25], height_ratios=[0.25, 10], wspace=0.02, hspace=0.02)
+    ax_groups = fig.add_subplot(gs[1, 0])
+    ax_heat = fig.add_subplot(gs[1, 1])
+    ax_chr = fig.add_subplot(gs[0, 1], sharex=ax_heat)
+    ax_cbar = fig.add_subplot(gs[1, 2])
+
+    im = ax_heat.imshow(mat, aspect="auto", cmap=cmap, norm=norm, interpolation="nearest",
+                        extent=(0, mat.shape[1], mat.shape[0], 0))
+    ax_heat.set_xticks([])
+    ax_heat.set_yticks([])
+    bounds = np.cumsum([0] + sizes)
+    for b in bounds[1:-1]:
+        ax_heat.axhline(b, color="black", lw=0.5)
+    ax_heat.vlines(chr_pos[1:], lw=0.6, ymin=ymin_lines, ymax=mat.shape[0], color="black")
+
+    group_colors = plt.get_cmap("tab20")(np.arange(len(cats)) % 20)
+    for i, c in enumerate(cats):
+        ax_groups.axhspan(bounds[i], bounds[i + 1], color=group_colors[i])
+        ax_groups.text(-0.1, (bounds[i] + bounds[i + 1]) / 2, str(c), ha="right", va="center", fontsize=8,
+                       transform=ax_groups.get_yaxis_transform())
+    ax_groups.set_ylim(mat.shape[0], 0)
+    ax_groups.set_xticks([])
+    ax_groups.set_yticks([])
+    ax_groups.set_ylabel(groupby)
+
+    ends = chr_pos[1:] + [mat.shape[1]]
+    for name, a, b in zip(chr_names, chr_pos, ends):
+        ax_chr.plot([a, b], [0, 0], color="black", lw=1)
+        ax_chr.text((a + b) / 2, 0.3, name.replace("chr", ""), ha="center", va="bottom", fontsize=7)
+    ax_chr.set_ylim(-0.5, 2)
+    ax_chr.axis("off")
+    fig.colorbar(im, cax=ax_cbar)
+
+    axes = {"heatmap_ax": ax_heat, "groupby_ax": ax_groups, "gene_groups_ax": ax_chr}
+    if save:
+        fname = save if isinstance(save, str) else "heatmap.png"
+        fig.savefig(fname, bbox_inches="tight")
+    if show:
+        plt.show()
+        return None
+    return axes
+
+
+def chromosome_heatmap(adata, *, groupby: str = "cnv_leiden", use_rep: str = "cnv", cmap="bwr",
+                       figsize=(16, 10), show=None, save=None, **kwargs):
+    """Heatmap of smoothed gene expression by chromosome (reference :11-92)."""
+    if groupby == "cnv_leiden" and "cnv_leiden" not in adata.obs.columns:
+        raise ValueError("'cnv_leiden' is not in `adata.obs`. Did you run `tl.leiden()`?")
+    x = adata.obsm[f"X_{use_rep}"]
+    chr_names, chr_pos = _sorted_chr_pos(adata, use_rep)
+
+    data = x.data if sp.issparse(x) else np.asarray(x)
+    vmin = kwargs.pop("vmin", None)
+    vmax = kwargs.pop("vmax", None)
+    if vmin is None:
+        vmin = np.nanmin(data)
+    if vmax is None:
+        vmax = np.nanmax(data)
+
+    dense = x.toarray() if sp.issparse(x) else np.asarray(x)
+    return _draw(dense, adata.obs[groupby].values, chr_names, chr_pos, groupby=groupby, cmap=cmap,
+                 figsize=figsize, vmin=vmin, vmax=vmax, show=bool(show), save=save, ymin_lines=0, **kwargs)
+
+
+def chromosome_heatmap_summary(adata, *, groupby: str = "cnv_leiden", use_rep: str = "cnv", cmap="bwr",
+                               figsize=(16, 10), show=None, save=None, **kwargs):
+    """Heatmap of per-group mean smoothed expression, each group drawn 10 rows high (reference :95-193)."""
+    if groupby == "cnv_leiden" and "cnv_leiden" not in adata.obs.columns:
+        raise ValueError("'cnv_leiden' is not in `adata.obs`. Did you run `tl.leiden()`?")
+    x = adata.obsm[f"X_{use_rep}"]
+    labels = np.asarray(adata.obs[groupby].values)
+    groups = list(dict.fromkeys(labels.tolist()))
+
+    def group_mean(g):
+        m = np.asarray(np.mean(x[labels == g, :], axis=0))
+        return m.reshape(1, -1)
+
+    mat = np.vstack([np.repeat(group_mean(g), 10, axis=0) for g in groups])
+    rep_labels = np.hstack([np.repeat(g, 10) for g in groups])
+    chr_names, chr_pos = _sorted_chr_pos(adata, use_rep)
+    vmin = kwargs.pop("vmin", None)
+    vmax = kwargs.pop("vmax", None)
+    if vmin is None:
+        vmin = np.min(mat)
+    if vmax is None:
+        vmax = np.max(mat)
+    return _draw(mat, rep_labels, chr_names, chr_pos, groupby=groupby, cmap=cmap, figsize=figsize, vmin=vmin,
+                 vmax=vmax, show=bool(show), save=save, ymin_lines=-1, **kwargs)

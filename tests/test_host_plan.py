@@ -1,0 +1,102 @@
+"""CPU tests: the C-ABI library loads, exports every declared symbol, and the host-side plan
+(gene order, window table, chr_pos) agrees with the oracle and with pandas' sort."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import cases
+from _golden import GoldenCase, case_names
+from infercnvpy_amd import _lib
+from infercnvpy_amd._plan import GenePlan
+from oracle import infercnv_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "infercnv_hip.h")).read()
+    declared = set(re.findall(r"\b(icv_[a-z_0-9]+)\s*\(", header)) - {"icv_status"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.icv_version() >= 100
+    assert lib.icv_device_count() >= 0
+
+
+def test_plan_errors_map_to_value_error():
+    with pytest.raises(ValueError):
+        GenePlan(np.array(["GL1", "GL1"], dtype=object), np.array([1, 2]), window_size=10, step=1)
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    col_pos = np.array([0, 0, 1], dtype=np.int32)  # not a permutation
+    off = np.array([0, 2], dtype=np.int32)
+    rc = lib.icv_plan_create(3, col_pos.ctypes.data, 1, off.ctypes.data, 2, 1, ctypes.byref(h))
+    assert rc == _lib.ICV_ERR_INVALID
+    assert b"permutation" in lib.icv_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_plan_matches_reference_chr_pos(name):
+    g = GoldenCase(name)
+    kw = g.kwargs
+    plan = GenePlan(g.chromosome, g.start, window_size=kw.get("window_size", 100), step=kw.get("step", 10),
+                    exclude_chromosomes=kw.get("exclude_chromosomes", ("chrX", "chrY")))
+    assert {k: int(v) for k, v in plan.chr_pos.items()} == g.chr_pos
+    assert list(plan.chr_pos.keys()) == list(g.chr_pos.keys())
+    assert plan.n_windows == g.out.shape[1]
+    # gene order = the oracle's (and hence the reference's) per-chromosome order
+    keep = ~plan.var_mask
+    ch, st = g.chromosome[keep], g.start[keep]
+    kept_idx = np.flatnonzero(keep)
+    expect = np.concatenate([kept_idx[O.chromosome_gene_order(ch, st, c)] for c in O.used_chromosomes(ch)])
+    np.testing.assert_array_equal(plan.order, expect)
+    # window table is consistent with W_c = ceil((G_c - n + 1) / step) or 1
+    st_w, ln_w = plan.window_table()
+    n, s = plan.window_size, plan.step
+    w = 0
+    for c, name_c in enumerate(plan.chromosomes):
+        gc = plan.chrom_offsets[c + 1] - plan.chrom_offsets[c]
+        wc = -(-(gc - n + 1) // s) if n < gc else 1
+        assert plan.chr_pos[name_c] == w
+        for j in range(wc):
+            assert st_w[w + j] == plan.chrom_offsets[c] + (j * s if n < gc else 0)
+            assert ln_w[w + j] == (n if n < gc else gc)
+        w += wc
+    assert w == plan.n_windows
+
+
+def test_gene_order_matches_pandas_sort_values_with_ties_and_nan():
+    rng = np.random.RandomState(0)
+    n = 400
+    chrom = rng.choice(["chr1", "chr2", "chr10", "chrX", "chrM", "KI27", None], size=n).astype(object)
+    start = rng.randint(0, 40, size=n).astype(float)  # many ties
+    start[rng.rand(n) < 0.05] = np.nan
+    var = pd.DataFrame({"chromosome": chrom, "start": start}, index=[f"g{i}" for i in range(n)])
+    plan = GenePlan(var["chromosome"].to_numpy(), var["start"].to_numpy(), window_size=10, step=2)
+    assert plan.chromosomes == ["chr1", "chr2", "chr10"]
+    expect = []
+    for c in plan.chromosomes:
+        genes = var.loc[var["chromosome"] == c].sort_values("start").index.to_numpy()
+        expect.append(var.index.get_indexer(genes))
+    np.testing.assert_array_equal(plan.order, np.concatenate(expect))
+    assert plan.n_without_position == int(pd.isnull(var["chromosome"]).sum())
+
+
+def test_plan_info_benchmark_geometry():
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+    assert plan.n_windows == 1802
+    assert plan.info.block == 10 and plan.info.n_blocks == 2000 and plan.info.padded_len == 20000
+    assert plan.info.workgroups_per_cu_f32 == 2, plan.info.lds_bytes_f32
+    plan250 = GenePlan(v["chromosome"], v["start"], window_size=250, step=10)
+    assert plan250.n_windows == 1472 and plan250.info.block == 5
+    plan1 = GenePlan(v["chromosome"], v["start"], window_size=100, step=1)
+    assert plan1.n_windows == 17822 and plan1.info.block == 1
