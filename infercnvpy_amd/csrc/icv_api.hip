@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -40,6 +41,8 @@ struct icv_plan_s {
     int n_cu = 0;
     int32_t *d_dst = nullptr, *d_src = nullptr, *d_wstart = nullptr, *d_wlen = nullptr;
     double* d_wdenom = nullptr;
+    int32_t* d_pad = nullptr;
+    uint16_t* d_dst16 = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
 };
@@ -66,6 +69,8 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.w_start.data(), p.w_start.size() * 4, (void**)&pl->d_wstart));
     HIP_TRY(up(p.w_len.data(), p.w_len.size() * 4, (void**)&pl->d_wlen));
     HIP_TRY(up(p.w_denom.data(), p.w_denom.size() * 8, (void**)&pl->d_wdenom));
+    HIP_TRY(up(p.pad_idx.data(), p.pad_idx.size() * 4, (void**)&pl->d_pad));
+    HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
     pl->device = dev;
@@ -122,6 +127,15 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.w_start = pl->d_wstart;
     K.w_len = pl->d_wlen;
     K.w_denom = pl->d_wdenom;
+    K.dst16 = pl->d_dst16;
+    K.pad_idx = pl->d_pad;
+    K.n_pad = (int32_t)p.pad_idx.size();
+    K.pyr_den = p.pyr_den;
+    K.pyr_rcp = p.pyr_rcp;
+    {
+        const double capd = (m->dtype == ICV_F32) ? (double)(float)lfc_clip : lfc_clip;
+        K.med_bound = capd * 1.000001 + 1e-30;
+    }
     K.B = p.B;
     K.NB = p.NB;
     K.Gp = p.Gp;
@@ -133,6 +147,56 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.cell_median = cell_median;
     K.cell_stats = cell_stats;
     return ICV_OK;
+}
+
+int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const icv::KParams& K, hipStream_t st) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (std::getenv("ICV_PHASE_PROFILE")) {
+        // developer diagnostic: shader cycles per phase, summed over workgroups (thread 0 of each)
+        unsigned long long* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d, 0, 5 * sizeof(unsigned long long)));
+        icv::KParams K2 = K;
+        K2.dbg = d;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K2);
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long h[5];
+        HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        (void)hipFree(d);
+        const char* names[5] = {"L load+scatter", "S block sums", "W windows", "M median", "O output"};
+        double tot = 0;
+        for (auto v : h) tot += (double)v;
+        std::fprintf(stderr, "[icv phase profile] grid=%lld rows=%lld lds=%d\n", (long long)grid,
+                     (long long)K.n_rows, lds);
+        for (int i = 0; i < 5; ++i)
+            std::fprintf(stderr, "  %-16s %12.0f cycles/cell  %5.1f %%\n", names[i], (double)h[i] / (double)K.n_rows,
+                         100.0 * (double)h[i] / tot);
+        return ICV_OK;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+// dense float32, blocked form, small enough geometry: register-prefetch kernel
+int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
+    const icv::Plan& p = pl->p;
+    const int need_b = (p.NB + icv::kThreads - 1) / icv::kThreads;
+    const int need_w = (p.W + icv::kThreads - 1) / icv::kThreads;
+    void (*kern)(const icv::KParams) = nullptr;
+    constexpr int U = icv::kFastUMax;
+    if (need_b <= 4 && p.B == 10) kern = icv::k_smooth_fast<U, 4, 4, 10>;
+    else if (need_b <= 4) kern = icv::k_smooth_fast<U, 4, 4, 0>;
+    else if (need_w <= 4 && p.B == 5) kern = icv::k_smooth_fast<U, 8, 4, 5>;
+    else if (need_w <= 4) kern = icv::k_smooth_fast<U, 8, 4, 0>;
+    else kern = icv::k_smooth_fast<U, 8, 8, 0>;
+    K.scratch_off = p.fast_scratch_off;
+    int per_cu = icv::kLdsLimit / p.fast_lds;
+    if (per_cu > 4) per_cu = 4;
+    int64_t grid = (int64_t)pl->n_cu * per_cu;
+    if (grid > K.n_rows) grid = K.n_rows;
+    if (grid < 1) return ICV_OK;
+    return run_kernel(kern, grid, p.fast_lds, K, st);
 }
 
 template <typename T, bool CSR>
@@ -147,8 +211,6 @@ int launch_smooth_t(icv_plan_t pl, const icv::KParams& K, const icv::Layout& lay
     if (maxb == 0) kern = icv::k_smooth<T, CSR, 0>;
     else if (maxb == 4) kern = icv::k_smooth<T, CSR, 4>;
     else kern = icv::k_smooth<T, CSR, 8>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lay.total));
     int per_cu = icv::kLdsLimit / lay.total;
     if (per_cu > 4) per_cu = 4;  // 32 wavefronts per CU / 8 per workgroup
     if (per_cu < 1) per_cu = 1;
@@ -160,13 +222,14 @@ int launch_smooth_t(icv_plan_t pl, const icv::KParams& K, const icv::Layout& lay
         hipLaunchKernelGGL(icv::k_zero_row<T>, dim3((n + 255) / 256), dim3(256), 0, st, K,
                            static_cast<T*>(pl->d_zrow), n);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lay.total, st, K);
-    HIP_TRY(hipGetLastError());
-    return ICV_OK;
+    return run_kernel(kern, grid, lay.total, K, st);
 }
 
 int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
                   hipStream_t st) {
+    if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.fast_ok && K.vec_ok && std::isfinite(K.cap) &&
+        !std::getenv("ICV_FORCE_GENERIC"))
+        return launch_smooth_fast(pl, K, st);
     if (m->dtype == ICV_F32)
         return m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, lay, st)
                                       : launch_smooth_t<float, true>(pl, K, lay, st);
@@ -234,6 +297,8 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_wstart);
         (void)hipFree(pl->d_wlen);
         (void)hipFree(pl->d_wdenom);
+        (void)hipFree(pl->d_pad);
+        (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_zrow);
     }
     delete pl;

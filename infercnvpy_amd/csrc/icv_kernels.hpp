@@ -45,6 +45,13 @@ struct KParams {
     const int32_t* w_start;
     const int32_t* w_len;
     const double* w_denom;
+    const uint16_t* dst16;   // fast path: padded table of LDS positions, Gp (trash slot) = masked
+    const int32_t* pad_idx;  // padded positions that hold no gene (must read as 0)
+    int32_t n_pad;
+    int32_t _pad0;
+    double pyr_den;          // sum of the pyramid weights, and its correctly rounded reciprocal
+    double pyr_rcp;
+    double med_bound;        // |window| <= med_bound (from the clip value); fast path bracket
     int32_t B, NB, Gp, W;
     int32_t win_off, scratch_off;
     // outputs
@@ -52,6 +59,7 @@ struct KParams {
     int64_t ldo;
     double* cell_median;
     double* cell_stats;
+    unsigned long long* dbg;  // developer diagnostic: per-phase shader-cycle totals (ICV_PHASE_PROFILE=1)
 };
 
 struct Scratch {
@@ -73,9 +81,8 @@ __device__ __forceinline__ T centre_clip(T x, T lo, T hi, T cap, int bounded, in
     if (!bounded) {
         v = x - lo;
     } else {
-        v = T(0);
-        if (x > hi) v = x - hi;
-        else if (x < lo) v = x - lo;
+        const T above = x - hi, below = x - lo;
+        v = (x > hi) ? above : ((x < lo) ? below : T(0));
         if (trunc_int & 1) v = (T)trunc((double)v);
         if (trunc_int & 2) v = (T)(float)v;
     }
@@ -94,11 +101,25 @@ __device__ __forceinline__ void block_accumulate(double v, int r, double& s0, do
     s1 = fma((double)r, v, s1);
 }
 
+// acc / denom.  Pyramid windows share one denominator: q = RN(acc * RN(1/d)) corrected by one
+// residual step is the correctly rounded quotient (Markstein) at 3 FMAs instead of a ~40
+// instruction IEEE division; flat windows (one per small chromosome) use the plain division.
+__device__ __forceinline__ double finish_window(double acc, int len, double pyr_den, double pyr_rcp,
+                                                double flat_den) {
+    if (len > 0) {
+        const double q = acc * pyr_rcp;
+        const double r = fma(-q, pyr_den, acc);
+        return fma(r, pyr_rcp, q);
+    }
+    return acc / flat_den;
+}
+
 template <typename F>  // F(m, &S0, &S1): partial sums of block m of the window
-__device__ __forceinline__ double window_from_blocks(int len, int B, double denom, F blk) {
+__device__ __forceinline__ double window_from_blocks(int len, int B, F blk) {
     double acc = 0.0;
     if (len > 0) {
         const int nb = len / B, hb = nb / 2;
+#pragma unroll 2
         for (int m = 0; m < nb; ++m) {
             double S0, S1;
             blk(m, S0, S1);
@@ -112,17 +133,18 @@ __device__ __forceinline__ double window_from_blocks(int len, int B, double deno
         }
     } else {
         const int nb = (-len) / B;
+#pragma unroll 1
         for (int m = 0; m < nb; ++m) {
             double S0, S1;
             blk(m, S0, S1);
             acc = acc + S0;
         }
     }
-    return acc / denom;
+    return acc;
 }
 
 template <typename F>  // F(k): clipped value k of the window as double
-__device__ __forceinline__ double window_direct(int len, double denom, F val) {
+__device__ __forceinline__ double window_direct(int len, F val) {
     double acc = 0.0;
     if (len > 0) {
         for (int k = 0; k < len; ++k) {
@@ -132,7 +154,7 @@ __device__ __forceinline__ double window_direct(int len, double denom, F val) {
     } else {
         for (int k = 0; k < -len; ++k) acc = acc + val(k);
     }
-    return acc / denom;
+    return acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -224,9 +246,17 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
 
     // pad slots of the row are never written by the scatter: zero them once (direct form, no
     // aliasing) or after every cell (blocked form, the aliased S01/win overwrite them).
-    for (int i = t; i < P.Gp; i += NT)
-        if (P.src[i] < 0) row[i] = T(0);
+    for (int i = t; i < P.n_pad; i += NT) row[P.pad_idx[i]] = T(0);
     __syncthreads();
+
+    unsigned long long tlast = 0, tacc[5] = {0, 0, 0, 0, 0};
+#define ICV_PHASE(i)                                              \
+    if (P.dbg && t == 0) {                                        \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+        tacc[i] += now_ - tlast;                                  \
+        tlast = now_;                                             \
+    }
+    if (P.dbg && t == 0) tlast = __builtin_amdgcn_s_memtime();
 
     for (int64_t cell = blockIdx.x; cell < P.n_rows; cell += gridDim.x) {
         // ---------------- L: load, centre, clip, scatter --------------------------------
@@ -286,6 +316,7 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
             }
         }
         __syncthreads();
+        ICV_PHASE(0)
 
         // ---------------- S + W: block partial sums, windows ----------------------------
         double lmin = __builtin_inf(), lmax = -__builtin_inf();
@@ -312,13 +343,15 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
                 }
             }
             __syncthreads();
+            ICV_PHASE(1)
             for (int j = t; j < W; j += NT) {
                 const int st = P.w_start[j], ln = P.w_len[j];
                 const double* sp = S01 + 2 * (st / B);
-                double v = window_from_blocks(ln, B, P.w_denom[j], [&](int m, double& a, double& b2) {
+                double v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
                     a = sp[2 * m];
                     b2 = sp[2 * m + 1];
                 });
+                v = finish_window(v, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
                 win[j] = v;
                 lmin = v < lmin ? v : lmin;
                 lmax = v > lmax ? v : lmax;
@@ -328,7 +361,8 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
             for (int j = t; j < W; j += NT) {
                 const int st = P.w_start[j], ln = P.w_len[j];
                 const T* rp = row + st;
-                double v = window_direct(ln, P.w_denom[j], [&](int k) { return (double)rp[k]; });
+                double v = window_direct(ln, [&](int k) { return (double)rp[k]; });
+                v = finish_window(v, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
                 win[j] = v;
                 lmin = v < lmin ? v : lmin;
                 lmax = v > lmax ? v : lmax;
@@ -342,6 +376,7 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
             sc->dred[0][1][wave] = lmax;
         }
         const int anynan = __syncthreads_or(lnan);  // also publishes win[] and dred
+        ICV_PHASE(2)
 
         // ---------------- M: median over all W windows (np.median, reference :442) ------
         double med;
@@ -433,6 +468,7 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
             }
         }
 
+        ICV_PHASE(3)
         // ---------------- O: centre, store, per-cell moments ----------------------------
         double sum = 0.0, sq = 0.0;
         float* orow = P.out + cell * P.ldo;
@@ -463,11 +499,406 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
         // re-zero the pad slots clobbered by the aliased S01 / win arrays
         if constexpr (MAXB > 0) {
             __syncthreads();
-            for (int i = t; i < P.Gp; i += NT)
-                if (P.src[i] < 0) row[i] = T(0);
+            for (int i = t; i < P.n_pad; i += NT) row[P.pad_idx[i]] = T(0);
         }
         __syncthreads();
+        ICV_PHASE(4)
     }
+    if (P.dbg && t == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(P.dbg + i, tacc[i]);
+#undef ICV_PHASE
+}
+
+// ---------------------------------------------------------------------------------------
+// DPP wavefront reductions (no LDS traffic, unlike __shfl): butterfly inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row values are
+// read back as scalars and combined in a fixed order -> deterministic, result uniform.
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
+}
+__device__ __forceinline__ double wave_min_dpp(double v) {
+    double o;
+    o = dpp_move<0xB1>(v); v = o < v ? o : v;
+    o = dpp_move<0x4E>(v); v = o < v ? o : v;
+    o = dpp_move<0x141>(v); v = o < v ? o : v;
+    o = dpp_move<0x140>(v); v = o < v ? o : v;
+    double a = readlane_d(v, 0), b = readlane_d(v, 16), c = readlane_d(v, 32), d = readlane_d(v, 48);
+    a = b < a ? b : a;
+    c = d < c ? d : c;
+    return c < a ? c : a;
+}
+__device__ __forceinline__ double wave_max_dpp(double v) { return -wave_min_dpp(-v); }
+
+// ---------------------------------------------------------------------------------------
+// Fast path of the smoothing kernel: dense float32, blocked form (B > 1), G <= 20480.
+//   * the NEXT cell's row is prefetched into registers (UMAX 16-byte loads per lane) right
+//     after the current row has been scattered, so HBM latency is covered by the S/W/M/O phases;
+//     no other global load is issued in those phases (a later load's s_waitcnt would drain the
+//     prefetch): window descriptors and the packed scatter table live in registers;
+//   * window values stay in registers: the median bisection counts with v_cmp + s_bcnt1
+//     (ballots), pivots by count interpolation, no LDS window array;
+//   * moments and tie resolution use DPP reductions.
+// Same float64 evaluation order as k_smooth: results are bit-identical.
+// ---------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    // raw buffer descriptor: base, stride 0, num_records = bytes (out-of-range lanes read 0)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+struct ScratchF {
+    int icnt[2][NWAVE];
+    int nanw[NWAVE];
+    int ncand;
+    int r1_found, r2_found;
+    int rank[64];
+    double cand[64];
+    double sel[2];
+    double dsum[NWAVE], dsq[NWAVE];
+    double dmin[NWAVE], dmax[NWAVE];
+};
+static_assert(sizeof(ScratchF) <= 1280, "ScratchF must fit the scratch region");
+
+template <int UMAX, int MAXB, int MAXW, int BT /* compile-time block size, 0 = runtime */>
+__global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    double* S01 = reinterpret_cast<double*>(smem);
+    ScratchF* sc = reinterpret_cast<ScratchF*>(smem + P.scratch_off);
+
+    const int t = threadIdx.x;
+    const float cap = (float)P.cap;
+    const int W = P.W, NB = P.NB;
+    const int B = BT > 0 ? BT : P.B;
+    const unsigned row_bytes = (unsigned)P.n_cols * 4u;
+    const unsigned voff = (unsigned)t * 16u;  // the only per-lane address register of the row loads
+    const __amdgpu_buffer_rsrc_t lo_rs = make_rsrc(P.ref_lo, row_bytes);
+    const __amdgpu_buffer_rsrc_t hi_rs = make_rsrc(P.bounded ? P.ref_hi : P.ref_lo, row_bytes);
+    const double pyr_den = P.pyr_den, pyr_rcp = P.pyr_rcp;
+    const float* xbase = static_cast<const float*>(P.values);
+
+    // ---- per-thread constants, loaded once --------------------------------------------
+    uint2 d16[UMAX];  // 4 packed 16-bit LDS positions per 16-byte load
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) d16[u] = reinterpret_cast<const uint2*>(P.dst16)[u * NT + t];
+    int w_pack[MAXW];  // start block (low 16) | signed length in genes (high 16)
+    int w_gc[MAXW];    // flat windows: gene count of the chromosome
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+        const int j = t + i * NT;
+        w_pack[i] = 0;
+        w_gc[i] = 1;
+        if (j < W) {
+            const int st = P.w_start[j], ln = P.w_len[j];
+            w_pack[i] = (int)((unsigned)((st / B) & 0xffff) | ((unsigned)ln << 16));
+            w_gc[i] = (int)P.w_denom[j];
+        }
+    }
+
+    // ---- prefetch the first row ----------------------------------------------------------
+    u32x4 xq[UMAX];
+    {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
+    }
+    __syncthreads();
+
+    unsigned long long tlast = 0, tacc[5] = {0, 0, 0, 0, 0};
+#define ICV_PHASE(i)                                            \
+    if (P.dbg && t == 0) {                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tacc[i] += now_ - tlast;                                \
+        tlast = now_;                                           \
+    }
+    if (P.dbg && t == 0) tlast = __builtin_amdgcn_s_memtime();
+
+    constexpr int UH = 5;  // reference loads in flight per sub-batch (register budget)
+    static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
+
+    for (int64_t cell = blockIdx.x; cell < P.n_rows; cell += gridDim.x) {
+        // Everything derived from the thread id below goes through `tl`, a copy laundered by an
+        // empty asm: otherwise the compiler hoists dozens of per-thread addresses and predicates
+        // out of the cell loop, spills them, and the scratch reloads (VMEM, in-order) would
+        // drain the prefetch queue in the middle of the compute phases.
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+        // ---------------- L: centre, clip, scatter the prefetched row ---------------------
+        // (pad slots are clobbered by the aliased S01 of the previous cell: clear them first)
+        for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
+// Masked columns point at a trash slot (index Gp) so the scatter is unconditional.  The packed
+// positions are laundered through an empty asm so that the compiler does not hoist the 40
+// unpacked addresses out of the cell loop (they would cost 40 VGPRs for the whole kernel).
+#define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
+    {                                                                                                            \
+        unsigned dx_ = (D).x, dy_ = (D).y;                                                                       \
+        asm volatile("" : "+v"(dx_), "+v"(dy_));                                                                 \
+        row[dx_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).x), __uint_as_float((LO).x),                 \
+                                                __uint_as_float((HI).x), cap, BND, P.trunc);                     \
+        row[dx_ >> 16] = centre_clip<float>(__uint_as_float((X).y), __uint_as_float((LO).y),                     \
+                                            __uint_as_float((HI).y), cap, BND, P.trunc);                         \
+        row[dy_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).z), __uint_as_float((LO).z),                 \
+                                                __uint_as_float((HI).z), cap, BND, P.trunc);                     \
+        row[dy_ >> 16] = centre_clip<float>(__uint_as_float((X).w), __uint_as_float((LO).w),                     \
+                                            __uint_as_float((HI).w), cap, BND, P.trunc);                         \
+    }
+        if (!P.bounded) {
+#pragma unroll
+            for (int h = 0; h < UMAX; h += UH) {
+                u32x4 lo[UH];
+#pragma unroll
+                for (int k = 0; k < UH; ++k)
+                    lo[k] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, (h + k) * NT * 16, 0);
+#pragma unroll
+                for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], d16[h + k], 0)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u) {
+                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * NT * 16, 0);
+                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(hi_rs, voff, u * NT * 16, 0);
+                ICV_SCATTER4(xq[u], lo, hi, d16[u], 1)
+            }
+        }
+#undef ICV_SCATTER4
+        // prefetch the next row of this workgroup; in flight until the next L phase
+        {
+            const int64_t nxt = cell + gridDim.x;
+            if (nxt < P.n_rows) {
+                const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + nxt * P.ld, row_bytes);
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u)
+                    xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
+            }
+        }
+        __syncthreads();
+        ICV_PHASE(0)
+
+        // ---------------- S: block partial sums (registers), then over the dead row -------
+        asm volatile("" : "+v"(tl));
+        {
+            double s0[MAXB], s1[MAXB];
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                s0[i] = 0.0;
+                s1[i] = 0.0;
+                const int b = tl + i * NT;
+                if (b < NB) {
+                    const float* rp = row + b * B;
+                    if constexpr (BT > 0 && (BT & 1) == 0) {
+                        const float2* rp2 = reinterpret_cast<const float2*>(rp);
+#pragma unroll
+                        for (int r = 0; r < BT; r += 2) {
+                            const float2 v2 = rp2[r >> 1];
+                            block_accumulate((double)v2.x, r, s0[i], s1[i]);
+                            block_accumulate((double)v2.y, r + 1, s0[i], s1[i]);
+                        }
+                    } else if constexpr (BT > 0) {
+#pragma unroll
+                        for (int r = 0; r < BT; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
+                    } else {
+#pragma unroll 1
+                        for (int r = 0; r < B; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int b = tl + i * NT;
+                if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
+            }
+            __syncthreads();
+        }
+        ICV_PHASE(1)
+
+        // ---------------- W: windows, kept in registers -----------------------------------
+        asm volatile("" : "+v"(tl));
+        double wv[MAXW];
+        int lnan = 0;
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            wv[i] = 0.0;
+            if (tl + i * NT < W) {
+                int wp = w_pack[i];
+                asm volatile("" : "+v"(wp));  // keep the decode inside the loop (register budget)
+                const int ln = wp >> 16;
+                const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
+                double v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
+                    const double2 s = sp[m];
+                    a = s.x;
+                    b2 = s.y;
+                });
+                v = finish_window(v, ln, pyr_den, pyr_rcp, (double)w_gc[i]);
+                wv[i] = v;
+                lnan |= (v != v);
+            }
+        }
+        ICV_PHASE(2)
+
+        // ---------------- M: median (np.median, reference :442) ---------------------------
+        // order statistics k1 <= k2 (0-based) stay inside (lo, hi]; cnt_x = #{w <= x}
+        const int k1 = (W - 1) / 2, k2 = W / 2;
+        double lo = -P.med_bound, hi = P.med_bound;
+        int cnt_lo = 0, cnt_hi = W;
+        int it = 0, anynan = 0, split = 0;
+        double med = 0.0, a_val = 0.0, b_val = 0.0;
+        while (true) {
+            double mid;
+            const int inside = cnt_hi - cnt_lo;
+            if (it >= 1 && inside <= 64) break;
+            if (it < 60) {
+                // count interpolation (every third step plain bisection as a safeguard)
+                double f = (it % 3 == 2) ? 0.5 : ((double)(k1 - cnt_lo) + 0.5) / (double)inside;
+                f = f < 0.02 ? 0.02 : (f > 0.98 ? 0.98 : f);
+                mid = lo + (hi - lo) * f;
+            } else {
+                const unsigned long long a = ordered_key(lo), b = ordered_key(hi);
+                mid = from_ordered_key(a + ((b - a) >> 1));
+            }
+            if (!(mid > lo && mid < hi)) {
+                mid = 0.5 * lo + 0.5 * hi;
+                if (!(mid > lo && mid < hi)) break;  // adjacent doubles: every candidate == hi
+            }
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                const bool in = (tl + i * NT < W) && (wv[i] <= mid);
+                c += __popcll(__builtin_amdgcn_ballot_w64(in));
+            }
+            const unsigned long long nanmask = (it == 0) ? __builtin_amdgcn_ballot_w64(lnan != 0) : 0ull;
+            if ((tl & 63) == 0) {
+                sc->icnt[it & 1][tl >> 6] = c;
+                if (it == 0) sc->nanw[tl >> 6] = nanmask != 0ull;
+            }
+            __syncthreads();
+            c = 0;
+#pragma unroll
+            for (int i = 0; i < NWAVE; ++i) c += sc->icnt[it & 1][i];
+            if (it == 0) {
+#pragma unroll
+                for (int i = 0; i < NWAVE; ++i) anynan |= sc->nanw[i];
+                if (anynan) break;
+            }
+            if (c > k2) { hi = mid; cnt_hi = c; }
+            else if (c <= k1) { lo = mid; cnt_lo = c; }
+            else { split = 1; a_val = mid; break; }  // k1 < c <= k2: pivot separates the two middles
+            if (++it >= 200) break;
+        }
+        if (anynan) {
+            med = __builtin_nan("");
+        } else if (split) {
+            // a = max{w <= pivot}, b = min{w > pivot}
+            double mx = -__builtin_inf(), mn = __builtin_inf();
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                if (tl + i * NT < W) {
+                    if (wv[i] <= a_val) mx = wv[i] > mx ? wv[i] : mx;
+                    else mn = wv[i] < mn ? wv[i] : mn;
+                }
+            }
+            mx = wave_max_dpp(mx);
+            mn = wave_min_dpp(mn);
+            if ((tl & 63) == 0) { sc->dmax[tl >> 6] = mx; sc->dmin[tl >> 6] = mn; }
+            __syncthreads();
+            mx = sc->dmax[0];
+            mn = sc->dmin[0];
+#pragma unroll
+            for (int i = 1; i < NWAVE; ++i) {
+                mx = sc->dmax[i] > mx ? sc->dmax[i] : mx;
+                mn = sc->dmin[i] < mn ? sc->dmin[i] : mn;
+            }
+            med = (mx + mn) / 2.0;
+        } else if (cnt_hi - cnt_lo <= 64) {
+            // rank the <= 64 candidates exactly: thread (i, p) compares candidate i with 8 others
+            if (tl < 64) sc->rank[tl] = 0;
+            if (tl == 0) sc->ncand = 0;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                if (tl + i * NT < W && wv[i] > lo && wv[i] <= hi) {
+                    const int idx = atomicAdd(&sc->ncand, 1);
+                    if (idx < 64) sc->cand[idx] = wv[i];
+                }
+            }
+            __syncthreads();
+            const int n = sc->ncand < 64 ? sc->ncand : 64;
+            {
+                const int ci = tl & 63, part = tl >> 6;
+                if (ci < n) {
+                    const double mine = sc->cand[ci];
+                    int r = 0;
+                    for (int jj = part * 8; jj < part * 8 + 8 && jj < n; ++jj) {
+                        const double o = sc->cand[jj];
+                        r += (o < mine || (o == mine && jj < ci)) ? 1 : 0;
+                    }
+                    if (r) atomicAdd(&sc->rank[ci], r);
+                }
+            }
+            __syncthreads();
+            if (tl < n) {
+                const int r = sc->rank[tl];
+                if (r == k1 - cnt_lo) sc->sel[0] = sc->cand[tl];
+                if (r == k2 - cnt_lo) sc->sel[1] = sc->cand[tl];
+            }
+            __syncthreads();
+            a_val = sc->sel[0];
+            b_val = sc->sel[1];
+            med = (k1 == k2) ? a_val : (a_val + b_val) / 2.0;
+        } else {
+            med = hi;  // more than 64 equal values around the median
+        }
+        ICV_PHASE(3)
+
+        // ---------------- O: centre, store, per-cell moments ------------------------------
+        asm volatile("" : "+v"(tl));
+        double sum = 0.0, sq = 0.0;
+        float* orow = P.out + cell * P.ldo;
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i) {
+            const int j = tl + i * NT;
+            if (j < W) {
+                const double y = wv[i] - med;
+                orow[j] = (float)y;
+                sum = sum + y;
+                sq = fma(y, y, sq);
+            }
+        }
+        sum = wave_sum_dpp(sum);
+        sq = wave_sum_dpp(sq);
+        if ((tl & 63) == 0) { sc->dsum[tl >> 6] = sum; sc->dsq[tl >> 6] = sq; }
+        __syncthreads();
+        if (tl == 0) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int i = 0; i < NWAVE; ++i) { s += sc->dsum[i]; q += sc->dsq[i]; }
+            P.cell_stats[2 * cell] = s;
+            P.cell_stats[2 * cell + 1] = q;
+            P.cell_median[cell] = med;
+        }
+        ICV_PHASE(4)
+    }
+    if (P.dbg && t == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(P.dbg + i, tacc[i]);
+#undef ICV_PHASE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -547,15 +978,18 @@ __device__ double recompute_window(const KParams& P, int64_t cell, int j) {
         return (double)centre_clip<T>(x, ref_lo[g], ref_hi[g], cap, P.bounded, P.trunc);
     };
     const int st = P.w_start[j], ln = P.w_len[j];
+    double acc;
     if (P.B > 1) {
         const int B = P.B;
-        return window_from_blocks(ln, B, P.w_denom[j], [&](int m, double& s0, double& s1) {
+        acc = window_from_blocks(ln, B, [&](int m, double& s0, double& s1) {
             s0 = 0.0;
             s1 = 0.0;
             for (int r = 0; r < B; ++r) block_accumulate(value_at(st + m * B + r), r, s0, s1);
         });
+    } else {
+        acc = window_direct(ln, [&](int k) { return value_at(st + k); });
     }
-    return window_direct(ln, P.w_denom[j], [&](int k) { return value_at(st + k); });
+    return finish_window(acc, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
 }
 
 template <typename T, bool CSR>

@@ -17,6 +17,8 @@ constexpr int kThreads = 512;          // workgroup size of the smoothing kernel
 constexpr int kMaxBlocksPerThread = 8; // register-buffered partial sums (aliased LDS layout)
 constexpr int kLdsLimit = 160 * 1024;  // gfx950: 160 KiB LDS per CU / per workgroup
 constexpr int kScratchBytes = 1024;    // struct Scratch, rounded up
+constexpr int kFastScratchBytes = 1280;  // struct ScratchF
+constexpr int kFastUMax = 10;          // 16-byte loads per lane held in registers (fast path)
 
 struct Layout {
     int elem_bytes = 4;
@@ -43,6 +45,11 @@ struct Plan {
     std::vector<int32_t> w_len;      // W: >0 pyramid length (genes); <0 flat over -len padded positions
     std::vector<double> w_denom;     // W: sum of weights / gene count
     std::vector<int32_t> w_start_sorted, w_len_sorted;  // sorted-gene coordinates, for the API
+    std::vector<int32_t> pad_idx;    // padded positions without a gene
+    std::vector<uint16_t> dst16;     // fast path: kFastUMax*kThreads*4 entries, Gp (trash slot) = masked
+    double pyr_den = 1.0, pyr_rcp = 1.0;
+    bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
+    int fast_lds = 0, fast_scratch_off = 0;
     Layout lay32, lay64;
 };
 
@@ -158,6 +165,27 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
     }
     p.lay32 = make_layout(p, 4);
     p.lay64 = make_layout(p, 8);
+
+    p.pad_idx.clear();
+    for (int i = 0; i < p.Gp; ++i)
+        if (p.src[i] < 0) p.pad_idx.push_back(i);
+    p.pyr_den = (window % 2 == 0) ? (double)(window / 2) * (double)(window / 2 + 1)
+                                  : (double)((window + 1) / 2) * (double)((window + 1) / 2);
+    p.pyr_rcp = 1.0 / p.pyr_den;
+
+    // fast path: float32 dense, blocked form, row + tables fit the register/LDS budget
+    p.fast_ok = false;
+    if (B > 1 && n_cols_all % 4 == 0 && n_cols_all <= kFastUMax * kThreads * 4 && p.Gp < 65535 &&
+        window <= 32767 && p.Gp <= 32767 * 1) {
+        int data = round_up((p.Gp + 1) * 4, 16);  // + trash slot for masked columns
+        if (16 * p.NB > data) data = 16 * p.NB;
+        p.fast_scratch_off = round_up(data, 16);
+        p.fast_lds = p.fast_scratch_off + kFastScratchBytes;
+        p.fast_ok = p.fast_lds <= kLdsLimit;
+        p.dst16.assign((size_t)kFastUMax * kThreads * 4, (uint16_t)p.Gp);
+        for (int g = 0; g < n_cols_all; ++g)
+            if (p.dst[g] >= 0) p.dst16[g] = (uint16_t)p.dst[g];
+    }
     return "";
 }
 
