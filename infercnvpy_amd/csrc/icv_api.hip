@@ -154,23 +154,26 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
     if (std::getenv("ICV_PHASE_PROFILE")) {
         // developer diagnostic: shader cycles per phase, summed over workgroups (thread 0 of each)
         unsigned long long* d = nullptr;
-        HIP_TRY(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d, 0, 5 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&d, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
         icv::KParams K2 = K;
         K2.dbg = d;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K2);
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long h[5];
+        unsigned long long h[8];
         HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
         (void)hipFree(d);
-        const char* names[5] = {"L load+scatter", "S block sums", "W windows", "M median", "O output"};
+        const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
+                                "M1 pivot search"};
         double tot = 0;
-        for (auto v : h) tot += (double)v;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
         std::fprintf(stderr, "[icv phase profile] grid=%lld rows=%lld lds=%d\n", (long long)grid,
                      (long long)K.n_rows, lds);
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 6; ++i)
             std::fprintf(stderr, "  %-16s %12.0f cycles/cell  %5.1f %%\n", names[i], (double)h[i] / (double)K.n_rows,
                          100.0 * (double)h[i] / tot);
+        std::fprintf(stderr, "  median iterations/cell %.2f, split cells %.4f\n", (double)h[6] / (double)K.n_rows,
+                     (double)h[7] / (double)K.n_rows);
         return ICV_OK;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K);
@@ -185,11 +188,12 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
     const int need_w = (p.W + icv::kThreads - 1) / icv::kThreads;
     void (*kern)(const icv::KParams) = nullptr;
     constexpr int U = icv::kFastUMax;
-    if (need_b <= 4 && p.B == 10) kern = icv::k_smooth_fast<U, 4, 4, 10>;
-    else if (need_b <= 4) kern = icv::k_smooth_fast<U, 4, 4, 0>;
-    else if (need_w <= 4 && p.B == 5) kern = icv::k_smooth_fast<U, 8, 4, 5>;
-    else if (need_w <= 4) kern = icv::k_smooth_fast<U, 8, 4, 0>;
-    else kern = icv::k_smooth_fast<U, 8, 8, 0>;
+    if (need_b <= 4 && p.B == 10 && p.window == 100) kern = icv::k_smooth_fast<U, 4, 4, 10, 10>;
+    else if (need_b <= 4 && p.B == 10) kern = icv::k_smooth_fast<U, 4, 4, 10, 0>;
+    else if (need_b <= 4) kern = icv::k_smooth_fast<U, 4, 4, 0, 0>;
+    else if (need_w <= 4 && p.B == 5) kern = icv::k_smooth_fast<U, 8, 4, 5, 0>;
+    else if (need_w <= 4) kern = icv::k_smooth_fast<U, 8, 4, 0, 0>;
+    else kern = icv::k_smooth_fast<U, 8, 8, 0, 0>;
     K.scratch_off = p.fast_scratch_off;
     int per_cu = icv::kLdsLimit / p.fast_lds;
     if (per_cu > 4) per_cu = 4;

@@ -209,6 +209,47 @@ __device__ __forceinline__ double from_ordered_key(unsigned long long k) {
 }
 
 // ---------------------------------------------------------------------------------------
+// DPP wavefront reductions (no LDS traffic, unlike __shfl): butterfly inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row values are
+// read back as scalars and combined in a fixed order -> deterministic, result uniform.
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
+}
+__device__ __forceinline__ double wave_min_dpp(double v) {
+    double o;
+    o = dpp_move<0xB1>(v); v = o < v ? o : v;
+    o = dpp_move<0x4E>(v); v = o < v ? o : v;
+    o = dpp_move<0x141>(v); v = o < v ? o : v;
+    o = dpp_move<0x140>(v); v = o < v ? o : v;
+    double a = readlane_d(v, 0), b = readlane_d(v, 16), c = readlane_d(v, 32), d = readlane_d(v, 48);
+    a = b < a ? b : a;
+    c = d < c ? d : c;
+    return c < a ? c : a;
+}
+__device__ __forceinline__ double wave_max_dpp(double v) { return -wave_min_dpp(-v); }
+
+// ---------------------------------------------------------------------------------------
 // the fused smoothing kernel
 // ---------------------------------------------------------------------------------------
 template <typename T> struct Vec16;
@@ -478,8 +519,8 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
             sum = sum + y;
             sq = fma(y, y, sq);
         }
-        sum = wave_sum(sum);
-        sq = wave_sum(sq);
+        sum = wave_sum_dpp(sum);  // same reduction tree as k_smooth_fast: bit-identical moments
+        sq = wave_sum_dpp(sq);
         if (lane == 0) {
             sc->dred[2][0][wave] = sum;
             sc->dred[2][1][wave] = sq;
@@ -510,43 +551,6 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
 }
 
 // ---------------------------------------------------------------------------------------
-// DPP wavefront reductions (no LDS traffic, unlike __shfl): butterfly inside each row of 16
-// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row values are
-// read back as scalars and combined in a fixed order -> deterministic, result uniform.
-// ---------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_move<0x141>(v);  // row_half_mirror
-    v += dpp_move<0x140>(v);  // row_mirror
-    return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
-}
-__device__ __forceinline__ double wave_min_dpp(double v) {
-    double o;
-    o = dpp_move<0xB1>(v); v = o < v ? o : v;
-    o = dpp_move<0x4E>(v); v = o < v ? o : v;
-    o = dpp_move<0x141>(v); v = o < v ? o : v;
-    o = dpp_move<0x140>(v); v = o < v ? o : v;
-    double a = readlane_d(v, 0), b = readlane_d(v, 16), c = readlane_d(v, 32), d = readlane_d(v, 48);
-    a = b < a ? b : a;
-    c = d < c ? d : c;
-    return c < a ? c : a;
-}
-__device__ __forceinline__ double wave_max_dpp(double v) { return -wave_min_dpp(-v); }
-
-// ---------------------------------------------------------------------------------------
 // Fast path of the smoothing kernel: dense float32, blocked form (B > 1), G <= 20480.
 //   * the NEXT cell's row is prefetched into registers (UMAX 16-byte loads per lane) right
 //     after the current row has been scattered, so HBM latency is covered by the S/W/M/O phases;
@@ -558,13 +562,15 @@ __device__ __forceinline__ double wave_max_dpp(double v) { return -wave_min_dpp(
 // Same float64 evaluation order as k_smooth: results are bit-identical.
 // ---------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     // raw buffer descriptor: base, stride 0, num_records = bytes (out-of-range lanes read 0)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+constexpr int NPIV = 6;  // pivots counted per median iteration
 struct ScratchF {
-    int icnt[2][NWAVE];
+    int pc[2][NPIV][NWAVE];  // [iteration parity][pivot][wave] partial counts
     int nanw[NWAVE];
     int ncand;
     int r1_found, r2_found;
@@ -574,9 +580,10 @@ struct ScratchF {
     double dsum[NWAVE], dsq[NWAVE];
     double dmin[NWAVE], dmax[NWAVE];
 };
-static_assert(sizeof(ScratchF) <= 1280, "ScratchF must fit the scratch region");
+static_assert(sizeof(ScratchF) <= 1536, "ScratchF must fit the scratch region");
 
-template <int UMAX, int MAXB, int MAXW, int BT /* compile-time block size, 0 = runtime */>
+template <int UMAX, int MAXB, int MAXW, int BT /* compile-time block size, 0 = runtime */,
+          int NBW /* compile-time blocks per pyramid window, 0 = runtime */>
 __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* row = reinterpret_cast<float*>(smem);
@@ -595,9 +602,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
     const float* xbase = static_cast<const float*>(P.values);
 
     // ---- per-thread constants, loaded once --------------------------------------------
-    uint2 d16[UMAX];  // 4 packed 16-bit LDS positions per 16-byte load
-#pragma unroll
-    for (int u = 0; u < UMAX; ++u) d16[u] = reinterpret_cast<const uint2*>(P.dst16)[u * NT + t];
+    // scatter table: 4 packed 16-bit LDS positions per 16-byte load, re-read from L2 every cell
+    // (holding it in registers costs 20 VGPRs and pushed the kernel into scratch spills)
+    const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(UMAX * NT * 8));
+    const unsigned voff8 = (unsigned)t * 8u;
     int w_pack[MAXW];  // start block (low 16) | signed length in genes (high 16)
     int w_gc[MAXW];    // flat windows: gene count of the chromosome
 #pragma unroll
@@ -612,6 +620,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
         }
     }
 
+    unsigned gi = 0;  // median iterations since kernel start (selects the counter slot)
+
     // ---- prefetch the first row ----------------------------------------------------------
     u32x4 xq[UMAX];
     {
@@ -621,7 +631,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
     }
     __syncthreads();
 
-    unsigned long long tlast = 0, tacc[5] = {0, 0, 0, 0, 0};
+    unsigned long long tlast = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define ICV_PHASE(i)                                            \
     if (P.dbg && t == 0) {                                      \
         unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -648,8 +658,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
 // unpacked addresses out of the cell loop (they would cost 40 VGPRs for the whole kernel).
 #define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
     {                                                                                                            \
-        unsigned dx_ = (D).x, dy_ = (D).y;                                                                       \
-        asm volatile("" : "+v"(dx_), "+v"(dy_));                                                                 \
+        const unsigned dx_ = (D).x, dy_ = (D).y;                                                                 \
         row[dx_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).x), __uint_as_float((LO).x),                 \
                                                 __uint_as_float((HI).x), cap, BND, P.trunc);                     \
         row[dx_ >> 16] = centre_clip<float>(__uint_as_float((X).y), __uint_as_float((LO).y),                     \
@@ -663,11 +672,14 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
 #pragma unroll
             for (int h = 0; h < UMAX; h += UH) {
                 u32x4 lo[UH];
+                u32x2 dd[UH];
 #pragma unroll
-                for (int k = 0; k < UH; ++k)
+                for (int k = 0; k < UH; ++k) {
                     lo[k] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, (h + k) * NT * 16, 0);
+                    dd[k] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, (h + k) * NT * 8, 0);
+                }
 #pragma unroll
-                for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], d16[h + k], 0)
+                for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], dd[k], 0)
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -675,7 +687,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
             for (int u = 0; u < UMAX; ++u) {
                 const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * NT * 16, 0);
                 const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(hi_rs, voff, u * NT * 16, 0);
-                ICV_SCATTER4(xq[u], lo, hi, d16[u], 1)
+                const u32x2 dd = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, u * NT * 8, 0);
+                ICV_SCATTER4(xq[u], lo, hi, dd, 1)
             }
         }
 #undef ICV_SCATTER4
@@ -736,18 +749,45 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
         int lnan = 0;
 #pragma unroll
         for (int i = 0; i < MAXW; ++i) {
-            wv[i] = 0.0;
+            wv[i] = __builtin_inf();  // slots beyond W never count as <= pivot
             if (tl + i * NT < W) {
-                int wp = w_pack[i];
-                asm volatile("" : "+v"(wp));  // keep the decode inside the loop (register budget)
+                int wp = w_pack[i], gc = w_gc[i];
+                asm volatile("" : "+v"(wp), "+v"(gc));  // keep the decode inside the loop (register budget)
                 const int ln = wp >> 16;
                 const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
-                double v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
-                    const double2 s = sp[m];
-                    a = s.x;
-                    b2 = s.y;
-                });
-                v = finish_window(v, ln, pyr_den, pyr_rcp, (double)w_gc[i]);
+                double v;
+                if constexpr (BT > 0 && NBW > 0) {
+                  if (ln == NBW * BT) {
+                    // same operation order as window_from_blocks, fully unrolled: all LDS reads first
+                    double2 sb[NBW > 0 ? NBW : 1];
+#pragma unroll
+                    for (int m = 0; m < NBW; ++m) sb[m] = sp[m];
+                    v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NBW; ++m) {
+                        if (m < NBW / 2) {
+                            v = fma((double)(m * BT + 1), sb[m].x, v);
+                            v = v + sb[m].y;
+                        } else {
+                            v = fma((double)(NBW * BT - m * BT), sb[m].x, v);
+                            v = v - sb[m].y;
+                        }
+                    }
+                  } else {
+                    v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
+                        const double2 s = sp[m];
+                        a = s.x;
+                        b2 = s.y;
+                    });
+                  }
+                } else {
+                    v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
+                        const double2 s = sp[m];
+                        a = s.x;
+                        b2 = s.y;
+                    });
+                }
+                v = finish_window(v, ln, pyr_den, pyr_rcp, (double)gc);
                 wv[i] = v;
                 lnan |= (v != v);
             }
@@ -761,48 +801,85 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
         int cnt_lo = 0, cnt_hi = W;
         int it = 0, anynan = 0, split = 0;
         double med = 0.0, a_val = 0.0, b_val = 0.0;
+        int mode = 0;  // 0: pivots around the count-interpolated position, 1: uniform 7-section
+        const int pl = tl & 7;  // lanes 0..5 of every wavefront each build one pivot
         while (true) {
-            double mid;
             const int inside = cnt_hi - cnt_lo;
             if (it >= 1 && inside <= 64) break;
-            if (it < 60) {
-                // count interpolation (every third step plain bisection as a safeguard)
-                double f = (it % 3 == 2) ? 0.5 : ((double)(k1 - cnt_lo) + 0.5) / (double)inside;
-                f = f < 0.02 ? 0.02 : (f > 0.98 ? 0.98 : f);
-                mid = lo + (hi - lo) * f;
+            const double mid = 0.5 * lo + 0.5 * hi;
+            if (!(mid > lo && mid < hi)) break;  // adjacent doubles: every candidate == hi
+            // NPIV pivots strictly inside (lo, hi); any choice is correct, the choice only sets the
+            // number of iterations (typically 2-3: each costs one workgroup barrier round trip)
+            double x;
+            if (it < 40) {
+                float f;
+                if (mode == 0) {
+                    const float inv = 1.0f / (float)inside;
+                    const float fc = ((float)(k1 - cnt_lo) + 0.5f) * inv, d = 24.0f * inv;
+                    const float mag = ldexpf(0.5f, 2 * (pl < 3 ? 2 - pl : pl - 3));  // .5, 2, 8
+                    f = fc + (pl < 3 ? -mag : mag) * d;
+                } else {
+                    f = (float)(pl + 1) * (1.0f / (float)(NPIV + 1));
+                }
+                f = f < 1e-4f ? 1e-4f : (f > 0.9999f ? 0.9999f : f);
+                x = lo + (hi - lo) * (double)f;
             } else {
                 const unsigned long long a = ordered_key(lo), b = ordered_key(hi);
-                mid = from_ordered_key(a + ((b - a) >> 1));
+                x = from_ordered_key(a + ((b - a) >> 1));
             }
-            if (!(mid > lo && mid < hi)) {
-                mid = 0.5 * lo + 0.5 * hi;
-                if (!(mid > lo && mid < hi)) break;  // adjacent doubles: every candidate == hi
-            }
-            int c = 0;
+            x = (x > lo && x < hi) ? x : mid;
+            double piv[NPIV];
+#pragma unroll
+            for (int p = 0; p < NPIV; ++p) piv[p] = readlane_d(x, p);
+            int cw[NPIV];
+#pragma unroll
+            for (int p = 0; p < NPIV; ++p) cw[p] = 0;
 #pragma unroll
             for (int i = 0; i < MAXW; ++i) {
-                const bool in = (tl + i * NT < W) && (wv[i] <= mid);
-                c += __popcll(__builtin_amdgcn_ballot_w64(in));
+#pragma unroll
+                for (int p = 0; p < NPIV; ++p)  // slots without a window hold +inf
+                    cw[p] += __popcll(__builtin_amdgcn_ballot_w64(wv[i] <= piv[p]));
             }
             const unsigned long long nanmask = (it == 0) ? __builtin_amdgcn_ballot_w64(lnan != 0) : 0ull;
-            if ((tl & 63) == 0) {
-                sc->icnt[it & 1][tl >> 6] = c;
-                if (it == 0) sc->nanw[tl >> 6] = nanmask != 0ull;
+            const unsigned slot = gi & 1u;
+            {
+                int myc = cw[0];
+#pragma unroll
+                for (int p = 1; p < NPIV; ++p) myc = (pl == p) ? cw[p] : myc;
+                if ((tl & 63) < NPIV) sc->pc[slot][pl][tl >> 6] = myc;
+                if (it == 0 && (tl & 63) == 0) sc->nanw[tl >> 6] = nanmask != 0ull;
             }
             __syncthreads();
-            c = 0;
-#pragma unroll
-            for (int i = 0; i < NWAVE; ++i) c += sc->icnt[it & 1][i];
+            ++gi;
             if (it == 0) {
 #pragma unroll
                 for (int i = 0; i < NWAVE; ++i) anynan |= sc->nanw[i];
                 if (anynan) break;
             }
-            if (c > k2) { hi = mid; cnt_hi = c; }
-            else if (c <= k1) { lo = mid; cnt_lo = c; }
-            else { split = 1; a_val = mid; break; }  // k1 < c <= k2: pivot separates the two middles
+            // lane l < 8*NPIV reads (pivot l>>3, wave l&7); DPP sum over each group of 8 lanes
+            int cv = ((tl & 63) < 8 * NPIV) ? (&sc->pc[slot][0][0])[tl & 63] : 0;
+            cv += dpp_move_i<0xB1>(cv);
+            cv += dpp_move_i<0x4E>(cv);
+            cv += dpp_move_i<0x141>(cv);
+#pragma unroll
+            for (int p = 0; p < NPIV; ++p) {
+                const int c = __builtin_amdgcn_readlane(cv, 8 * p);
+                const double xp = piv[p];
+                if (c <= k1) {
+                    if (xp > lo) { lo = xp; cnt_lo = c; }
+                } else if (c > k2) {
+                    if (xp < hi) { hi = xp; cnt_hi = c; }
+                } else {  // k1 < c <= k2: this pivot separates the two middle elements
+                    split = 1;
+                    a_val = xp;
+                }
+            }
+            if (split) break;
+            mode = ((cnt_hi - cnt_lo) * 2 > inside) ? 1 : 0;
             if (++it >= 200) break;
         }
+        ICV_PHASE(5)
+        if (P.dbg && t == 0) { tacc[6] += (unsigned long long)it; tacc[7] += (unsigned long long)split; }
         if (anynan) {
             med = __builtin_nan("");
         } else if (split) {
@@ -897,7 +974,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
         ICV_PHASE(4)
     }
     if (P.dbg && t == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd(P.dbg + i, tacc[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(P.dbg + i, tacc[i]);
 #undef ICV_PHASE
 }
 

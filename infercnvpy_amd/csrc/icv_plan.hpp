@@ -17,7 +17,7 @@ constexpr int kThreads = 512;          // workgroup size of the smoothing kernel
 constexpr int kMaxBlocksPerThread = 8; // register-buffered partial sums (aliased LDS layout)
 constexpr int kLdsLimit = 160 * 1024;  // gfx950: 160 KiB LDS per CU / per workgroup
 constexpr int kScratchBytes = 1024;    // struct Scratch, rounded up
-constexpr int kFastScratchBytes = 1280;  // struct ScratchF
+constexpr int kFastScratchBytes = 1536;  // struct ScratchF
 constexpr int kFastUMax = 10;          // 16-byte loads per lane held in registers (fast path)
 
 struct Layout {

@@ -248,10 +248,10 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
             v[key] = v[key][:n_genes4]
         plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=step)
         X = torch.from_numpy(cases.synthetic_expr(700, n_genes4, seed=21)).cuda()
-        X[5] = 0  # a constant row: every window equal (> 64 ties at the median)
+        ref = X[7:].mean(dim=0)
+        X[5] = ref  # centred row is all zero: every window equal (> 64 ties at the median)
         X[6, 17] = float("nan")
         dm = _engine.DeviceMatrix(dense=X)
-        ref = X[7:].mean(dim=0)
         monkeypatch.delenv("ICV_FORCE_GENERIC", raising=False)
         fast = _engine.run_hot_path(plan, dm, ref, chunksize=300)
         torch.cuda.synchronize()

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 
 echo "== phase profile" | tee "$OUT/phase.txt"
-ICV_PHASE_PROFILE=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep -A6 "icv phase" | tee -a "$OUT/phase.txt"
+ICV_PHASE_PROFILE=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep -A8 "icv phase" | tee -a "$OUT/phase.txt"
 
 echo "== rocprofv3 kernel stats"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH > "$OUT/rocprof_stats.log" 2>&1)
