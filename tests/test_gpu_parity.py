@@ -266,6 +266,48 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         assert (fast.out[5] == 0).all()
 
 
+def test_unaligned_shards_match_single_run():
+    """Two row shards cut in the middle of a std-chunk (what ``dist.run_shard`` does per rank, here
+    sequentially on one GPU): chunk moments summed across shards give the same thresholds and the
+    same thresholded rows as one run over all rows."""
+    import ctypes as C
+
+    import torch
+
+    from infercnvpy_amd import _engine, _lib, dist as icd
+    from infercnvpy_amd._plan import GenePlan
+
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+    X = torch.from_numpy(cases.synthetic_expr(1100, 20000, seed=41)).cuda()
+    ref = X.mean(dim=0)
+    cs = 400
+    whole = _engine.run_hot_path(plan, _engine.DeviceMatrix(dense=X), ref, chunksize=cs)
+    cut = 537
+    parts, moments = [], []
+    for r0, r1 in ((0, cut), (cut, 1100)):
+        dm = _engine.DeviceMatrix(dense=X[r0:r1].contiguous())
+        res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=None)
+        parts.append((r0, r1, dm, res))
+        moments.append(icd.chunk_moments(res.cell_stats, r0, cs, 3))
+    thr_all = icd.thresholds_from_moments(moments[0] + moments[1], plan.n_windows, 1.5)
+    np.testing.assert_allclose(thr_all.cpu().numpy(), whole.thr.cpu().numpy(), rtol=1e-13)
+    lib = _lib.load()
+    for r0, r1, dm, res in parts:
+        k0 = r0 // cs
+        thr = thr_all[k0:(r1 - 1) // cs + 1].contiguous()
+        m = dm.c_struct()
+        _lib.check(lib.icv_apply_threshold(
+            plan.handle, C.byref(m), _engine._ptr(ref), None, 3.0, 0, _engine._ptr(res.out), res.out.stride(0),
+            _engine._ptr(res.cell_median), _engine._ptr(thr), cs, r0 % cs, _engine._stream_ptr(torch)))
+        torch.cuda.synchronize()
+        assert torch.equal(res.out, whole.out[r0:r1])
+    # run_shard with a chunk-aligned shard and no process group is the plain single-GPU path
+    dm = _engine.DeviceMatrix(dense=X[400:800].contiguous())
+    res = icd.run_shard(plan, dm, ref, global_row0=400, n_obs_global=1100, chunksize=cs)
+    assert torch.equal(res.out, whole.out[400:800])
+
+
 # ---- properties at the benchmark size ---------------------------------------------------------
 def _bench_inputs(n_cells, seed=2):
     import torch
