@@ -13,6 +13,7 @@
 #include <string>
 
 #include "icv_kernels.hpp"
+#include "icv_kernel_ws.hpp"
 #include "icv_plan.hpp"
 
 namespace {
@@ -42,6 +43,10 @@ struct icv_plan_s {
     int32_t *d_dst = nullptr, *d_src = nullptr, *d_wstart = nullptr, *d_wlen = nullptr;
     double* d_wdenom = nullptr;
     int32_t* d_pad = nullptr;
+    int32_t* d_wpack = nullptr;
+    int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
+    int* d_row_count = nullptr;
+    int64_t row_list_cap = 0;
     uint16_t* d_dst16 = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
@@ -70,6 +75,7 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.w_len.data(), p.w_len.size() * 4, (void**)&pl->d_wlen));
     HIP_TRY(up(p.w_denom.data(), p.w_denom.size() * 8, (void**)&pl->d_wdenom));
     HIP_TRY(up(p.pad_idx.data(), p.pad_idx.size() * 4, (void**)&pl->d_pad));
+    HIP_TRY(up(p.w_pack.data(), p.w_pack.size() * 4, (void**)&pl->d_wpack));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
@@ -129,6 +135,7 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.w_denom = pl->d_wdenom;
     K.dst16 = pl->d_dst16;
     K.pad_idx = pl->d_pad;
+    K.w_pack = pl->d_wpack;
     K.n_pad = (int32_t)p.pad_idx.size();
     K.pyr_den = p.pyr_den;
     K.pyr_rcp = p.pyr_rcp;
@@ -172,8 +179,9 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
         for (int i = 0; i < 6; ++i)
             std::fprintf(stderr, "  %-16s %12.0f cycles/cell  %5.1f %%\n", names[i], (double)h[i] / (double)K.n_rows,
                          100.0 * (double)h[i] / tot);
-        std::fprintf(stderr, "  median iterations/cell %.2f, split cells %.4f\n", (double)h[6] / (double)K.n_rows,
-                     (double)h[7] / (double)K.n_rows);
+        std::fprintf(stderr, "  [6] %.2f  [7] %.4f per cell (fast: median iterations, split cells; ws: phases are "
+                             "A-wait, gather+L, B1-wait, S+emit, S01+B3, W+B4; [6] = selector scan cycles, [7] = fallback cells)\n",
+                     (double)h[6] / (double)K.n_rows, (double)h[7] / (double)K.n_rows);
         return ICV_OK;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K);
@@ -195,12 +203,44 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
     else if (need_w <= 4) kern = icv::k_smooth_fast<U, 8, 4, 0, 0>;
     else kern = icv::k_smooth_fast<U, 8, 8, 0, 0>;
     K.scratch_off = p.fast_scratch_off;
+    bool use_ws = false;
+    if (p.ws_ok && !std::getenv("ICV_NO_WS")) {
+        kern = (p.B == 10 && p.window == 100) ? icv::k_smooth_ws<U, 4, 4, 10, 10> : icv::k_smooth_ws<U, 4, 4, 0, 0>;
+        use_ws = true;
+        K.hist_off = p.ws_hist_off;
+        if (pl->row_list_cap < K.n_rows) {
+            (void)hipFree(pl->d_row_list);
+            pl->d_row_list = nullptr;
+            HIP_TRY(hipMalloc((void**)&pl->d_row_list, (size_t)K.n_rows * sizeof(int64_t)));
+            pl->row_list_cap = K.n_rows;
+        }
+        if (!pl->d_row_count) HIP_TRY(hipMalloc((void**)&pl->d_row_count, sizeof(int)));
+        HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
+        K.row_list = pl->d_row_list;
+        K.row_count = pl->d_row_count;
+    }
     int per_cu = icv::kLdsLimit / p.fast_lds;
     if (per_cu > 4) per_cu = 4;
     int64_t grid = (int64_t)pl->n_cu * per_cu;
     if (grid > K.n_rows) grid = K.n_rows;
     if (grid < 1) return ICV_OK;
-    return run_kernel(kern, grid, p.fast_lds, K, st);
+    int rc = run_kernel(kern, grid, p.fast_lds, K, st);
+    if (rc || !use_ws) return rc;
+    // cells whose median bins held more than 64 windows: recompute them with the generic kernel
+    // (reads the device-side count; exits at once when the list is empty)
+    icv::KParams G = K;
+    G.win_off = p.lay32.win_off;
+    G.scratch_off = p.lay32.scratch_off;
+    G.dbg = nullptr;
+    const int need = (p.NB + icv::kThreads - 1) / icv::kThreads;
+    void (*gk)(const icv::KParams) = need <= 4 ? icv::k_smooth<float, false, 4> : icv::k_smooth<float, false, 8>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                p.lay32.total));
+    int64_t g2 = pl->n_cu;
+    if (g2 > K.n_rows) g2 = K.n_rows;
+    hipLaunchKernelGGL(gk, dim3((unsigned)g2), dim3(icv::NT), p.lay32.total, st, G);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
 }
 
 template <typename T, bool CSR>
@@ -302,6 +342,9 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_wlen);
         (void)hipFree(pl->d_wdenom);
         (void)hipFree(pl->d_pad);
+        (void)hipFree(pl->d_wpack);
+        (void)hipFree(pl->d_row_list);
+        (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_zrow);
     }

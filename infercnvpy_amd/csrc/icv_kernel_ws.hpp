@@ -1,0 +1,416 @@
+// k_smooth_ws: the fast smoothing kernel with a pipelined, iteration-free median
+// (dense float32, blocked form).  Same L / S / W phases as k_smooth_fast, all 8 wavefronts take part;
+// the median of cell k is resolved while cell k+1 flows through the same barriers:
+//   W(k)          every window value also increments one bin of a 4096-bin LDS histogram
+//                 (monotone piecewise-linear binning, so bins keep the rank order)
+//   before A(k+1) wavefront 0 scans the histogram (DPP prefix sums): bins b1, b2 of the two middle
+//                 order statistics, number of windows in lower bins
+//   after B1(k+1) every thread appends its windows of cell k that fall in b1 / b2 to cand[] (<= 64)
+//   before B3(k+1) wavefront 0 ranks the candidates exactly in float64 -> median
+//   after B3(k+1) x_res = window - median from the windows still in registers, store, moments
+// A cell whose bins hold more than 64 candidates is handed back (row_list) and recomputed by the
+// generic k_smooth right after this kernel; NaN cells are final here (median NaN).
+// 5 workgroup barriers per cell (k_smooth_fast: ~10, with 2-3 data-dependent search rounds):
+//   A  (histogram scanned, row free)        B1 (row scattered)
+//   B2 (block sums in registers, candidates complete)
+//   B3 ({S0,S1} in LDS, histogram cleared, median published)     B4 (histogram complete)
+// Arithmetic and evaluation order of windows and median are those of k_smooth / k_smooth_fast
+// (bit-identical x_res and moments).
+#pragma once
+#include "icv_kernels.hpp"
+
+namespace icv {
+
+constexpr int NBIN = 4096;  // 3072 bins over the central quarter of [-bound, bound], 512 per tail
+
+struct ScratchW {
+    int nanflag;
+    int mode;               // 0: gather candidates of bins b1/b2, 1: median final, 2: cell handed back
+    int b1, b2;
+    int ncand;
+    int below;              // windows in bins below b1
+    double med;             // median of the previous cell, published before B3
+    double psum[NWAVE], psq[NWAVE];  // per-wave moments of the previous cell
+    double cand[64];
+};
+static_assert(sizeof(ScratchW) <= 1536, "ScratchW must fit the scratch region");
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS traffic)
+__device__ __forceinline__ int wave_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// Monotone non-decreasing map window value -> histogram bin.  Piecewise linear: |v| < bound/8 is
+// resolved by 3072 bins (medians of centred, smoothed expression live there), the tails by 512 each.
+__device__ __forceinline__ int hist_bin(double v, float inv_bound) {
+    const float u = (float)v * inv_bound;  // in [-1, 1]
+    float f;
+    int lo_b, hi_b;
+    if (u < -0.125f) { f = (u + 1.0f) * (512.0f / 0.875f); lo_b = 0; hi_b = 511; }
+    else if (u < 0.125f) { f = fmaf(u + 0.125f, 3072.0f / 0.25f, 512.0f); lo_b = 512; hi_b = 3583; }
+    else { f = fmaf(u - 0.125f, 512.0f / 0.875f, 3584.0f); lo_b = 3584; hi_b = NBIN - 1; }
+    const int b = (int)floorf(f);
+    return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);  // segments stay disjoint under rounding
+}
+
+template <int UMAX, int MAXB, int MAXW, int BT, int NBW>
+__global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* row = reinterpret_cast<float*>(smem);
+    double* S01 = reinterpret_cast<double*>(smem);
+    int* hist = reinterpret_cast<int*>(smem + P.hist_off);
+    ScratchW* sc = reinterpret_cast<ScratchW*>(smem + P.scratch_off);
+
+    const int t = threadIdx.x;
+    const bool selector = __builtin_amdgcn_readfirstlane(t >> 6) == 0;  // wavefront 0 (wave-uniform)
+    const int W = P.W, NB = P.NB;
+    const int B = BT > 0 ? BT : P.B;
+    const int k1 = (W - 1) / 2, k2 = W / 2;
+    const float inv_bound = (float)(1.0 / P.med_bound);
+    const float cap = (float)P.cap;
+    const unsigned row_bytes = (unsigned)P.n_cols * 4u;
+    const unsigned voff = (unsigned)t * 16u, voff8 = (unsigned)t * 8u;
+    const __amdgpu_buffer_rsrc_t lo_rs = make_rsrc(P.ref_lo, row_bytes);
+    const __amdgpu_buffer_rsrc_t hi_rs = make_rsrc(P.bounded ? P.ref_hi : P.ref_lo, row_bytes);
+    const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(UMAX * NT * 8));
+    // window descriptors (start block | length << 16): re-read from L2 in every L phase, ahead of the
+    // row prefetch; as loop-carried registers they end up in scratch
+    const __amdgpu_buffer_rsrc_t wp_rs = make_rsrc(P.w_pack, (unsigned)W * 4u);
+    const double pyr_den = P.pyr_den, pyr_rcp = P.pyr_rcp;
+    const float* xbase = static_cast<const float*>(P.values);
+    // cells of this workgroup: blockIdx.x, +gridDim.x, ...; plus one pipeline-drain iteration
+    const int64_t n_mine = (P.n_rows - blockIdx.x + gridDim.x - 1) / gridDim.x;
+
+    if (t == 0) {
+        sc->nanflag = 0;
+        sc->mode = 1;
+        sc->ncand = 0;
+        sc->med = 0.0;
+    }
+    u32x4 xq[UMAX];
+    {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
+    }
+    constexpr int UH = 5;
+    static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
+    double wv[MAXW];  // this thread's windows of the previous cell (x_res needs its median)
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) wv[i] = 0.0;
+    __syncthreads();
+
+    // phase timers cost ~18 VGPRs for every lane: compiled in only with -DICV_WS_PROFILE
+#ifdef ICV_WS_PROFILE
+    unsigned long long tlast = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define ICV_PHASE(i)                                            \
+    if (P.dbg && t == 64) {                                     \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tacc[i] += now_ - tlast;                                \
+        tlast = now_;                                           \
+    }
+    if (P.dbg && t == 64) tlast = __builtin_amdgcn_s_memtime();
+#else
+#define ICV_PHASE(i)
+#endif
+
+    for (int64_t it = 0; it <= n_mine; ++it) {
+        const bool more = it < n_mine;  // a cell to smooth in this iteration
+        const bool have_prev = it > 0;  // a cell whose median is being resolved
+        const int64_t cell = (int64_t)blockIdx.x + it * gridDim.x;
+        const int64_t pcell = cell - gridDim.x;
+        int tl = t;
+        asm volatile("" : "+v"(tl));  // see k_smooth_fast: keep thread-derived values out of LICM
+
+        // ---------------- wavefront 0: scan the histogram of the previous cell --------------------
+        if (selector && have_prev) {
+            const int lane = tl;
+            if (sc->nanflag) {
+                if (lane == 0) {
+                    sc->nanflag = 0;
+                    sc->med = __builtin_nan("");
+                    sc->mode = 1;
+                }
+            } else {
+                // level 1: lane l sums bins [64 l, 64 l + 64); which lanes hold ranks k1 / k2
+                const int4* h4 = reinterpret_cast<const int4*>(hist) + lane * 16;
+                int tot = 0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int4 v = h4[q];
+                    tot += (v.x + v.y) + (v.z + v.w);
+                }
+                const int incl = wave_scan_dpp(tot);
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(incl > k1);
+                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(incl > k2);
+                const int l1 = m1 ? (int)__builtin_ctzll(m1) : 63, l2 = m2 ? (int)__builtin_ctzll(m2) : 63;
+                const int ex1 = __builtin_amdgcn_readlane(incl - tot, l1), ex2 = __builtin_amdgcn_readlane(incl - tot, l2);
+                // level 2: lane i looks at bin 64 l + i of the located group
+                const int c1 = hist[l1 * 64 + lane], c2 = hist[l2 * 64 + lane];
+                const int in1 = wave_scan_dpp(c1) + ex1, in2 = wave_scan_dpp(c2) + ex2;
+                const unsigned long long n1 = __builtin_amdgcn_ballot_w64(in1 > k1);
+                const unsigned long long n2 = __builtin_amdgcn_ballot_w64(in2 > k2);
+                const int j1 = n1 ? (int)__builtin_ctzll(n1) : 63, j2 = n2 ? (int)__builtin_ctzll(n2) : 63;
+                const int b1 = l1 * 64 + j1, b2 = l2 * 64 + j2;
+                const int below = __builtin_amdgcn_readlane(in1 - c1, j1);
+                const int n = __builtin_amdgcn_readlane(c1, j1) + (b2 != b1 ? __builtin_amdgcn_readlane(c2, j2) : 0);
+                if (lane == 0) {
+                    if (n <= 64) {
+                        sc->b1 = b1;
+                        sc->b2 = b2;
+                        sc->below = below;
+                        sc->ncand = 0;
+                        sc->mode = 0;
+                    } else {
+                        // too many windows share the median bins: hand the cell back to k_smooth
+                        const int slot = atomicAdd(P.row_count, 1);
+                        P.row_list[slot] = pcell;
+                        sc->med = 0.0;
+                        sc->mode = 2;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // A: histogram consumed, row free; b1/b2 published
+        ICV_PHASE(0)
+        int w_pack[MAXW];
+        if (more) {
+            // ---------------- L: centre, clip, scatter the prefetched row -------------------------
+            for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
+#define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
+    {                                                                                                            \
+        const unsigned dx_ = (D).x, dy_ = (D).y;                                                                 \
+        row[dx_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).x), __uint_as_float((LO).x),                 \
+                                                __uint_as_float((HI).x), cap, BND, P.trunc);                     \
+        row[dx_ >> 16] = centre_clip<float>(__uint_as_float((X).y), __uint_as_float((LO).y),                     \
+                                            __uint_as_float((HI).y), cap, BND, P.trunc);                         \
+        row[dy_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).z), __uint_as_float((LO).z),                 \
+                                                __uint_as_float((HI).z), cap, BND, P.trunc);                     \
+        row[dy_ >> 16] = centre_clip<float>(__uint_as_float((X).w), __uint_as_float((LO).w),                     \
+                                            __uint_as_float((HI).w), cap, BND, P.trunc);                         \
+    }
+            if (!P.bounded) {
+#pragma unroll
+                for (int h = 0; h < UMAX; h += UH) {
+                    u32x4 lo[UH];
+                    u32x2 dd[UH];
+#pragma unroll
+                    for (int k = 0; k < UH; ++k) {
+                        lo[k] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, (h + k) * NT * 16, 0);
+                        dd[k] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, (h + k) * NT * 8, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], dd[k], 0)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u) {
+                    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * NT * 16, 0);
+                    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(hi_rs, voff, u * NT * 16, 0);
+                    const u32x2 dd = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, u * NT * 8, 0);
+                    ICV_SCATTER4(xq[u], lo, hi, dd, 1)
+                }
+            }
+#undef ICV_SCATTER4
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i)  // out-of-range windows read 0 (buffer bounds check)
+                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+            const int64_t nxt = cell + gridDim.x;
+            if (nxt < P.n_rows) {
+                const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + nxt * P.ld, row_bytes);
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
+            }
+        }
+        ICV_PHASE(1)
+        __syncthreads();  // B1: row scattered
+        ICV_PHASE(2)
+        asm volatile("" : "+v"(tl));
+        if (have_prev && sc->mode == 0) {
+            // windows of the previous cell in the bins of its two middle order statistics -> cand[]
+            const int b1 = sc->b1, b2 = sc->b2;
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                if (tl + i * NT < W) {
+                    const int b = hist_bin(wv[i], inv_bound);
+                    if (b == b1 || b == b2) {
+                        const int idx = atomicAdd(&sc->ncand, 1);
+                        if (idx < 64) sc->cand[idx] = wv[i];
+                    }
+                }
+            }
+        }
+        // ---------------- S: block partial sums (registers) ---------------------------------------
+        double s0[MAXB], s1[MAXB];
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                s0[i] = 0.0;
+                s1[i] = 0.0;
+                const int b = tl + i * NT;
+                if (b < NB) {
+                    const float* rp = row + b * B;
+                    if constexpr (BT > 0 && (BT & 1) == 0) {
+                        const float2* rp2 = reinterpret_cast<const float2*>(rp);
+#pragma unroll
+                        for (int r = 0; r < BT; r += 2) {
+                            const float2 v2 = rp2[r >> 1];
+                            block_accumulate((double)v2.x, r, s0[i], s1[i]);
+                            block_accumulate((double)v2.y, r + 1, s0[i], s1[i]);
+                        }
+                    } else if constexpr (BT > 0) {
+#pragma unroll
+                        for (int r = 0; r < BT; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
+                    } else {
+#pragma unroll 1
+                        for (int r = 0; r < B; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
+                    }
+                }
+            }
+        }
+        ICV_PHASE(3)
+        __syncthreads();  // B2: row dead; candidates of the previous cell complete
+        asm volatile("" : "+v"(tl));
+        if (more) {
+            int4* h4 = reinterpret_cast<int4*>(hist);  // clear the histogram (dead part of the row)
+            for (int i = tl; i < NBIN / 4; i += NT) h4[i] = make_int4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int b = tl + i * NT;
+                if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
+            }
+        }
+        if (selector && have_prev && sc->mode == 0) {
+            // exact float64 rank among the <= 64 gathered candidates -> median
+            const int lane = tl;
+            const int n = sc->ncand < 64 ? sc->ncand : 64;
+            const int below = sc->below;
+            const double mine = (lane < n) ? sc->cand[lane] : __builtin_inf();
+            int rank = 0;
+            for (int jj = 0; jj < n; ++jj) {
+                const double o = readlane_d(mine, jj);  // jj is wave-uniform
+                rank += (o < mine || (o == mine && jj < lane)) ? 1 : 0;
+            }
+            const unsigned long long r1 = __builtin_amdgcn_ballot_w64(lane < n && rank == k1 - below);
+            const unsigned long long r2 = __builtin_amdgcn_ballot_w64(lane < n && rank == k2 - below);
+            const double a = readlane_d(mine, r1 ? (int)__builtin_ctzll(r1) : 0);
+            const double b = readlane_d(mine, r2 ? (int)__builtin_ctzll(r2) : 0);
+            const double med = (k1 == k2) ? a : (a + b) / 2.0;
+            if (lane == 0) sc->med = med;
+        }
+        __syncthreads();  // B3: {S0,S1} ready, histogram cleared, median of the previous cell published
+        ICV_PHASE(4)
+        asm volatile("" : "+v"(tl));
+        if (have_prev) {
+            // x_res of the previous cell from the windows still in registers
+            const double med = sc->med;
+            double sum = 0.0, sq = 0.0;
+            float* orow = P.out + pcell * P.ldo;
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                const int j = tl + i * NT;
+                if (j < W) {
+                    const double y = wv[i] - med;
+                    orow[j] = (float)y;
+                    sum = sum + y;
+                    sq = fma(y, y, sq);
+                }
+            }
+            sum = wave_sum_dpp(sum);
+            sq = wave_sum_dpp(sq);
+            if ((tl & 63) == 0) {
+                sc->psum[tl >> 6] = sum;
+                sc->psq[tl >> 6] = sq;
+            }
+        }
+        // ---------------- W: windows (registers) + histogram --------------------------------------
+        if (more) {
+            int lnan = 0;
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) {
+                const int j = tl + i * NT;
+                wv[i] = 0.0;
+                if (j < W) {
+                    const int wp = w_pack[i];
+                    const int ln = wp >> 16;
+                    const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
+                    double v;
+                    if constexpr (BT > 0 && NBW > 0) {
+                        if (ln == NBW * BT) {
+                            // same operation order as window_from_blocks; two half-windows so that only
+                            // 5 x ds_read_b128 results are live at a time (register budget)
+                            constexpr int HB = NBW > 0 ? NBW / 2 : 1;
+                            v = 0.0;
+                            {
+                                double2 sb[HB];
+#pragma unroll
+                                for (int m = 0; m < HB; ++m) sb[m] = sp[m];
+#pragma unroll
+                                for (int m = 0; m < HB; ++m) {
+                                    v = fma((double)(m * BT + 1), sb[m].x, v);
+                                    v = v + sb[m].y;
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            {
+                                double2 sb[HB];
+#pragma unroll
+                                for (int m = 0; m < HB; ++m) sb[m] = sp[HB + m];
+#pragma unroll
+                                for (int m = 0; m < HB; ++m) {
+                                    v = fma((double)(NBW * BT - (HB + m) * BT), sb[m].x, v);
+                                    v = v - sb[m].y;
+                                }
+                            }
+                        } else {
+                            v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
+                                const double2 s = sp[m];
+                                a = s.x;
+                                b2 = s.y;
+                            });
+                        }
+                    } else {
+                        v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
+                            const double2 s = sp[m];
+                            a = s.x;
+                            b2 = s.y;
+                        });
+                    }
+                    // flat windows (one per chromosome with <= window genes) read their gene count from
+                    // the window table: a rare global load in this otherwise load-free phase
+                    v = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
+                    wv[i] = v;
+                    lnan |= (v != v);
+                    atomicAdd(&hist[hist_bin(v, inv_bound)], 1);
+                }
+            }
+            if (lnan) sc->nanflag = 1;  // benign race: every writer stores 1
+        }
+        __syncthreads();  // B4: histogram complete; moments of the previous cell complete
+        ICV_PHASE(5)
+        if (have_prev && tl == 64 && sc->mode != 2) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int i = 0; i < NWAVE; ++i) {
+                s += sc->psum[i];
+                q += sc->psq[i];
+            }
+            P.cell_stats[2 * pcell] = s;
+            P.cell_stats[2 * pcell + 1] = q;
+            P.cell_median[pcell] = sc->med;
+        }
+    }
+#ifdef ICV_WS_PROFILE
+    if (P.dbg && t == 64)
+        for (int i = 0; i < 6; ++i) atomicAdd(P.dbg + i, tacc[i]);
+#endif
+#undef ICV_PHASE
+}
+
+}  // namespace icv

@@ -46,6 +46,7 @@ struct KParams {
     const int32_t* w_len;
     const double* w_denom;
     const uint16_t* dst16;   // fast path: padded table of LDS positions, Gp (trash slot) = masked
+    const int32_t* w_pack;   // ws path: per window (start block & 0xffff) | (len << 16)
     const int32_t* pad_idx;  // padded positions that hold no gene (must read as 0)
     int32_t n_pad;
     int32_t _pad0;
@@ -53,13 +54,17 @@ struct KParams {
     double pyr_rcp;
     double med_bound;        // |window| <= med_bound (from the clip value); fast path bracket
     int32_t B, NB, Gp, W;
-    int32_t win_off, scratch_off;
+    int32_t win_off, scratch_off, hist_off, _pad1;
     // outputs
     float* out;
     int64_t ldo;
     double* cell_median;
     double* cell_stats;
     unsigned long long* dbg;  // developer diagnostic: per-phase shader-cycle totals (ICV_PHASE_PROFILE=1)
+    // k_smooth only: process rows row_list[0 .. *row_count) instead of 0 .. n_rows (cells a fast
+    // kernel handed back); k_smooth_ws appends to the same list
+    int64_t* row_list;
+    int* row_count;
 };
 
 struct Scratch {
@@ -299,7 +304,9 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
     }
     if (P.dbg && t == 0) tlast = __builtin_amdgcn_s_memtime();
 
-    for (int64_t cell = blockIdx.x; cell < P.n_rows; cell += gridDim.x) {
+    const int64_t n_work = P.row_list ? (int64_t)*P.row_count : P.n_rows;
+    for (int64_t work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int64_t cell = P.row_list ? P.row_list[work] : work;
         // ---------------- L: load, centre, clip, scatter --------------------------------
         if constexpr (!CSR) {
             const T* xrow = static_cast<const T*>(P.values) + cell * P.ld;

@@ -19,6 +19,8 @@ constexpr int kLdsLimit = 160 * 1024;  // gfx950: 160 KiB LDS per CU / per workg
 constexpr int kScratchBytes = 1024;    // struct Scratch, rounded up
 constexpr int kFastScratchBytes = 1536;  // struct ScratchF
 constexpr int kFastUMax = 10;          // 16-byte loads per lane held in registers (fast path)
+constexpr int kWsUMax = 12;            // same for the 448 worker threads of k_smooth_ws
+constexpr int kWsMaxB = 5, kWsMaxW = 5, kWsMaxK = 30;
 
 struct Layout {
     int elem_bytes = 4;
@@ -46,10 +48,12 @@ struct Plan {
     std::vector<double> w_denom;     // W: sum of weights / gene count
     std::vector<int32_t> w_start_sorted, w_len_sorted;  // sorted-gene coordinates, for the API
     std::vector<int32_t> pad_idx;    // padded positions without a gene
+    std::vector<int32_t> w_pack;     // ws path: (start block & 0xffff) | (len << 16)
     std::vector<uint16_t> dst16;     // fast path: kFastUMax*kThreads*4 entries, Gp (trash slot) = masked
     double pyr_den = 1.0, pyr_rcp = 1.0;
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
-    int fast_lds = 0, fast_scratch_off = 0;
+    bool ws_ok = false;              // ... and the wave-specialised k_smooth_ws
+    int fast_lds = 0, fast_scratch_off = 0, ws_win_off = 0, ws_hist_off = 0;
     Layout lay32, lay64;
 };
 
@@ -182,7 +186,14 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         p.fast_scratch_off = round_up(data, 16);
         p.fast_lds = p.fast_scratch_off + kFastScratchBytes;
         p.fast_ok = p.fast_lds <= kLdsLimit;
-        p.dst16.assign((size_t)kFastUMax * kThreads * 4, (uint16_t)p.Gp);
+        p.dst16.assign((size_t)kWsUMax * (kThreads - 64) * 4, (uint16_t)p.Gp);  // >= kFastUMax*kThreads*4
+        p.w_pack.resize(p.W);
+        for (int j = 0; j < p.W; ++j)
+            p.w_pack[j] = (int32_t)((uint32_t)((p.w_start[j] / B) & 0xffff) | ((uint32_t)p.w_len[j] << 16));
+        p.ws_win_off = 16 * p.NB;
+        p.ws_hist_off = p.ws_win_off;  // the histogram follows {S0,S1} inside the (dead) row
+        p.ws_ok = p.fast_ok && p.ws_hist_off + 4096 * 4 <= p.fast_scratch_off && p.NB <= kThreads * 4 &&
+                  p.W <= kThreads * 4;
         for (int g = 0; g < n_cols_all; ++g)
             if (p.dst[g] >= 0) p.dst16[g] = (uint16_t)p.dst[g];
     }

@@ -232,12 +232,25 @@ def test_error_behaviour_matches_reference():
 
 
 def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
-    """k_smooth_fast (register prefetch, ballot median) and k_smooth (generic) share one float64
-    evaluation order: outputs, medians, moments and thresholds must agree bit for bit."""
+    """k_smooth_ws (wave-specialised), k_smooth_fast (register prefetch, ballot median) and k_smooth
+    (generic) share one float64 evaluation order for windows and median: outputs and medians must
+    agree bit for bit.  The per-cell moments are reduced in kernel-specific (fixed) orders, so they and
+    the thresholds agree to float64 rounding."""
     import torch
 
     from infercnvpy_amd import _engine
     from infercnvpy_amd._plan import GenePlan
+
+    def run(plan, dm, ref, env):
+        for k in ("ICV_FORCE_GENERIC", "ICV_NO_WS"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        res = _engine.run_hot_path(plan, dm, ref, chunksize=300)
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        return res
 
     for genes, window, step in ((cases.GENES_PER_CHROM_20K, 100, 10), (cases.GENES_PER_CHROM_20K, 250, 10),
                                 ([230, 110, 101, 100, 99, 57, 140], 100, 10), ([600, 260, 251, 250, 249], 20, 4)):
@@ -252,18 +265,15 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         X[5] = ref  # centred row is all zero: every window equal (> 64 ties at the median)
         X[6, 17] = float("nan")
         dm = _engine.DeviceMatrix(dense=X)
-        monkeypatch.delenv("ICV_FORCE_GENERIC", raising=False)
-        fast = _engine.run_hot_path(plan, dm, ref, chunksize=300)
-        torch.cuda.synchronize()
-        monkeypatch.setenv("ICV_FORCE_GENERIC", "1")
-        gen = _engine.run_hot_path(plan, dm, ref, chunksize=300)
-        torch.cuda.synchronize()
-        monkeypatch.delenv("ICV_FORCE_GENERIC")
-        for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median), (fast.cell_stats, gen.cell_stats),
-                     (fast.thr, gen.thr)):
-            assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0))
-        assert torch.isnan(fast.out[6]).all() and not torch.isnan(fast.out[:6]).any()
-        assert (fast.out[5] == 0).all()
+        gen = run(plan, dm, ref, ["ICV_FORCE_GENERIC"])
+        for env in ([], ["ICV_NO_WS"]):
+            fast = run(plan, dm, ref, env)
+            for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median)):
+                assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)), env
+            for a, b in ((fast.cell_stats, gen.cell_stats), (fast.thr, gen.thr)):
+                torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
+            assert torch.isnan(fast.out[6]).all() and not torch.isnan(fast.out[:6]).any()
+            assert (fast.out[5] == 0).all()
 
 
 def test_unaligned_shards_match_single_run():
