@@ -46,6 +46,26 @@ def synth_on_device(torch, n_cells, n_genes, seed):
     return out
 
 
+def synth_csr_on_device(torch, n_cells, n_genes, density, seed):
+    """10x-like CSR: Bernoulli(density) mask x log1p(1 + poisson-ish counts)."""
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    indptr = [torch.zeros(1, dtype=torch.int64, device="cuda")]
+    indices, data = [], []
+    rows, nnz = 10_000, 0
+    for r in range(0, n_cells, rows):
+        k = min(rows, n_cells - r)
+        mask = torch.rand((k, n_genes), device="cuda", generator=gen) < density
+        vals = torch.log1p(1.0 + torch.floor(torch.rand((k, n_genes), device="cuda", generator=gen) ** 3 * 8.0))
+        counts = mask.sum(dim=1)
+        indptr.append(nnz + torch.cumsum(counts, 0))
+        nnz += int(counts.sum())
+        idx = mask.nonzero(as_tuple=False)
+        indices.append(idx[:, 1].to(torch.int32))
+        data.append(vals[mask].float())
+    return torch.cat(indptr), torch.cat(indices), torch.cat(data)
+
+
 def cpu_baseline(cells_per_worker=250, window=100, step=10):
     """Oracle (numpy port of the reference algorithm) on the host cores, reference-style fan-out."""
     import numpy as np
@@ -79,6 +99,9 @@ def main():
     ap.add_argument("--window", type=int, default=100)
     ap.add_argument("--step", type=int, default=10)
     ap.add_argument("--chunksize", type=int, default=5000)
+    ap.add_argument("--format", choices=["dense", "csr"], default="dense",
+                    help="csr = BASELINE config 4 style input (not the default bench line)")
+    ap.add_argument("--density", type=float, default=0.07)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-refmean", action="store_true", help="exclude the reference-mean pass from the step")
     args = ap.parse_args()
@@ -107,8 +130,14 @@ def main():
     plan = GenePlan(v["chromosome"], v["start"], window_size=args.window, step=args.step)
     W = plan.n_windows
     n_local = args.cells
-    X = synth_on_device(torch, n_local, G, seed=2 + rank)
-    dm = _engine.DeviceMatrix(dense=X)
+    if args.format == "dense":
+        X = synth_on_device(torch, n_local, G, seed=2 + rank)
+        dm = _engine.DeviceMatrix(dense=X)
+        nnz_row = G
+    else:
+        ip, ix, dv = synth_csr_on_device(torch, n_local, G, args.density, seed=3 + rank)
+        dm = _engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(n_local, G))
+        nnz_row = dv.numel() / n_local
     out = torch.empty((n_local, W), dtype=torch.float32, device="cuda")
     sums = torch.zeros((1, G), dtype=torch.float64, device="cuda")
     fixed_ref = None
@@ -155,7 +184,8 @@ def main():
     cells_total = n_local * n_gpus
     value = cells_total / (dt / args.steps)
 
-    bytes_per_cell = 4 * G + 4 * W  # 87 208 B/cell at window 100 / step 10
+    # dense 4*G + 4*W = 87 208 B/cell at window 100 / step 10; CSR 8*nnz_row + 8 + 4*W
+    bytes_per_cell = (4 * G + 4 * W) if args.format == "dense" else (8 * nnz_row + 8 + 4 * W)
     avg_smooth_ms = sum(smooth_ms) / max(len(smooth_ms), 1)
     achieved = bytes_per_cell * n_local / (avg_smooth_ms * 1e-3) / 1e9
     traffic = None
@@ -181,7 +211,9 @@ def main():
         "dtype": "f32 in / f64 accumulate",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE config 2: dense fp32 {n_local} cells/GPU x {G} genes (chr1..22, random var order), "
+            "workload": ("BASELINE config 2: dense fp32" if args.format == "dense" else
+                         f"BASELINE config 4 style: CSR fp32 density {args.density}") +
+                        f" {n_local} cells/GPU x {G} genes (chr1..22, random var order), "
                         f"window {args.window}, step {args.step}, chunksize {args.chunksize}, lfc_clip 3, "
                         f"dynamic_threshold 1.5, reference = all-cell mean"
                         + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)"),
@@ -190,7 +222,8 @@ def main():
             "parallelism": f"row shards x{n_gpus}, all-reduce of the [G] float64 reference sums only",
         },
         "roofline": {
-            "kernel": "k_smooth<float,dense>",
+            "kernel": "k_smooth_ws<10,4,4,10,10> (dense fp32 fast path)" if args.format == "dense" and args.window == 100
+                      else "k_smooth (generic / k_smooth_fast)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

@@ -61,7 +61,7 @@ typedef struct {
     int64_t ld;             /* dense: row stride in elements (>= n_cols)               */
     const void *values;     /* dense: n_rows x ld row-major; csr: nnz values           */
     const int64_t *indptr;  /* csr: n_rows + 1                                         */
-    const int32_t *indices; /* csr: nnz column indices (any order within a row)        */
+    const int32_t *indices; /* csr: nnz column indices, unique and ascending within a row */
 } icv_matrix;
 
 typedef struct icv_plan_s *icv_plan_t;

@@ -89,7 +89,7 @@ def to_device_matrix(X, dtype=None, device="cuda"):
     np_dtype = {None: None, torch.float32: np.float32, torch.float64: np.float64}[dtype]
     if sp.issparse(X):
         X = X.tocsr()
-        if not X.has_canonical_format:
+        if not X.has_canonical_format:  # the kernels expect unique, sorted column indices per row
             X = X.copy()
             X.sum_duplicates()
         data = X.data if np_dtype is None else X.data.astype(np_dtype, copy=False)

@@ -389,14 +389,31 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nc = m->n_cols;
     if (m->format == ICV_CSR) {
-        dim3 grid((unsigned)((m->n_rows + 3) / 4)), block(256);
-        if (m->dtype == ICV_F32)
-            hipLaunchKernelGGL(icv::k_colsum_csr<float>, grid, block, 0, st, (const float*)m->values, m->indptr,
-                               m->indices, m->n_rows, nc, row_group, sums);
-        else
-            hipLaunchKernelGGL(icv::k_colsum_csr<double>, grid, block, 0, st, (const double*)m->values, m->indptr,
-                               m->indices, m->n_rows, nc, row_group, sums);
+        const int rows_per_slab = 512;
+        const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
+        const int n_tiles = (nc + icv::kCsrTileCols - 1) / icv::kCsrTileCols;
+        const int lds = icv::kCsrTileCols * (int)sizeof(double);
+        double* partial = nullptr;
+        HIP_TRY(hipMallocAsync((void**)&partial, (size_t)n_slabs * nc * sizeof(double), st));
+        dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(512);
+        void (*kf)(const float*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
+            icv::k_colsum_csr<float>;
+        void (*kd)(const double*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
+            icv::k_colsum_csr<double>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        for (int g = 0; g < n_groups; ++g) {
+            if (m->dtype == ICV_F32)
+                hipLaunchKernelGGL(kf, grid, block, lds, st, (const float*)m->values, m->indptr, m->indices, m->n_rows,
+                                   nc, row_group, g, rows_per_slab, partial);
+            else
+                hipLaunchKernelGGL(kd, grid, block, lds, st, (const double*)m->values, m->indptr, m->indices, m->n_rows,
+                                   nc, row_group, g, rows_per_slab, partial);
+            hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 255) / 256), dim3(256), 0, st, partial, (int)n_slabs, nc,
+                               sums + (int64_t)g * nc);
+        }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipFreeAsync(partial, st));
         return ICV_OK;
     }
     const int rows_per_slab = 256;

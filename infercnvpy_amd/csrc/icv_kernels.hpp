@@ -1043,53 +1043,96 @@ __global__ void __launch_bounds__(256) k_chunk_thr(const double* stats, int64_t 
 // decides except when it ties with float32(thr): then the window is recomputed from the input
 // with the canonical evaluation order above (bit-identical to k_smooth) and compared in float64.
 // ---------------------------------------------------------------------------------------
+// clipped, centred value of padded position pp of one cell, re-read from the input matrix
 template <typename T, bool CSR>
-__device__ double recompute_window(const KParams& P, int64_t cell, int j) {
-    const T cap = (T)P.cap;
+__device__ double value_at(const KParams& P, int64_t cell, int pp) {
+    const int g = P.src[pp];
+    if (g < 0) return 0.0;
     const T* ref_lo = static_cast<const T*>(P.ref_lo);
     const T* ref_hi = P.bounded ? static_cast<const T*>(P.ref_hi) : ref_lo;
-    auto value_at = [&](int pp) -> double {
-        const int g = P.src[pp];
-        if (g < 0) return 0.0;
-        T x = T(0);
-        if constexpr (!CSR) {
-            x = static_cast<const T*>(P.values)[cell * P.ld + g];
-        } else {
-            const T* vals = static_cast<const T*>(P.values);
-            for (int64_t k = P.indptr[cell]; k < P.indptr[cell + 1]; ++k)
-                if (P.indices[k] == g) x = vals[k];
+    T x = T(0);
+    if constexpr (!CSR) {
+        x = static_cast<const T*>(P.values)[cell * P.ld + g];
+    } else {
+        // column indices are sorted within a row (the host driver sorts them): binary search
+        int64_t lo = P.indptr[cell], hi = P.indptr[cell + 1];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (P.indices[mid] < g) lo = mid + 1;
+            else hi = mid;
         }
-        return (double)centre_clip<T>(x, ref_lo[g], ref_hi[g], cap, P.bounded, P.trunc);
-    };
-    const int st = P.w_start[j], ln = P.w_len[j];
+        if (lo < P.indptr[cell + 1] && P.indices[lo] == g) x = static_cast<const T*>(P.values)[lo];
+    }
+    return (double)centre_clip<T>(x, ref_lo[g], ref_hi[g], (T)P.cap, P.bounded, P.trunc);
+}
+
+// canonical (bit-identical to k_smooth) float64 window from a value accessor val(k), k = 0 .. |len|-1
+template <typename F>
+__device__ double window_canonical(const KParams& P, int j, F val) {
+    const int ln = P.w_len[j];
     double acc;
     if (P.B > 1) {
         const int B = P.B;
         acc = window_from_blocks(ln, B, [&](int m, double& s0, double& s1) {
             s0 = 0.0;
             s1 = 0.0;
-            for (int r = 0; r < B; ++r) block_accumulate(value_at(st + m * B + r), r, s0, s1);
+            for (int r = 0; r < B; ++r) block_accumulate(val(m * B + r), r, s0, s1);
         });
     } else {
-        acc = window_direct(ln, [&](int k) { return value_at(st + k); });
+        acc = window_direct(ln, val);
     }
     return finish_window(acc, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
 }
 
+constexpr int kTieBuf = 2048;  // genes of a tied window staged in LDS (longer windows: serial path)
+
 template <typename T, bool CSR>
 __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double* thr, int64_t chunksize,
                                                    int64_t row_phase) {
+    __shared__ int tie_n;
+    __shared__ int tie_j[32];
+    __shared__ double vals[kTieBuf];
     const int64_t cell = blockIdx.x;
     const double th = thr[(cell + row_phase) / chunksize];
     const float thf = (float)th;
     float* orow = P.out + cell * P.ldo;
+    if (threadIdx.x == 0) tie_n = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < P.W; j += 256) {
         const float y = orow[j];
         const float a = fabsf(y);
         if (a < thf) {
             orow[j] = 0.0f;
         } else if (a == thf) {
-            const double yd = recompute_window<T, CSR>(P, cell, j) - P.cell_median[cell];
+            // float32 cannot decide: queue the window for an exact float64 recomputation
+            const int idx = atomicAdd(&tie_n, 1);
+            if (idx < 32) {
+                tie_j[idx] = j;
+            } else {  // > 32 ties in one row: resolve serially
+                const int st = P.w_start[j];
+                const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                                  P.cell_median[cell];
+                if (fabs(yd) < th) orow[j] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    const int nt = tie_n < 32 ? tie_n : 32;
+    for (int i = 0; i < nt; ++i) {  // rare (about one window in 1e7): the block recomputes it together
+        const int j = tie_j[i];
+        const int st = P.w_start[j], ln = P.w_len[j];
+        const int len = ln > 0 ? ln : -ln;
+        if (len <= kTieBuf) {
+            for (int k = threadIdx.x; k < len; k += 256) vals[k] = value_at<T, CSR>(P, cell, st + k);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double yd = window_canonical(P, j, [&](int k) { return vals[k]; }) - P.cell_median[cell];
+                if (fabs(yd) < th) orow[j] = 0.0f;
+            }
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                              P.cell_median[cell];
             if (fabs(yd) < th) orow[j] = 0.0f;
         }
     }
@@ -1134,17 +1177,36 @@ __global__ void __launch_bounds__(256) k_colsum_finish(const double* partial, in
     sums[col] += acc;
 }
 
+// CSR: a workgroup owns (row slab) x (tile of 8192 columns): float64 accumulators in LDS (ds_add_f64),
+// one pass over the slab's entries per column tile, then the tile goes to partial[slab][...] and
+// k_colsum_finish adds the slabs.  (Global float64 atomics on 20 000 addresses serialise badly.)
+constexpr int kCsrTileCols = 8192;
 template <typename T>
-__global__ void __launch_bounds__(256) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
-                                                    int64_t n_rows, int n_cols, const int32_t* row_group,
-                                                    double* sums) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const int g = row_group ? row_group[row] : 0;
-    if (g < 0) return;
-    double* dst = sums + (int64_t)g * n_cols;
-    for (int64_t k = indptr[row] + (threadIdx.x & 63); k < indptr[row + 1]; k += 64)
-        atomicAdd(dst + indices[k], (double)vals[k]);
+__global__ void __launch_bounds__(512) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
+                                                    int64_t n_rows, int n_cols, const int32_t* row_group, int group,
+                                                    int rows_per_slab, double* partial /* n_slabs x n_cols */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tile = reinterpret_cast<double*>(smem);
+    const int c0 = blockIdx.x * kCsrTileCols;
+    const int nc = (n_cols - c0) < kCsrTileCols ? (n_cols - c0) : kCsrTileCols;
+    for (int i = threadIdx.x; i < nc; i += 512) tile[i] = 0.0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+    int64_t r1 = r0 + rows_per_slab;
+    if (r1 > n_rows) r1 = n_rows;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t row = r0 + wave; row < r1; row += 8) {
+        if (row_group && row_group[row] != group) continue;
+        const int64_t e = indptr[row + 1];
+        for (int64_t k = indptr[row] + lane; k < e; k += 64) {
+            const int c = indices[k] - c0;
+            if (c >= 0 && c < nc)
+                __hip_atomic_fetch_add(tile + c, (double)vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    double* dst = partial + (int64_t)blockIdx.y * n_cols + c0;
+    for (int i = threadIdx.x; i < nc; i += 512) dst[i] = tile[i];
 }
 
 // cnv_score: per-row sum |x| (tl/_scores.py:66), one wavefront per row, float64

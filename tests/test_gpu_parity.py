@@ -276,6 +276,51 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
             assert (fast.out[5] == 0).all()
 
 
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_threshold_ties_are_decided_in_float64(fmt):
+    """Force the rare tie path of k_apply_thr: choose thr = (double)float32(|x|) of existing entries, so
+    the stored float32 cannot decide and the window is recomputed from the input in float64.  The
+    decision must be the oracle's |x64| < thr."""
+    import ctypes as C
+
+    import torch
+
+    from infercnvpy_amd import _engine, _lib
+    from infercnvpy_amd._plan import GenePlan
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var([900, 400, 260, 120], seed_start=3, seed_perm=4)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+    Xh = cases.synthetic_expr(64, 1680, seed=51)
+    refh = Xh.mean(axis=0, dtype=np.float64).astype(np.float32)
+    dm = _engine.to_device_matrix(sp.csr_matrix(Xh) if fmt == "csr" else Xh)
+    ref = torch.from_numpy(refh).cuda()
+    raw = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=None)
+    _, x64, _, _ = O.infercnv_chunk(Xh, v["chromosome"], v["start"], refh[None, :], 3, 100, 10, None)
+    out0 = raw.out.clone()
+    lib = _lib.load()
+    checked = 0
+    for row in range(0, 64, 7):
+        for col in (3, 40, 101):
+            thr_val = float(abs(out0[row, col].item()))  # exactly a float32 value
+            if thr_val == 0.0:
+                continue
+            out = out0.clone()
+            thr = torch.full((64,), thr_val, dtype=torch.float64, device="cuda")
+            m = dm.c_struct()
+            _lib.check(lib.icv_apply_threshold(
+                plan.handle, C.byref(m), _engine._ptr(ref), None, 3.0, 0, _engine._ptr(out), out.stride(0),
+                _engine._ptr(raw.cell_median), _engine._ptr(thr), 1, 0, _engine._stream_ptr(torch)))
+            torch.cuda.synchronize()
+            got_zero = out[row, col].item() == 0.0
+            assert got_zero == (abs(x64[row, col]) < thr_val), (row, col)
+            # every entry of the row that does not tie follows the plain float32 comparison
+            free = out0[row].abs() != thr_val
+            assert torch.equal((out[row] == 0)[free], ((out0[row].abs() < thr_val) | (out0[row] == 0))[free])
+            checked += 1
+    assert checked >= 20
+
+
 def test_unaligned_shards_match_single_run():
     """Two row shards cut in the middle of a std-chunk (what ``dist.run_shard`` does per rank, here
     sequentially on one GPU): chunk moments summed across shards give the same thresholds and the
