@@ -62,6 +62,8 @@ typedef struct {
     const void *values;     /* dense: n_rows x ld row-major; csr: nnz values           */
     const int64_t *indptr;  /* csr: n_rows + 1                                         */
     const int32_t *indices; /* csr: nnz column indices, unique and ascending within a row */
+    int64_t csr_begin;      /* csr: host copies of indptr[0] and indptr[n_rows]; both 0 = unknown  */
+    int64_t csr_end;        /*      (the prepared-entry fast path needs them to size its workspace) */
 } icv_matrix;
 
 typedef struct icv_plan_s *icv_plan_t;

@@ -36,7 +36,7 @@ def _ptr(t):
 class DeviceMatrix:
     """A cells x genes matrix resident in HBM (dense row-major or CSR), float32 or float64."""
 
-    def __init__(self, *, dense=None, indptr=None, indices=None, data=None, shape=None):
+    def __init__(self, *, dense=None, indptr=None, indices=None, data=None, shape=None, indptr_host=None):
         torch = _torch()
         if dense is not None:
             assert dense.is_cuda and dense.dim() == 2 and dense.stride(1) == 1
@@ -54,6 +54,8 @@ class DeviceMatrix:
             self.shape = tuple(shape)
             self.dtype = data.dtype
             self._keep = (indptr, indices, data)
+            # host copy of the row pointers (8 B per row): slices need indptr[row0], indptr[row1]
+            self.indptr_host = indptr_host if indptr_host is not None else indptr.cpu().numpy()
 
     def c_struct(self, row0=0, row1=None):
         """icv_matrix for rows [row0, row1)."""
@@ -74,6 +76,8 @@ class DeviceMatrix:
             m.values = self.data.data_ptr()
             m.indptr = self.indptr.data_ptr() + 8 * row0  # absolute offsets into indices/values
             m.indices = self.indices.data_ptr()
+            m.csr_begin = int(self.indptr_host[row0])
+            m.csr_end = int(self.indptr_host[row1])
         return m
 
 
@@ -94,6 +98,7 @@ def to_device_matrix(X, dtype=None, device="cuda"):
             X.sum_duplicates()
         data = X.data if np_dtype is None else X.data.astype(np_dtype, copy=False)
         return DeviceMatrix(
+            indptr_host=X.indptr.astype(np.int64),
             indptr=torch.from_numpy(X.indptr.astype(np.int64)).to(device),
             indices=torch.from_numpy(X.indices.astype(np.int32)).to(device),
             data=torch.from_numpy(np.ascontiguousarray(data)).to(device),

@@ -31,7 +31,7 @@ class Matrix(C.Structure):
     _fields_ = [
         ("format", C.c_int32), ("dtype", C.c_int32), ("n_rows", C.c_int64), ("n_cols", C.c_int32),
         ("_pad", C.c_int32), ("ld", C.c_int64), ("values", C.c_void_p), ("indptr", C.c_void_p),
-        ("indices", C.c_void_p),
+        ("indices", C.c_void_p), ("csr_begin", C.c_int64), ("csr_end", C.c_int64),
     ]
 
 

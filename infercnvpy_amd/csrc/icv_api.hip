@@ -77,7 +77,7 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.pad_idx.data(), p.pad_idx.size() * 4, (void**)&pl->d_pad));
     HIP_TRY(up(p.w_pack.data(), p.w_pack.size() * 4, (void**)&pl->d_wpack));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
-    pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;
+    pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;  // >= Gp + 1: the trash slot reads 0
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
     pl->device = dev;
     return ICV_OK;
@@ -125,6 +125,7 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.ref_lo = ref_lo;
     K.ref_hi = ref_hi;
     K.zrow = pl->d_zrow;
+    K.zrow_bytes = (int64_t)pl->zrow_elems * ((m->dtype == ICV_F32) ? 4 : 8);
     K.bounded = ref_hi != nullptr;
     K.trunc = flags & (ICV_FLAG_TRUNC_TO_INT | ICV_FLAG_ROUND_F32);
     K.cap = lfc_clip;
@@ -189,8 +190,8 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
     return ICV_OK;
 }
 
-// dense float32, blocked form, small enough geometry: register-prefetch kernel
-int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
+// float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
+int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, int64_t csr_begin, int64_t csr_end) {
     const icv::Plan& p = pl->p;
     const int need_b = (p.NB + icv::kThreads - 1) / icv::kThreads;
     const int need_w = (p.W + icv::kThreads - 1) / icv::kThreads;
@@ -204,8 +205,32 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
     else kern = icv::k_smooth_fast<U, 8, 8, 0, 0>;
     K.scratch_off = p.fast_scratch_off;
     bool use_ws = false;
-    if (p.ws_ok && !std::getenv("ICV_NO_WS")) {
-        kern = (p.B == 10 && p.window == 100) ? icv::k_smooth_ws<U, 4, 4, 10, 10> : icv::k_smooth_ws<U, 4, 4, 0, 0>;
+    void* ws_buf = nullptr;
+    if (p.ws_ok && (csr || !std::getenv("ICV_NO_WS"))) {
+        const bool u10 = (p.B == 10 && p.window == 100);
+        if (!csr) {
+            if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, false> : icv::k_smooth_ws<U, 4, 4, 0, 0, false>;
+            else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, false> : icv::k_smooth_ws<U, 8, 4, 0, 0, false>;
+        } else {
+            if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
+            else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
+            // zero row + prepared entries {LDS position, centred and clipped value}
+            const int nz = (int)pl->zrow_elems;
+            hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
+                               static_cast<float*>(pl->d_zrow), nz);
+            const int64_t n = csr_end - csr_begin;
+            HIP_TRY(hipMallocAsync(&ws_buf, (size_t)(n > 0 ? n : 1) * 6, st));
+            float* cv = static_cast<float*>(ws_buf);
+            uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
+            K.cvals = cv - csr_begin;  // indexed by the absolute entry number
+            K.pos16 = ps - csr_begin;
+            if (n > 0) {
+                int64_t g = (n + 255) / 256;
+                if (g > 8192) g = 8192;
+                hipLaunchKernelGGL(icv::k_csr_prepare, dim3((unsigned)g), dim3(256), 0, st, K, csr_begin, csr_end,
+                                   const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
+            }
+        }
         use_ws = true;
         K.hist_off = p.ws_hist_off;
         if (pl->row_list_cap < K.n_rows) {
@@ -218,6 +243,8 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
         HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
         K.row_list = pl->d_row_list;
         K.row_count = pl->d_row_count;
+    } else if (csr) {
+        return -1;  // caller falls back to the generic CSR kernel
     }
     int per_cu = icv::kLdsLimit / p.fast_lds;
     if (per_cu > 4) per_cu = 4;
@@ -225,6 +252,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
     if (grid > K.n_rows) grid = K.n_rows;
     if (grid < 1) return ICV_OK;
     int rc = run_kernel(kern, grid, p.fast_lds, K, st);
+    if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
     if (rc || !use_ws) return rc;
     // cells whose median bins held more than 64 windows: recompute them with the generic kernel
     // (reads the device-side count; exits at once when the list is empty)
@@ -233,7 +261,9 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st) {
     G.scratch_off = p.lay32.scratch_off;
     G.dbg = nullptr;
     const int need = (p.NB + icv::kThreads - 1) / icv::kThreads;
-    void (*gk)(const icv::KParams) = need <= 4 ? icv::k_smooth<float, false, 4> : icv::k_smooth<float, false, 8>;
+    void (*gk)(const icv::KParams);
+    if (csr) gk = need <= 4 ? icv::k_smooth<float, true, 4> : icv::k_smooth<float, true, 8>;
+    else gk = need <= 4 ? icv::k_smooth<float, false, 4> : icv::k_smooth<float, false, 8>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 p.lay32.total));
     int64_t g2 = pl->n_cu;
@@ -273,7 +303,12 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
                   hipStream_t st) {
     if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.fast_ok && K.vec_ok && std::isfinite(K.cap) &&
         !std::getenv("ICV_FORCE_GENERIC"))
-        return launch_smooth_fast(pl, K, st);
+        return launch_smooth_fast(pl, K, st, false, 0, 0);
+    if (m->dtype == ICV_F32 && m->format == ICV_CSR && pl->p.ws_ok && std::isfinite(K.cap) &&
+        m->csr_end > m->csr_begin && aligned16(K.ref_lo) && !std::getenv("ICV_FORCE_GENERIC")) {
+        const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end);
+        if (rc >= 0) return rc;
+    }
     if (m->dtype == ICV_F32)
         return m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, lay, st)
                                       : launch_smooth_t<float, true>(pl, K, lay, st);

@@ -21,7 +21,8 @@
 
 namespace icv {
 
-constexpr int NBIN = 4096;  // 3072 bins over the central quarter of [-bound, bound], 512 per tail
+constexpr int NBIN = 4096;  // 3072 bins over the central quarter of [-bound, bound], 512 per tail;
+                            // stored as 16-bit counters, two per LDS word (8 KB)
 
 struct ScratchW {
     int nanflag;
@@ -58,7 +59,14 @@ __device__ __forceinline__ int hist_bin(double v, float inv_bound) {
     return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);  // segments stay disjoint under rounding
 }
 
-template <int UMAX, int MAXB, int MAXW, int BT, int NBW>
+// CSR input (k_csr_prepare has turned every stored entry into {LDS position, centred+clipped value}):
+// the L phase writes the pre-centred zero row (clip(0 - ref), held in registers for the whole kernel)
+// over the LDS row and scatters the cell's entries on top; the next cell's first PF entries per
+// thread are prefetched like the dense row.
+constexpr int kCsrPF = 4;  // prepared entries prefetched per thread (rows with <= 2048 entries; longer rows
+                           // fetch the rest inside the L phase)
+
+template <int UMAX, int MAXB, int MAXW, int BT, int NBW, bool CSR>
 __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* row = reinterpret_cast<float*>(smem);
@@ -92,11 +100,28 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         sc->ncand = 0;
         sc->med = 0.0;
     }
-    u32x4 xq[UMAX];
-    {
+    u32x4 xq[CSR ? 1 : UMAX];  // dense: the prefetched row
+    unsigned short epos[CSR ? kCsrPF : 1];  // CSR: prefetched entries of the next cell
+    float eval[CSR ? kCsrPF : 1];
+    // CSR: the pre-centred zero row is re-read from L2 in every L phase (it is not HBM traffic, and
+    // holding it in 40 registers pushed the 8-blocks-per-thread variants into scratch)
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(P.zrow, (unsigned)P.zrow_bytes);
+    if constexpr (!CSR) {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
+    } else {
+        const int64_t e0 = P.indptr[blockIdx.x], e1 = P.indptr[blockIdx.x + 1];
+#pragma unroll
+        for (int i = 0; i < kCsrPF; ++i) {
+            const int64_t k = e0 + t + i * NT;
+            epos[i] = 0;
+            eval[i] = 0.0f;
+            if (k < e1) {
+                epos[i] = P.pos16[k];
+                eval[i] = P.cvals[k];
+            }
+        }
     }
     constexpr int UH = 5;
     static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
@@ -137,13 +162,15 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     sc->mode = 1;
                 }
             } else {
-                // level 1: lane l sums bins [64 l, 64 l + 64); which lanes hold ranks k1 / k2
-                const int4* h4 = reinterpret_cast<const int4*>(hist) + lane * 16;
+                // level 1: lane l sums bins [64 l, 64 l + 64) (two 16-bit bins per word); which lanes
+                // hold ranks k1 / k2
+                const int4* h4 = reinterpret_cast<const int4*>(hist) + lane * 8;
                 int tot = 0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < 8; ++q) {
                     const int4 v = h4[q];
-                    tot += (v.x + v.y) + (v.z + v.w);
+                    const int s = (v.x + v.y) + (v.z + v.w);  // no carry between halves: counts <= W < 65536
+                    tot += (s & 0xffff) + ((unsigned)s >> 16);
                 }
                 const int incl = wave_scan_dpp(tot);
                 const unsigned long long m1 = __builtin_amdgcn_ballot_w64(incl > k1);
@@ -151,7 +178,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                 const int l1 = m1 ? (int)__builtin_ctzll(m1) : 63, l2 = m2 ? (int)__builtin_ctzll(m2) : 63;
                 const int ex1 = __builtin_amdgcn_readlane(incl - tot, l1), ex2 = __builtin_amdgcn_readlane(incl - tot, l2);
                 // level 2: lane i looks at bin 64 l + i of the located group
-                const int c1 = hist[l1 * 64 + lane], c2 = hist[l2 * 64 + lane];
+                const int c1 = (hist[l1 * 32 + (lane >> 1)] >> ((lane & 1) * 16)) & 0xffff;
+                const int c2 = (hist[l2 * 32 + (lane >> 1)] >> ((lane & 1) * 16)) & 0xffff;
                 const int in1 = wave_scan_dpp(c1) + ex1, in2 = wave_scan_dpp(c2) + ex2;
                 const unsigned long long n1 = __builtin_amdgcn_ballot_w64(in1 > k1);
                 const unsigned long long n2 = __builtin_amdgcn_ballot_w64(in2 > k2);
@@ -180,6 +208,42 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         ICV_PHASE(0)
         int w_pack[MAXW];
         if (more) {
+          if constexpr (CSR) {
+            // ---------------- L (CSR): zero row, then the cell's prepared entries ------------------
+            const int nvec_row = P.scratch_off >> 4;  // 16-byte vectors of the LDS row region
+#pragma unroll
+            for (int h = 0; h < UMAX; h += UH) {
+                u32x4 z[UH];
+#pragma unroll
+                for (int k = 0; k < UH; ++k) z[k] = __builtin_amdgcn_raw_buffer_load_b128(zr, voff, (h + k) * NT * 16, 0);
+#pragma unroll
+                for (int k = 0; k < UH; ++k) {
+                    const int i = (h + k) * NT + tl;
+                    if (i < nvec_row) reinterpret_cast<u32x4*>(row)[i] = z[k];
+                }
+            }
+            const int64_t e0 = P.indptr[cell], e1 = P.indptr[cell + 1];
+            __syncthreads();  // every slot initialised before any entry lands on it
+#pragma unroll
+            for (int i = 0; i < kCsrPF; ++i)
+                if (e0 + tl + i * NT < e1) row[epos[i]] = eval[i];
+            for (int64_t k = e0 + tl + (int64_t)kCsrPF * NT; k < e1; k += NT) row[P.pos16[k]] = P.cvals[k];
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i)
+                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+            const int64_t nxt = cell + gridDim.x;
+            if (nxt < P.n_rows) {
+                const int64_t n0 = P.indptr[nxt], n1 = P.indptr[nxt + 1];
+#pragma unroll
+                for (int i = 0; i < kCsrPF; ++i) {
+                    const int64_t k = n0 + tl + i * NT;
+                    if (k < n1) {
+                        epos[i] = P.pos16[k];
+                        eval[i] = P.cvals[k];
+                    }
+                }
+            }
+          } else {
             // ---------------- L: centre, clip, scatter the prefetched row -------------------------
             for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
 #define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
@@ -227,6 +291,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #pragma unroll
                 for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
             }
+          }
         }
         ICV_PHASE(1)
         __syncthreads();  // B1: row scattered
@@ -279,7 +344,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         asm volatile("" : "+v"(tl));
         if (more) {
             int4* h4 = reinterpret_cast<int4*>(hist);  // clear the histogram (dead part of the row)
-            for (int i = tl; i < NBIN / 4; i += NT) h4[i] = make_int4(0, 0, 0, 0);
+            for (int i = tl; i < NBIN / 8; i += NT) h4[i] = make_int4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
                 const int b = tl + i * NT;
@@ -387,7 +452,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     v = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
                     wv[i] = v;
                     lnan |= (v != v);
-                    atomicAdd(&hist[hist_bin(v, inv_bound)], 1);
+                    const int hb = hist_bin(v, inv_bound);
+                    atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));  // 16-bit bins, two per word
                 }
             }
             if (lnan) sc->nanflag = 1;  // benign race: every writer stores 1

@@ -36,6 +36,7 @@ struct KParams {
     const void* ref_lo;
     const void* ref_hi;
     const void* zrow;  // CSR: padded row of centre_clip(0) values (matrix dtype)
+    int64_t zrow_bytes;
     int32_t bounded;
     int32_t trunc;
     double cap;
@@ -47,6 +48,8 @@ struct KParams {
     const double* w_denom;
     const uint16_t* dst16;   // fast path: padded table of LDS positions, Gp (trash slot) = masked
     const int32_t* w_pack;   // ws path: per window (start block & 0xffff) | (len << 16)
+    const uint16_t* pos16;   // ws CSR path: per stored entry, LDS position (k_csr_prepare)
+    const float* cvals;      //              and centred + clipped value
     const int32_t* pad_idx;  // padded positions that hold no gene (must read as 0)
     int32_t n_pad;
     int32_t _pad0;
@@ -1002,6 +1005,20 @@ __global__ void k_zero_row(KParams P, T* zrow, int n_alloc) {
         }
     }
     zrow[i] = v;
+}
+
+// CSR fast path: every stored entry -> {LDS position of its column, centred + clipped value}.
+// Element-wise over the entries (centring depends on the column only), coalesced.
+__global__ void __launch_bounds__(256) k_csr_prepare(const KParams P, int64_t k0, int64_t k1, uint16_t* pos16,
+                                                     float* cvals) {
+    const float* lo = static_cast<const float*>(P.ref_lo);
+    const float* hi = P.bounded ? static_cast<const float*>(P.ref_hi) : lo;
+    const float* vals = static_cast<const float*>(P.values);
+    for (int64_t k = k0 + (int64_t)blockIdx.x * 256 + threadIdx.x; k < k1; k += (int64_t)gridDim.x * 256) {
+        const int g = P.indices[k];
+        pos16[k] = P.dst16[g];
+        cvals[k] = centre_clip<float>(vals[k], lo[g], hi[g], (float)P.cap, P.bounded, P.trunc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

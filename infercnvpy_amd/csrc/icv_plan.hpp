@@ -192,7 +192,7 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
             p.w_pack[j] = (int32_t)((uint32_t)((p.w_start[j] / B) & 0xffff) | ((uint32_t)p.w_len[j] << 16));
         p.ws_win_off = 16 * p.NB;
         p.ws_hist_off = p.ws_win_off;  // the histogram follows {S0,S1} inside the (dead) row
-        p.ws_ok = p.fast_ok && p.ws_hist_off + 4096 * 4 <= p.fast_scratch_off && p.NB <= kThreads * 4 &&
+        p.ws_ok = p.fast_ok && p.ws_hist_off + 4096 * 2 <= p.fast_scratch_off && p.W < 65536 && p.NB <= kThreads * 8 &&
                   p.W <= kThreads * 4;
         for (int g = 0; g < n_cols_all; ++g)
             if (p.dst[g] >= 0) p.dst16[g] = (uint16_t)p.dst[g];

@@ -266,8 +266,9 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         X[6, 17] = float("nan")
         dm = _engine.DeviceMatrix(dense=X)
         gen = run(plan, dm, ref, ["ICV_FORCE_GENERIC"])
-        for env in ([], ["ICV_NO_WS"]):
-            fast = run(plan, dm, ref, env)
+        dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
+        for env, mat in (([], dm), (["ICV_NO_WS"], dm), ([], dm_csr), (["ICV_FORCE_GENERIC"], dm_csr)):
+            fast = run(plan, mat, ref, env)
             for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median)):
                 assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)), env
             for a, b in ((fast.cell_stats, gen.cell_stats), (fast.thr, gen.thr)):
