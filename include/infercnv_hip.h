@@ -157,6 +157,17 @@ int icv_infercnv_run(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, c
                      int32_t flags, float *out, int64_t ldo, double *cell_median, double *cell_stats,
                      double *thr, icv_profile *h_profile, void *stream);
 
+/* ---- calculate_gene_values=True (reference :247-298, :443-453) -------------------------------
+ * Per-gene CNV values: mean of the kept windows that contain the gene, minus the per-cell median
+ * over the covered genes, zeroed below the chunk's noise threshold (`thr` from
+ * icv_chunk_thresholds / icv_infercnv_run; NULL = no thresholding).  `gene_out` (device, float64,
+ * n_rows x ldg, ldg >= n_cols) is written completely: NaN for genes no kept window covers and for
+ * masked genes (reference: reindex with NaN fill, :147).  Uses the generic smoothing kernel and
+ * stream-ordered temporary buffers (8*(W + n_covered) bytes per row). */
+int icv_gene_values(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                    double lfc_clip, int32_t flags, const double *thr, int64_t chunksize,
+                    int64_t row_phase, double *gene_out, int64_t ldg, void *stream);
+
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);

@@ -173,3 +173,16 @@ def row_abs_sum(x_cnv):
     _lib.check(lib.icv_row_abs_sum(_ptr(x_cnv), x_cnv.shape[0], x_cnv.shape[1], x_cnv.stride(0), _ptr(res),
                                    _stream_ptr(torch)))
     return res
+
+
+def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, thr=None, chunksize=5000,
+                row_phase=0, flags=0):
+    """calculate_gene_values: float64 ``rows x n_vars`` device tensor, NaN where a gene has no value."""
+    torch = _torch()
+    lib = _lib.load()
+    out = torch.empty((dm.shape[0], dm.shape[1]), dtype=torch.float64, device="cuda")
+    m = dm.c_struct()
+    _lib.check(lib.icv_gene_values(
+        plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(thr), int(chunksize),
+        int(row_phase), _ptr(out), out.stride(0), _stream_ptr(torch)))
+    return out

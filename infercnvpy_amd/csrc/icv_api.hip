@@ -44,6 +44,7 @@ struct icv_plan_s {
     double* d_wdenom = nullptr;
     int32_t* d_pad = nullptr;
     int32_t* d_wpack = nullptr;
+    int32_t *d_cov_col = nullptr, *d_cov_j0 = nullptr, *d_cov_cnt = nullptr;
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
@@ -76,6 +77,9 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.w_denom.data(), p.w_denom.size() * 8, (void**)&pl->d_wdenom));
     HIP_TRY(up(p.pad_idx.data(), p.pad_idx.size() * 4, (void**)&pl->d_pad));
     HIP_TRY(up(p.w_pack.data(), p.w_pack.size() * 4, (void**)&pl->d_wpack));
+    HIP_TRY(up(p.cov_col.data(), p.cov_col.size() * 4, (void**)&pl->d_cov_col));
+    HIP_TRY(up(p.cov_j0.data(), p.cov_j0.size() * 4, (void**)&pl->d_cov_j0));
+    HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;  // >= Gp + 1: the trash slot reads 0
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
@@ -378,6 +382,9 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_wdenom);
         (void)hipFree(pl->d_pad);
         (void)hipFree(pl->d_wpack);
+        (void)hipFree(pl->d_cov_col);
+        (void)hipFree(pl->d_cov_j0);
+        (void)hipFree(pl->d_cov_cnt);
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_dst16);
@@ -551,6 +558,69 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         HIP_TRY(hipEventElapsedTime(&prof->total_ms, ev[0], ev[3]));
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
+    return ICV_OK;
+}
+
+int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                    int32_t flags, const double* thr, int64_t chunksize, int64_t row_phase, double* gene_out,
+                    int64_t ldg, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    if (!gene_out || ldg < m->n_cols) return fail(ICV_ERR_INVALID, "gene_out is null or ldg < n_cols");
+    if (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
+        return fail(ICV_ERR_INVALID, "chunksize / row_phase invalid");
+    if ((rc = ensure_device(pl))) return rc;
+    const icv::Plan& p = pl->p;
+    const int64_t n = m->n_rows;
+    if (n < 1) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int W = p.W, n_cov = (int)p.cov_col.size();
+    float* out32 = nullptr;
+    double *win = nullptr, *gv = nullptr, *med = nullptr, *cmed = nullptr, *cstat = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&out32, (size_t)n * W * sizeof(float), st));
+    HIP_TRY(hipMallocAsync((void**)&win, (size_t)n * W * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&gv, (size_t)n * (n_cov > 0 ? n_cov : 1) * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&med, (size_t)n * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&cmed, (size_t)n * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&cstat, (size_t)n * 2 * sizeof(double), st));
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out32, W, cmed, cstat, K, lay))) return rc;
+    K.win_out = win;
+    if (m->dtype == ICV_F32)
+        rc = m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, *lay, st)
+                                    : launch_smooth_t<float, true>(pl, K, *lay, st);
+    else
+        rc = m->format == ICV_DENSE ? launch_smooth_t<double, false>(pl, K, *lay, st)
+                                    : launch_smooth_t<double, true>(pl, K, *lay, st);
+    if (rc) return rc;
+    {
+        const int64_t total = n * ldg;
+        hipLaunchKernelGGL(icv::k_fill_nan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gene_out, total);
+    }
+    if (n_cov > 0) {
+        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
+            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
+            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
+            hipLaunchKernelGGL(icv::k_gene_means, grid, dim3(256), 0, st, win + r0 * W, nr, W, pl->d_cov_j0,
+                               pl->d_cov_cnt, n_cov, gv + r0 * n_cov);
+        }
+        hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, gv, n, n_cov, med);
+        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
+            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
+            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
+            // chunk of row r0 + i: (r0 + i + row_phase) / chunksize relative to thr[0]
+            hipLaunchKernelGGL(icv::k_gene_finish, grid, dim3(256), 0, st, gv + r0 * n_cov, med + r0, thr, chunksize,
+                               row_phase + r0, pl->d_cov_col, n_cov, gene_out + r0 * ldg, ldg);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(out32, st));
+    HIP_TRY(hipFreeAsync(win, st));
+    HIP_TRY(hipFreeAsync(gv, st));
+    HIP_TRY(hipFreeAsync(med, st));
+    HIP_TRY(hipFreeAsync(cmed, st));
+    HIP_TRY(hipFreeAsync(cstat, st));
     return ICV_OK;
 }
 

@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 
         // ---------------- wavefront 0: scan the histogram of the previous cell --------------------
         if (selector && have_prev) {
+            __builtin_amdgcn_s_setprio(3);  // the other 7 wavefronts of the workgroup wait for this scan
             const int lane = tl;
             if (sc->nanflag) {
                 if (lane == 0) {
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // A: histogram consumed, row free; b1/b2 published
         ICV_PHASE(0)
         int w_pack[MAXW];
@@ -353,6 +355,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         if (selector && have_prev && sc->mode == 0) {
             // exact float64 rank among the <= 64 gathered candidates -> median
+            __builtin_amdgcn_s_setprio(3);
             const int lane = tl;
             const int n = sc->ncand < 64 ? sc->ncand : 64;
             const int below = sc->below;
@@ -368,6 +371,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             const double b = readlane_d(mine, r2 ? (int)__builtin_ctzll(r2) : 0);
             const double med = (k1 == k2) ? a : (a + b) / 2.0;
             if (lane == 0) sc->med = med;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();  // B3: {S0,S1} ready, histogram cleared, median of the previous cell published
         ICV_PHASE(4)

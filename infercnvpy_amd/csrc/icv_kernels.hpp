@@ -68,6 +68,7 @@ struct KParams {
     // kernel handed back); k_smooth_ws appends to the same list
     int64_t* row_list;
     int* row_count;
+    double* win_out;  // k_smooth only (optional): float64 smoothed windows before centring, n_rows x W
 };
 
 struct Scratch {
@@ -526,6 +527,7 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
         for (int j = t; j < W; j += NT) {
             const double y = win[j] - med;
             orow[j] = (float)y;
+            if (P.win_out) P.win_out[cell * (int64_t)W + j] = win[j];
             sum = sum + y;
             sq = fma(y, y, sq);
         }
@@ -1236,6 +1238,162 @@ __global__ void __launch_bounds__(256) k_row_abs_sum(const float* x, int64_t n_r
     for (int j = threadIdx.x & 63; j < n_cols; j += 64) acc += (double)fabsf(xr[j]);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// calculate_gene_values (reference tl/_infercnv.py:247-298, :443-453)
+//   gene value = np.mean over the kept windows that contain the gene (sorted-gene coordinates);
+//   then minus the per-cell median over the covered genes; |v| < noise threshold -> 0.
+// ---------------------------------------------------------------------------------------
+// numpy's float64 add.reduce of a contiguous array (pairwise summation with 8 accumulators for
+// 8 <= n <= 128, recursion above) -- np.mean(list of window values) goes through it
+__device__ inline double numpy_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;  // numpy starts from -0.0; the sign of a zero sum is irrelevant here
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i = 8;
+        for (; i + 8 <= n; i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_sum(a, n2) + numpy_sum(a + n2, n - n2);
+}
+
+// gv[cell][q] for covered gene q: mean of windows j0 .. j0+cnt-1 of that cell
+__global__ void __launch_bounds__(256) k_gene_means(const double* win, int64_t n_rows, int W, const int32_t* cov_j0,
+                                                    const int32_t* cov_cnt, int n_cov, double* gv) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int64_t cell = blockIdx.y;
+    if (q >= n_cov) return;
+    const int cnt = cov_cnt[q];
+    const double* w = win + cell * (int64_t)W + cov_j0[q];
+    gv[cell * (int64_t)n_cov + q] = numpy_sum(w, cnt) / (double)cnt;
+}
+
+// per-row median of a float64 matrix resident in HBM (np.median): one workgroup per row, value-space
+// bisection with workgroup-wide counts until <= 1024 candidates, which are then ranked in LDS
+__global__ void __launch_bounds__(256) k_row_median(const double* x, int64_t n_rows, int n, double* med) {
+    __shared__ double cand[1024];
+    __shared__ int icnt[2][4];
+    __shared__ double dmn[4], dmx[4];
+    __shared__ int ncand, anynan;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double* row = x + (int64_t)blockIdx.x * n;
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    int nanl = 0;
+    for (int i = t; i < n; i += 256) {
+        const double v = row[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        nanl |= (v != v);
+    }
+    mn = wave_min_dpp(mn);
+    mx = wave_max_dpp(mx);
+    if (t == 0) { ncand = 0; anynan = 0; }
+    __syncthreads();
+    if (lane == 0) { dmn[wave] = mn; dmx[wave] = mx; }
+    if (nanl) anynan = 1;
+    __syncthreads();
+    if (anynan) {
+        if (t == 0) med[blockIdx.x] = __builtin_nan("");
+        return;
+    }
+    mn = dmn[0]; mx = dmx[0];
+    for (int i = 1; i < 4; ++i) { mn = dmn[i] < mn ? dmn[i] : mn; mx = dmx[i] > mx ? dmx[i] : mx; }
+    const int k1 = (n - 1) / 2, k2 = n / 2;
+    double lo = prev_double(mn), hi = mx;  // order statistics k1, k2 in (lo, hi]
+    int cnt_lo = 0, cnt_hi = n, it = 0;
+    while (cnt_hi - cnt_lo > 1024 && it < 200) {
+        double mid;
+        if (it < 60) mid = 0.5 * lo + 0.5 * hi;
+        else {
+            const unsigned long long a = ordered_key(lo), b = ordered_key(hi);
+            mid = from_ordered_key(a + ((b - a) >> 1));
+        }
+        if (!(mid > lo && mid < hi)) break;
+        int c = 0;
+        for (int i = t; i < n; i += 256) c += (row[i] <= mid) ? 1 : 0;
+        c = wave_sum_i(c);
+        if (lane == 0) icnt[it & 1][wave] = c;
+        __syncthreads();
+        c = icnt[it & 1][0] + icnt[it & 1][1] + icnt[it & 1][2] + icnt[it & 1][3];
+        if (c > k2) { hi = mid; cnt_hi = c; }
+        else if (c <= k1) { lo = mid; cnt_lo = c; }
+        else {  // pivot separates the two middle elements: a = max{<= mid}, b = min{> mid}
+            double a = -__builtin_inf(), b = __builtin_inf();
+            for (int i = t; i < n; i += 256) {
+                const double v = row[i];
+                if (v <= mid) a = v > a ? v : a;
+                else b = v < b ? v : b;
+            }
+            a = wave_max_dpp(a);
+            b = wave_min_dpp(b);
+            __syncthreads();
+            if (lane == 0) { dmx[wave] = a; dmn[wave] = b; }
+            __syncthreads();
+            if (t == 0) {
+                for (int i = 1; i < 4; ++i) { a = dmx[i] > a ? dmx[i] : a; b = dmn[i] < b ? dmn[i] : b; }
+                med[blockIdx.x] = (a + b) / 2.0;
+            }
+            return;
+        }
+        ++it;
+    }
+    if (cnt_hi - cnt_lo > 1024) {  // adjacent doubles: every candidate equals hi
+        if (t == 0) med[blockIdx.x] = hi;
+        return;
+    }
+    for (int i = t; i < n; i += 256) {
+        const double v = row[i];
+        if (v > lo && v <= hi) {
+            const int idx = atomicAdd(&ncand, 1);
+            if (idx < 1024) cand[idx] = v;
+        }
+    }
+    __syncthreads();
+    const int m = ncand < 1024 ? ncand : 1024;
+    // exact ranks: thread i ranks candidates i, i+256, ...
+    for (int i = t; i < m; i += 256) {
+        const double mine = cand[i];
+        int r = 0;
+        for (int jj = 0; jj < m; ++jj) {
+            const double o = cand[jj];
+            r += (o < mine || (o == mine && jj < i)) ? 1 : 0;
+        }
+        if (r == k1 - cnt_lo) dmn[0] = mine;  // both written before the barrier below, read after
+        if (r == k2 - cnt_lo) dmx[0] = mine;
+    }
+    __syncthreads();
+    if (t == 0) med[blockIdx.x] = (k1 == k2) ? dmn[0] : (dmn[0] + dmx[0]) / 2.0;
+}
+
+// centre on the per-cell median, zero below the chunk threshold, scatter to input column order
+__global__ void __launch_bounds__(256) k_gene_finish(const double* gv, const double* med, const double* thr,
+                                                     int64_t chunksize, int64_t row_phase, const int32_t* cov_col,
+                                                     int n_cov, double* out, int64_t ldg) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int64_t cell = blockIdx.y;
+    if (q >= n_cov) return;
+    double v = gv[cell * (int64_t)n_cov + q] - med[cell];
+    if (thr) {
+        const double th = thr[(cell + row_phase) / chunksize];
+        if (fabs(v) < th) v = 0.0;
+    }
+    out[cell * ldg + cov_col[q]] = v;
+}
+
+__global__ void __launch_bounds__(256) k_fill_nan(double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = __builtin_nan("");
 }
 
 }  // namespace icv

@@ -48,6 +48,8 @@ struct Plan {
     std::vector<double> w_denom;     // W: sum of weights / gene count
     std::vector<int32_t> w_start_sorted, w_len_sorted;  // sorted-gene coordinates, for the API
     std::vector<int32_t> pad_idx;    // padded positions without a gene
+    // calculate_gene_values: genes covered by at least one kept window, in chromosome-sorted order
+    std::vector<int32_t> cov_col, cov_j0, cov_cnt;  // input column, first covering window, #windows
     std::vector<int32_t> w_pack;     // ws path: (start block & 0xffff) | (len << 16)
     std::vector<uint16_t> dst16;     // fast path: kFastUMax*kThreads*4 entries, Gp (trash slot) = masked
     double pyr_den = 1.0, pyr_rcp = 1.0;
@@ -169,6 +171,28 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
     }
     p.lay32 = make_layout(p, 4);
     p.lay64 = make_layout(p, 8);
+
+    // per-gene window coverage (reference _calculate_gene_averages, :247-291): kept window j of a
+    // chromosome covers sorted genes [j*step, j*step + window); small chromosomes: the single window
+    p.cov_col.clear(); p.cov_j0.clear(); p.cov_cnt.clear();
+    for (int c = 0; c < n_chr; ++c) {
+        const int gc = p.chrom_off[c + 1] - p.chrom_off[c];
+        const int w0 = p.chr_pos[c];
+        const int wc = (c + 1 < n_chr ? p.chr_pos[c + 1] : p.W) - w0;
+        for (int i = 0; i < gc; ++i) {
+            int j0 = 0, j1 = 0;  // windows [j0, j1]
+            if (window < gc) {
+                j0 = (i - window + 1 + step - 1) / step;
+                if (i - window + 1 < 0) j0 = 0;
+                j1 = i / step;
+                if (j1 > wc - 1) j1 = wc - 1;
+                if (j1 < j0) continue;  // not covered -> NaN in the output
+            }
+            p.cov_col.push_back(order[p.chrom_off[c] + i]);
+            p.cov_j0.push_back(w0 + j0);
+            p.cov_cnt.push_back(j1 - j0 + 1);
+        }
+    }
 
     p.pad_idx.clear();
     for (int i = 0; i < p.Gp; ++i)

@@ -109,8 +109,6 @@ def infercnv(
     if {"chromosome", "start", "end"} - set(adata.var.columns) != set():
         raise ValueError(
             "Genomic positions not found. There need to be `chromosome`, `start`, and `end` columns in `adata.var`. ")
-    if calculate_gene_values:
-        raise NotImplementedError("calculate_gene_values=True is not implemented on the GPU path yet")
     _lib.load()  # fail loudly before doing any work if the HIP extension is missing
 
     plan = GenePlan(adata.var["chromosome"].to_numpy(), adata.var["start"].to_numpy(),
@@ -153,6 +151,8 @@ def infercnv(
         per_row = max(1.0, X.nnz / max(n_obs, 1)) * (esz + 4) + 8 + 4 * plan.n_windows + 64
     else:
         per_row = n_vars * esz + 4 * plan.n_windows + 64
+    if calculate_gene_values:  # float64 gene matrix + float64 windows + covered-gene means
+        per_row += 8 * (2 * n_vars + plan.n_windows) + 4 * plan.n_windows
     slab_rows = int((0.45 * free_b) // per_row)
     slab_rows = max(chunksize, slab_rows // chunksize * chunksize)
     bounds = [(r, min(n_obs, r + slab_rows)) for r in range(0, max(n_obs, 1), slab_rows)] if n_obs else []
@@ -185,12 +185,16 @@ def infercnv(
         elif X.dtype in (np.float32, np.float16) and compute == np.float64:
             flags |= _lib.ICV_FLAG_ROUND_F32
 
-    pieces = []
+    pieces, gene_pieces = [], []
     for i, (r0, r1) in enumerate(bounds):
         res = _engine.run_hot_path(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip,
                                    dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags)
         host = res.out.cpu().numpy()
         pieces.append(sp.csr_matrix(host.astype(np.float64)))
+        if calculate_gene_values:
+            gv = _engine.gene_values(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr,
+                                     chunksize=chunksize, flags=flags)
+            gene_pieces.append(gv.cpu().numpy())
     cache.clear()
     if pieces:
         res_mat = sp.vstack(pieces).tocsr() if len(pieces) > 1 else pieces[0]
@@ -199,10 +203,14 @@ def infercnv(
 
     chr_pos = dict(plan.chr_pos)
     per_gene_mtx = None
+    if calculate_gene_values:
+        per_gene_mtx = np.vstack(gene_pieces) if gene_pieces else np.zeros((0, n_vars))
     plan.close()
 
     if inplace:
         adata.obsm[f"X_{key_added}"] = res_mat
         adata.uns[key_added] = {"chr_pos": chr_pos}
+        if calculate_gene_values:
+            adata.layers[f"gene_values_{key_added}"] = per_gene_mtx
     else:
         return chr_pos, res_mat, per_gene_mtx

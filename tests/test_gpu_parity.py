@@ -97,6 +97,46 @@ def test_golden_reference_mean_on_gpu(name):
     np.testing.assert_allclose(got[~flipped], g.out[~flipped], rtol=0, atol=ATOL)
 
 
+@pytest.mark.parametrize("name", [n for n in case_names() if n.startswith("genevals") or n.startswith("mock4x10")])
+def test_golden_gene_values(name):
+    """calculate_gene_values=True against the captured reference (incl. the reference's own 4 x 10 fixture,
+    tests/test_tools.py:143-191): NaN pattern exact, values to float64 rounding."""
+    import infercnvpy_amd as cnv
+
+    g = GoldenCase(name)
+    ad = _adata(g)
+    chr_pos, res, per_gene = cnv.tl.infercnv(ad, inplace=False, **g.api_kwargs())
+    assert {k: int(v) for k, v in chr_pos.items()} == g.chr_pos
+    np.testing.assert_allclose(res.toarray(), g.out, rtol=0, atol=ATOL_TIGHT)
+    assert per_gene.shape == g.per_gene.shape and per_gene.dtype == np.float64
+    np.testing.assert_array_equal(np.isnan(per_gene), np.isnan(g.per_gene))
+    np.testing.assert_array_equal(np.nan_to_num(per_gene) == 0, np.nan_to_num(g.per_gene) == 0)
+    np.testing.assert_allclose(np.nan_to_num(per_gene), np.nan_to_num(g.per_gene), rtol=0, atol=1e-12)
+    cnv.tl.infercnv(ad, **g.api_kwargs())
+    assert "gene_values_cnv" in ad.layers and ad.layers["gene_values_cnv"].shape == g.per_gene.shape
+
+
+def test_gene_values_against_oracle_medium():
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var([300, 120, 101, 60], extra=(("chrX", 10), (None, 3)))
+    X = cases.synthetic_expr(40, len(v["names"]), seed=61)
+    ref = X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    for fmt in (np.asarray, sp.csr_matrix):
+        ad = SimpleAnnData(fmt(X), var=var)
+        _, res, pg = cnv.tl.infercnv(ad, reference=ref, window_size=50, step=7, chunksize=16,
+                                     calculate_gene_values=True, inplace=False)
+        _, o_res, o_pg, _ = O.infercnv(fmt(X), v["chromosome"], v["start"], reference=ref, window_size=50, step=7,
+                                       chunksize=16, calculate_gene_values=True)
+        np.testing.assert_allclose(res.toarray(), o_res.toarray(), rtol=0, atol=ATOL_TIGHT)
+        np.testing.assert_array_equal(np.isnan(pg), np.isnan(o_pg))
+        np.testing.assert_array_equal(np.nan_to_num(pg) == 0, np.nan_to_num(o_pg) == 0)
+        np.testing.assert_allclose(np.nan_to_num(pg), np.nan_to_num(o_pg), rtol=0, atol=1e-12)
+
+
 def test_reference_fixture_through_public_api():
     """The reference's own 4 x 10 fixture (tests/conftest.py:61-108) through tl.infercnv, chunksize=2."""
     import infercnvpy_amd as cnv
