@@ -168,6 +168,13 @@ int icv_gene_values(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, co
                     double lfc_clip, int32_t flags, const double *thr, int64_t chunksize,
                     int64_t row_phase, double *gene_out, int64_t ldg, void *stream);
 
+/* ---- CSR packing of X_cnv (reference :455 `csr_matrix(x_res)`, :137 vstack) ------------------
+ * Two steps around a caller-side prefix sum: count the non-zeros of every row of the dense float32
+ * result, then write column indices (int32) and values (float64) at indptr[row]. */
+int icv_csr_count(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, int64_t *row_nnz, void *stream);
+int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const int64_t *indptr,
+                 int32_t *indices, double *data, void *stream);
+
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);

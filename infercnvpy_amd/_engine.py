@@ -186,3 +186,21 @@ def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_cl
         plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(thr), int(chunksize),
         int(row_phase), _ptr(out), out.stride(0), _stream_ptr(torch)))
     return out
+
+
+def dense_to_host_csr(out, n_cols):
+    """Dense float32 device result -> scipy CSR float64 on the host, packed on the GPU first."""
+    torch = _torch()
+    lib = _lib.load()
+    rows = out.shape[0]
+    counts = torch.empty(rows, dtype=torch.int64, device="cuda")
+    _lib.check(lib.icv_csr_count(_ptr(out), rows, n_cols, out.stride(0), _ptr(counts), _stream_ptr(torch)))
+    indptr = torch.zeros(rows + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(counts, 0, out=indptr[1:])
+    nnz = int(indptr[-1].item())
+    indices = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
+    data = torch.empty(max(nnz, 1), dtype=torch.float64, device="cuda")
+    _lib.check(lib.icv_csr_fill(_ptr(out), rows, n_cols, out.stride(0), _ptr(indptr), _ptr(indices), _ptr(data),
+                                _stream_ptr(torch)))
+    return sp.csr_matrix((data[:nnz].cpu().numpy(), indices[:nnz].cpu().numpy(), indptr.cpu().numpy()),
+                         shape=(rows, n_cols))

@@ -624,6 +624,26 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     return ICV_OK;
 }
 
+int icv_csr_count(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, int64_t* row_nnz, void* stream) {
+    if (!x || !row_nnz || n_cols < 0 || ld < n_cols) return fail(ICV_ERR_INVALID, "bad csr_count arguments");
+    if (n_rows < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_csr_count, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld, row_nnz);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_csr_fill(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, const int64_t* indptr, int32_t* indices,
+                 double* data, void* stream) {
+    if (!x || !indptr || !indices || !data || n_cols < 0 || ld < n_cols)
+        return fail(ICV_ERR_INVALID, "bad csr_fill arguments");
+    if (n_rows < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_csr_fill, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld, indptr, indices, data);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
 int icv_row_abs_sum(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, double* row_sum, void* stream) {
     if (!x || !row_sum || n_cols < 0 || ld < n_cols) return fail(ICV_ERR_INVALID, "bad row_abs_sum arguments");
     if (n_rows < 1) return ICV_OK;

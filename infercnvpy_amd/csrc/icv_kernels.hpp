@@ -1396,4 +1396,40 @@ __global__ void __launch_bounds__(256) k_fill_nan(double* out, int64_t n) {
     if (i < n) out[i] = __builtin_nan("");
 }
 
+// ---------------------------------------------------------------------------------------
+// X_cnv is returned as CSR float64 (reference :455, :137): count / pack the non-zeros of the dense
+// float32 result on the device, so that only ~13 % of the matrix crosses PCIe.  One wavefront per row.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_csr_count(const float* x, int64_t n_rows, int n_cols, int64_t ld,
+                                                   int64_t* row_nnz) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* xr = x + row * ld;
+    int c = 0;
+    for (int j = threadIdx.x & 63; j < n_cols; j += 64) c += (xr[j] != 0.0f) ? 1 : 0;  // NaN counts as stored
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) row_nnz[row] = c;
+}
+
+__global__ void __launch_bounds__(256) k_csr_fill(const float* x, int64_t n_rows, int n_cols, int64_t ld,
+                                                  const int64_t* indptr, int32_t* indices, double* data) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * ld;
+    int64_t base = indptr[row];
+    for (int j0 = 0; j0 < n_cols; j0 += 64) {
+        const int j = j0 + lane;
+        const float v = j < n_cols ? xr[j] : 0.0f;
+        const bool nz = v != 0.0f;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(nz);
+        if (nz) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            indices[base + pos] = j;
+            data[base + pos] = (double)v;
+        }
+        base += __popcll(m);
+    }
+}
+
 }  // namespace icv

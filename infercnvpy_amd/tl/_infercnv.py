@@ -189,8 +189,7 @@ def infercnv(
     for i, (r0, r1) in enumerate(bounds):
         res = _engine.run_hot_path(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip,
                                    dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags)
-        host = res.out.cpu().numpy()
-        pieces.append(sp.csr_matrix(host.astype(np.float64)))
+        pieces.append(_engine.dense_to_host_csr(res.out, plan.n_windows))
         if calculate_gene_values:
             gv = _engine.gene_values(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr,
                                      chunksize=chunksize, flags=flags)
