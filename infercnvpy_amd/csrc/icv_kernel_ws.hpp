@@ -30,7 +30,7 @@ struct ScratchW {
     int b1, b2;
     int ncand;
     int below;              // windows in bins below b1
-    double med;             // median of the previous cell, published before B3
+    double ma, mb;          // the two middle order statistics of the previous cell, published before B3
     double psum[NWAVE], psq[NWAVE];  // per-wave moments of the previous cell
     double cand[64];
 };
@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         sc->nanflag = 0;
         sc->mode = 1;
         sc->ncand = 0;
-        sc->med = 0.0;
+        sc->ma = 0.0;
+        sc->mb = 0.0;
     }
     u32x4 xq[CSR ? 1 : UMAX];  // dense: the prefetched row
     unsigned short epos[CSR ? kCsrPF : 1];  // CSR: prefetched entries of the next cell
@@ -159,7 +160,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             if (sc->nanflag) {
                 if (lane == 0) {
                     sc->nanflag = 0;
-                    sc->med = __builtin_nan("");
+                    sc->ma = __builtin_nan("");
+                    sc->mb = __builtin_nan("");
                     sc->mode = 1;
                 }
             } else {
@@ -199,7 +201,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                         // too many windows share the median bins: hand the cell back to k_smooth
                         const int slot = atomicAdd(P.row_count, 1);
                         P.row_list[slot] = pcell;
-                        sc->med = 0.0;
+                        sc->ma = 0.0;
+                        sc->mb = 0.0;
                         sc->mode = 2;
                     }
                 }
@@ -353,32 +356,38 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                 if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
             }
         }
-        if (selector && have_prev && sc->mode == 0) {
-            // exact float64 rank among the <= 64 gathered candidates -> median
-            __builtin_amdgcn_s_setprio(3);
-            const int lane = tl;
+        if (have_prev && sc->mode == 0) {
+            // exact float64 ranks of the <= 64 gathered candidates, all wavefronts: thread (ci, part)
+            // compares candidate ci with candidates 8 part .. 8 part + 7, the 8 partial ranks of a
+            // candidate sit in 8 consecutive lanes and are added with DPP
             const int n = sc->ncand < 64 ? sc->ncand : 64;
             const int below = sc->below;
-            const double mine = (lane < n) ? sc->cand[lane] : __builtin_inf();
-            int rank = 0;
-            for (int jj = 0; jj < n; ++jj) {
-                const double o = readlane_d(mine, jj);  // jj is wave-uniform
-                rank += (o < mine || (o == mine && jj < lane)) ? 1 : 0;
+            const int ci = tl >> 3, part = tl & 7;
+            const double mine = (ci < n) ? sc->cand[ci] : __builtin_inf();
+            int r = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int jj = part * 8 + q;
+                const double o = sc->cand[jj];
+                r += (jj < n && (o < mine || (o == mine && jj < ci))) ? 1 : 0;
             }
-            const unsigned long long r1 = __builtin_amdgcn_ballot_w64(lane < n && rank == k1 - below);
-            const unsigned long long r2 = __builtin_amdgcn_ballot_w64(lane < n && rank == k2 - below);
-            const double a = readlane_d(mine, r1 ? (int)__builtin_ctzll(r1) : 0);
-            const double b = readlane_d(mine, r2 ? (int)__builtin_ctzll(r2) : 0);
-            const double med = (k1 == k2) ? a : (a + b) / 2.0;
-            if (lane == 0) sc->med = med;
-            __builtin_amdgcn_s_setprio(0);
+            r += dpp_move_i<0xB1>(r);   // lanes ^1
+            r += dpp_move_i<0x4E>(r);   // lanes ^2
+            r += dpp_move_i<0x141>(r);  // row_half_mirror: the other quad of the 8-lane group
+            if (part == 0 && ci < n) {
+                if (r == k1 - below) sc->ma = mine;
+                if (r == k2 - below) sc->mb = mine;
+            }
         }
         __syncthreads();  // B3: {S0,S1} ready, histogram cleared, median of the previous cell published
         ICV_PHASE(4)
         asm volatile("" : "+v"(tl));
+        double med = 0.0;    // kept in registers for the write-out after B4: by then wavefront 0 may
+        int prev_mode = 1;   // already be publishing the next cell's state in the same LDS words
         if (have_prev) {
             // x_res of the previous cell from the windows still in registers
-            const double med = sc->med;
+            med = (k1 == k2) ? sc->ma : (sc->ma + sc->mb) / 2.0;
+            prev_mode = sc->mode;
             double sum = 0.0, sq = 0.0;
             float* orow = P.out + pcell * P.ldo;
 #pragma unroll
@@ -464,7 +473,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         __syncthreads();  // B4: histogram complete; moments of the previous cell complete
         ICV_PHASE(5)
-        if (have_prev && tl == 64 && sc->mode != 2) {
+        if (have_prev && tl == 64 && prev_mode != 2) {
             double s = 0.0, q = 0.0;
 #pragma unroll
             for (int i = 0; i < NWAVE; ++i) {
@@ -473,7 +482,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
             P.cell_stats[2 * pcell] = s;
             P.cell_stats[2 * pcell + 1] = q;
-            P.cell_median[pcell] = sc->med;
+            P.cell_median[pcell] = med;
         }
     }
 #ifdef ICV_WS_PROFILE
