@@ -244,6 +244,30 @@ def test_cnv_score_known_answer_and_oracle():
         cnv.tl.cnv_score(ad, obs_key="g", inplace=False)
 
 
+def test_edge_shapes():
+    """Empty matrix, a single cell, fewer cells than a chunk, all-zero matrix."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var([300, 120, 101, 60])
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    n_genes = len(v["names"])
+    ref = np.linspace(0.0, 1.0, n_genes).astype(np.float32)
+    for n in (0, 1, 3):
+        for fmt in (np.asarray, sp.csr_matrix):
+            X = cases.synthetic_expr(max(n, 1), n_genes, seed=71)[:n]
+            chr_pos, res, _ = cnv.tl.infercnv(SimpleAnnData(fmt(X), var=var), reference=ref, inplace=False)
+            assert res.shape == (n, 26) and list(chr_pos) == ["chr1", "chr2", "chr3", "chr4"]
+            if n:
+                _, o_res, _, _ = O.infercnv(fmt(X), v["chromosome"], v["start"], reference=ref)
+                np.testing.assert_array_equal(res.toarray() == 0, o_res.toarray() == 0)
+                np.testing.assert_allclose(res.toarray(), o_res.toarray(), rtol=0, atol=ATOL_TIGHT)
+    Z = np.zeros((5, n_genes), dtype=np.float32)
+    _, res, _ = cnv.tl.infercnv(SimpleAnnData(Z, var=var), reference=np.zeros(n_genes, np.float32), inplace=False)
+    assert res.nnz == 0 and res.shape == (5, 26)
+
+
 def test_error_behaviour_matches_reference():
     import infercnvpy_amd as cnv
     from infercnvpy_amd._compat import SimpleAnnData
