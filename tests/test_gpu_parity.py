@@ -244,6 +244,59 @@ def test_cnv_score_known_answer_and_oracle():
         cnv.tl.cnv_score(ad, obs_key="g", inplace=False)
 
 
+def test_config1_like_step1_direct_form():
+    """BASELINE config 1 stand-in (the oligodendroglioma file is not shipped): 183 cells x 11 000 genes,
+    window 100, step 1 (the notebook's setting) -> ~9 000 windows, direct-form generic kernel; dense, CSR
+    and CSC inputs give the same result (reference tests/conftest.py:17-24 parametrisation)."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    genes = [1290, 730, 610, 430, 500, 590, 520, 390, 445, 420, 730, 580, 190, 375, 345, 495, 665, 160, 825, 315,
+             140, 255]
+    v = cases.synthetic_var(genes, seed_start=5, seed_perm=6, extra=(("chrX", 300), ("chrM", 13), (None, 40)))
+    X = cases.synthetic_expr(183, len(v["names"]), seed=81)
+    labels = np.array(["Microglia"] * 30 + ["Oligo"] * 25 + ["tumor"] * 128)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    obs = pd.DataFrame({"cell_type": labels}, index=[f"c{i}" for i in range(183)])
+    ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum()
+                     for c in ("Microglia", "Oligo")]).astype(np.float32)
+    o_pos, o_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, step=1)
+    exp = o_res.toarray()
+    assert exp.shape[1] == sum(g - 99 for g in genes)
+    first = None
+    for wrap in (np.asarray, sp.csr_matrix, sp.csc_matrix):
+        ad = SimpleAnnData(wrap(X), obs=obs.copy(), var=var)
+        cnv.tl.infercnv(ad, reference_key="cell_type", reference_cat=["Microglia", "Oligo"], step=1)
+        got = ad.obsm["X_cnv"].toarray()
+        assert {k: int(x) for k, x in ad.uns["cnv"]["chr_pos"].items()} == {k: int(x) for k, x in o_pos.items()}
+        np.testing.assert_array_equal(got == 0, exp == 0)
+        np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
+        if first is None:
+            first = got
+        np.testing.assert_array_equal(got, first)
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_large_gene_count_generic_path(fmt):
+    """30 000 genes do not fit the register-prefetch kernels (G <= 20 480): the generic kernel takes
+    over with one workgroup per CU (120 KB LDS row)."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    genes = [int(g * 1.5) for g in cases.GENES_PER_CHROM_20K]
+    v = cases.synthetic_var(genes, seed_start=7, seed_perm=8)
+    X = cases.synthetic_expr(150, sum(genes), seed=82)
+    ref = X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    Xin = sp.csr_matrix(X) if fmt == "csr" else X
+    _, res, _ = cnv.tl.infercnv(SimpleAnnData(Xin, var=var), reference=ref, chunksize=64, inplace=False)
+    _, o_res, _, _ = O.infercnv(Xin, v["chromosome"], v["start"], reference=ref, chunksize=64, n_jobs=8)
+    np.testing.assert_array_equal(res.toarray() == 0, o_res.toarray() == 0)
+    np.testing.assert_allclose(res.toarray(), o_res.toarray(), rtol=0, atol=ATOL_TIGHT)
+
+
 def test_edge_shapes():
     """Empty matrix, a single cell, fewer cells than a chunk, all-zero matrix."""
     import infercnvpy_amd as cnv
