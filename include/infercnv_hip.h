@@ -175,6 +175,14 @@ int icv_csr_count(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, in
 int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const int64_t *indptr,
                  int32_t *indices, double *data, void *stream);
 
+/* ---- ithcna / ithgex (tl/_scores.py:77-221) -------------------------------------------------
+ * Interquartile range of all n x n entries of np.corrcoef(x) for one group of cells: x is a dense
+ * float32 n x k matrix in HBM (rows = cells).  Rows are centred / scaled with float64 statistics, the
+ * Gram matrix is computed with fp32 MFMA tiles, the percentiles (numpy "linear" method) from exactly
+ * selected order statistics.  Synchronous (the selection reads counters back); *h_iqr is a host double.
+ * Needs 4*n*(n + k) bytes of temporary device memory. */
+int icv_corr_iqr(const float *x, int64_t n, int32_t k, int64_t ld, double *h_iqr, void *stream);
+
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);

@@ -204,3 +204,13 @@ def dense_to_host_csr(out, n_cols):
                                 _stream_ptr(torch)))
     return sp.csr_matrix((data[:nnz].cpu().numpy(), indices[:nnz].cpu().numpy(), indptr.cpu().numpy()),
                          shape=(rows, n_cols))
+
+
+def corr_iqr(x):
+    """IQR of all entries of np.corrcoef(x) for a device float32 matrix (cells x features)."""
+    torch = _torch()
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    out = C.c_double()
+    _lib.check(lib.icv_corr_iqr(_ptr(x), x.shape[0], x.shape[1], x.stride(0), C.byref(out), _stream_ptr(torch)))
+    return float(out.value)

@@ -23,7 +23,7 @@ ICV_FLAG_ROUND_F32 = 2
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
-    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_row_abs_sum", "icv_last_error", "icv_version", "icv_device_count",
+    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_corr_iqr", "icv_row_abs_sum", "icv_last_error", "icv_version", "icv_device_count",
 )
 
 
@@ -81,6 +81,7 @@ def load():
     lib.icv_gene_values.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, i64, vp, i64, vp]
     lib.icv_csr_count.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_csr_fill.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp]
+    lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
     lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_last_error.restype = C.c_char_p
     lib.icv_last_error.argtypes = []

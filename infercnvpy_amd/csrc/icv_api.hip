@@ -14,6 +14,7 @@
 
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
+#include "icv_corr.hpp"
 #include "icv_plan.hpp"
 
 namespace {
@@ -641,6 +642,78 @@ int icv_csr_fill(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, con
     hipLaunchKernelGGL(icv::k_csr_fill, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld, indptr, indices, data);
     HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr, void* stream) {
+    if (!x || !h_iqr || n < 2 || k < 1 || ld < k) return fail(ICV_ERR_INVALID, "bad corr_iqr arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kz = icv::round_up(k, icv::GK);
+    float *z = nullptr, *c = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    struct Guard {  // frees the temporaries on every exit path
+        float *&z, *&c;
+        unsigned long long*& n;
+        ~Guard() {
+            (void)hipFree(z);
+            (void)hipFree(c);
+            (void)hipFree(n);
+        }
+    } guard{z, c, d_cnt};
+    HIP_TRY(hipMalloc((void**)&z, (size_t)n * kz * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c, (size_t)n * n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&d_cnt, 5 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
+    const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
+    hipLaunchKernelGGL(icv::k_gram_mfma, dim3(gt, gt), dim3(256), 0, st, z, n, kz, c);
+    HIP_TRY(hipGetLastError());
+    // the 25 % and 75 % percentiles interpolate between order statistics floor(pos), floor(pos) + 1
+    const double m1 = (double)n * (double)n - 1.0;
+    const double pos[2] = {0.25 * m1, 0.75 * m1};
+    unsigned long long target[4];
+    for (int q = 0; q < 2; ++q) {
+        target[2 * q] = (unsigned long long)std::floor(pos[q]);
+        target[2 * q + 1] = target[2 * q] + 1 < (unsigned long long)(m1 + 1.0) ? target[2 * q] + 1 : target[2 * q];
+    }
+    // smallest key K with #{key <= K} > target, by bisection on the ordered 32-bit keys (exact)
+    unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const int64_t m = n * n;
+    int64_t grid = (m + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    bool any_nan = false;
+    for (int it = 0; it < 33; ++it) {
+        bool active = false;
+        unsigned mid[4];
+        for (int q = 0; q < 4; ++q) {
+            mid[q] = lo[q] + (hi[q] - lo[q]) / 2;
+            active |= lo[q] < hi[q];
+        }
+        if (!active) break;
+        HIP_TRY(hipMemsetAsync(d_cnt, 0, 5 * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(icv::k_count_le4, dim3((unsigned)grid), dim3(256), 0, st, c, m, mid[0], mid[1], mid[2],
+                           mid[3], d_cnt);
+        unsigned long long h[5];
+        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h[4]) { any_nan = true; break; }
+        for (int q = 0; q < 4; ++q) {
+            if (lo[q] >= hi[q]) continue;
+            if (h[q] > target[q]) hi[q] = mid[q];
+            else lo[q] = mid[q] + 1;
+        }
+    }
+    if (any_nan) {
+        *h_iqr = std::nan("");
+        return ICV_OK;
+    }
+    double qv[2];
+    for (int q = 0; q < 2; ++q) {
+        const double a = (double)icv::from_ordered_key32(lo[2 * q]), b = (double)icv::from_ordered_key32(lo[2 * q + 1]);
+        const double t = pos[q] - std::floor(pos[q]);
+        const double d = b - a;
+        qv[q] = t >= 0.5 ? b - d * (1.0 - t) : a + d * t;  // numpy's _lerp
+    }
+    *h_iqr = qv[1] - qv[0];
     return ICV_OK;
 }
 

@@ -45,3 +45,57 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
         adata.obs[key_added] = np.array([cluster_score[c] for c in adata.obs[groupby]])
     else:
         return cluster_score
+
+
+def _group_iqr(adata, groupby, get_matrix, key_added, inplace):
+    """Shared driver of ithcna / ithgex (reference tl/_scores.py:128-151, :197-221)."""
+    torch = _engine._torch()
+    labels = adata.obs[groupby]
+    values = np.asarray(labels.values if hasattr(labels, "values") else labels)
+    groups = labels.unique()
+    scores = {}
+    for group in groups:
+        sel = values == group
+        X = get_matrix(sel)
+        if sp.issparse(X):
+            X = X.toarray()
+        X = np.asarray(X)
+        if X.shape[0] <= 1:
+            continue
+        xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
+        scores[group] = np.float64(_engine.corr_iqr(xd))
+    if inplace:
+        obs = np.empty(adata.shape[0])
+        for group in groups:
+            obs[values == group] = scores[group]  # KeyError for single-cell groups, as the reference
+        adata.obs[key_added] = obs
+    else:
+        return scores
+
+
+def ithgex(adata, groupby: str, *, use_raw=None, layer=None, inplace: bool = True, key_added: str = "ithgex"):
+    """ITHGEX diversity score: IQR of the cell-cell Pearson correlations of gene expression per group.
+
+    Drop-in for ``infercnvpy.tl.ithgex`` (reference tl/_scores.py:77-151); the correlation matrix is an
+    fp32 MFMA contraction on the GPU.
+    """
+    if use_raw and layer is not None:
+        raise ValueError(
+            f"Cannot use expression from both layer and raw. You provided:'use_raw={use_raw}' and 'layer={layer}'")
+
+    def get(sel):
+        if layer is not None:
+            return adata.layers[layer][sel]
+        if use_raw:
+            return adata.raw.X[sel]
+        return adata.X[sel]
+
+    return _group_iqr(adata, groupby, get, key_added, inplace)
+
+
+def ithcna(adata, groupby: str, *, use_rep: str = "X_cnv", key_added: str = "ithcna", inplace: bool = True):
+    """ITHCNA diversity score: IQR of the cell-cell Pearson correlations of the CNV profiles per group.
+
+    Drop-in for ``infercnvpy.tl.ithcna`` (reference tl/_scores.py:154-221).
+    """
+    return _group_iqr(adata, groupby, lambda sel: adata.obsm[use_rep][sel], key_added, inplace)

@@ -41,6 +41,7 @@ __all__ = [
     "infercnv",
     "gene_values_from_windows",
     "cnv_score",
+    "ith_score",
 ]
 
 
@@ -327,3 +328,26 @@ def cnv_score(x_cnv, groups):
         if g not in order:
             order.append(g)
     return {g: np.mean(np.abs(x_cnv[groups == g, :])) for g in order}
+
+
+def ith_score(X, groups):
+    """IQR of all entries of the cell x cell Pearson correlation matrix, per group.
+
+    Restates ``ithgex`` / ``ithcna`` (tl/_scores.py:128-144, :197-213): groups with <= 1 cell are skipped.
+    """
+    groups = np.asarray(groups, dtype=object)
+    order = []
+    for g in groups:
+        if g not in order:
+            order.append(g)
+    out = {}
+    for g in order:
+        x = X[groups == g]
+        if sp.issparse(x):
+            x = x.todense()
+        if x.shape[0] <= 1:
+            continue
+        pcorr = np.corrcoef(x, rowvar=True)
+        q75, q25 = np.percentile(pcorr, [75, 25])
+        out[g] = q75 - q25
+    return out

@@ -14,7 +14,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NA = "__NA__"
 
 
-def case_names(prefixes=None, exclude=("refmean_",)):
+def case_names(prefixes=None, exclude=("refmean_", "ith_")):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     names = [n for n in names if not any(n.startswith(e) for e in exclude)]
     if prefixes:

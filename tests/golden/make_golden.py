@@ -108,8 +108,47 @@ def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="
           f"chr_pos={dict(zip(out['chr_names'], out['chr_vals']))}  [{os.path.getsize(path) / 1024:.0f} KiB]")
 
 
+class DuckRows:
+    """AnnData stand-in for the score functions: boolean row selection only (tl/_scores.py:131, :201)."""
+
+    def __init__(self, X, obs, obsm):
+        self.X, self.obs, self.obsm = X, obs, obsm
+
+    @property
+    def shape(self):
+        return self.X.shape
+
+    def __getitem__(self, key):
+        rows, _ = key
+        m = np.asarray(rows)
+        return DuckRows(self.X[m], self.obs[m], {k: v[m] for k, v in self.obsm.items()})
+
+
+def ith_cases(scores):
+    """ithgex / ithcna through the reference's own functions on seeded data."""
+    rs = np.random.RandomState(11)
+    n, k = 400, 333
+    labels = np.array(["g0"] * 150 + ["g1"] * 249 + ["solo"])[rs.permutation(n)]
+    base = rs.standard_normal((3, k))
+    X = (rs.standard_normal((n, k)) + 0.7 * base[rs.randint(0, 3, n)]).astype(np.float32)
+    X[labels == "g1"] *= rs.gamma(2.0, 1.0, (int((labels == "g1").sum()), 1)).astype(np.float32)
+    cnv = sp.csr_matrix(np.where(np.abs(X) > 0.8, X, 0).astype(np.float64))
+    obs = pd.DataFrame({"group": labels})
+    ad = DuckRows(X, obs, {"X_cnv": cnv})
+    gex = scores.ithgex(ad, "group", inplace=False)
+    cna = scores.ithcna(ad, "group", inplace=False)
+    keys = sorted(gex)
+    assert keys == sorted(cna) == ["g0", "g1"]
+    np.savez_compressed(os.path.join(HERE, "ith_scores.npz"), X=X, labels=labels, keys=np.array(keys),
+                        gex=np.array([gex[g] for g in keys]), cna=np.array([cna[g] for g in keys]))
+    print("ith_scores:", {g: (gex[g], cna[g]) for g in keys})
+
+
 def main():
     ref, scores = load_reference()
+    if "--only-ith" in sys.argv:
+        return ith_cases(scores)
+    ith_cases(scores)
 
     extra = (("chrX", 30), ("chrY", 6), ("chrM", 8), ("GL000218.1", 9), (None, 5))
     var_m = cases.synthetic_var([230, 110, 101, 100, 99, 57, 140],

@@ -8,6 +8,8 @@ Tolerance (BASELINE.json north_star): X_cnv within 1e-5 (float32 output of float
 additionally check 1e-6), gene/window indexing (chr_pos, window count, zero pattern of the
 threshold step) bit-exact.
 """
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -546,3 +548,52 @@ def test_full_size_properties():
     shifted = _engine.run_hot_path(plan, _engine.DeviceMatrix(dense=(X[rows] + 0.25).contiguous()), ref + 0.25,
                                    dynamic_threshold=None)
     np.testing.assert_allclose(shifted.out.cpu().numpy(), alone.out.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_ith_scores_known_answers_golden_and_oracle():
+    """ithgex / ithcna (reference tests/test_scores.py:6-15) on the MFMA correlation path.
+
+    Tolerance 1e-5 absolute on the score: the Gram matrix is accumulated in float32 (rows normalised
+    with float64 statistics), numpy's corrcoef in float64.
+    """
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    X = np.array([[1, 1, 1, 1, 1, 1, 2, 3], [2, 2, 2, 2, 2, 2, 8, 0], [3, 3, 3, 3, 3, 10, 3, 7]]).T
+    x_cnv = np.array([[1, 1, 1, 2, 2, 1, 1, 1], [2, 2, 2, 1, 1, 2, 2, 2], [4, 4, 4, 2, 2, 3, 3, 3],
+                      [2, 2, 2, 4, 4, 4, 4, 4]]).T
+    obs = pd.DataFrame({"group": list("AAAAABBB")}, index=[f"c{i}" for i in range(8)])
+    for wrap in (np.array, sp.csr_matrix, sp.csc_matrix):
+        ad = SimpleAnnData(wrap(X), obs=obs.copy(), obsm={"X_cnv": wrap(x_cnv)})
+        res = cnv.tl.ithgex(ad, "group", inplace=False)
+        assert res["A"] == 0 and res["B"] == pytest.approx(1.2628, abs=1e-3)
+        assert res["B"] == pytest.approx(O.ith_score(X, list("AAAAABBB"))["B"], abs=1e-5)
+        res = cnv.tl.ithcna(ad, "group", inplace=False)
+        assert res["A"] == pytest.approx(1.053, abs=1e-3) and res["B"] == 0
+        cnv.tl.ithcna(ad, "group")
+        cnv.tl.ithgex(ad, "group", key_added="gex")
+        assert ad.obs["ithcna"].values[0] == pytest.approx(1.053, abs=1e-3) and ad.obs["gex"].values[-1] == pytest.approx(1.2628, abs=1e-3)
+    with pytest.raises(ValueError):
+        cnv.tl.ithgex(ad, "group", use_raw=True, layer="counts")
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ith_scores.npz"), allow_pickle=False)
+    Xg, labels = z["X"], z["labels"]
+    ad = SimpleAnnData(Xg, obs=pd.DataFrame({"group": labels}),
+                       obsm={"X_cnv": sp.csr_matrix(np.where(np.abs(Xg) > 0.8, Xg, 0).astype(np.float64))})
+    gex = cnv.tl.ithgex(ad, "group", inplace=False)
+    cna = cnv.tl.ithcna(ad, "group", inplace=False)
+    assert sorted(gex) == list(z["keys"]) == sorted(cna)
+    for i, g in enumerate(z["keys"]):
+        np.testing.assert_allclose(gex[g], z["gex"][i], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(cna[g], z["cna"][i], rtol=0, atol=1e-5, equal_nan=True)
+    with pytest.raises(KeyError):  # the reference fails the same way on a single-cell group (:148)
+        cnv.tl.ithgex(ad, "group")
+
+    # ragged sizes (n not a multiple of the 128 tile, k not a multiple of 16) against numpy
+    rng = np.random.RandomState(5)
+    for n, k in ((2, 3), (129, 17), (700, 1802), (2500, 4000)):
+        Xr = (rng.standard_normal((n, k)) + rng.standard_normal((1, k))).astype(np.float32)
+        got = cnv.tl.ithcna(SimpleAnnData(np.zeros((n, 1)), obs=pd.DataFrame({"g": ["a"] * n}), obsm={"X_cnv": Xr}),
+                            "g", inplace=False)["a"]
+        assert got == pytest.approx(O.ith_score(Xr, ["a"] * n)["a"], abs=1e-5)

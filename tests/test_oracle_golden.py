@@ -6,6 +6,8 @@
 (2) vectors captured by running the reference in the build container
     (tests/golden/make_golden.py) -- bit-exact float64 comparison.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -144,3 +146,34 @@ def test_oracle_reference_means_match_captured(fmt):
     np.testing.assert_array_equal(np.asarray(O.reference_profile(X, None, None, None, X.shape[1])), z["r_all"])
     np.testing.assert_array_equal(
         np.asarray(O.reference_profile(X, z["obs"], ["normalA", "normalB"], None, X.shape[1])), z["r_cat"])
+
+
+# --------------------------------------------------------------------------- #
+# ithgex / ithcna: the reference's own known answers (tests/test_scores.py:6-15, conftest.py:111-138)
+# --------------------------------------------------------------------------- #
+ITH_X = np.array([[1, 1, 1, 1, 1, 1, 2, 3], [2, 2, 2, 2, 2, 2, 8, 0], [3, 3, 3, 3, 3, 10, 3, 7]]).T
+ITH_CNV = np.array(
+    [[1, 1, 1, 2, 2, 1, 1, 1], [2, 2, 2, 1, 1, 2, 2, 2], [4, 4, 4, 2, 2, 3, 3, 3], [2, 2, 2, 4, 4, 4, 4, 4]]
+).T
+ITH_GROUPS = list("AAAAABBB")
+
+
+@pytest.mark.parametrize("fmt", [np.array, sp.csr_matrix, sp.csc_matrix])
+def test_ith_score_reference_known_answers(fmt):
+    gex = O.ith_score(fmt(ITH_X), ITH_GROUPS)
+    assert gex["A"] == 0
+    assert gex["B"] == pytest.approx(1.2628, abs=0.001)
+    cna = O.ith_score(fmt(ITH_CNV), ITH_GROUPS)
+    assert cna["A"] == pytest.approx(1.053, abs=0.001)
+    assert cna["B"] == 0
+
+
+def test_ith_score_captured_reference():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ith_scores.npz"), allow_pickle=False)
+    X, labels = z["X"], z["labels"]
+    gex = O.ith_score(X, labels)
+    cna = O.ith_score(sp.csr_matrix(np.where(np.abs(X) > 0.8, X, 0).astype(np.float64)), labels)
+    assert sorted(gex) == list(z["keys"])  # the single-cell group is skipped
+    for i, g in enumerate(z["keys"]):
+        np.testing.assert_array_equal(gex[g], z["gex"][i])
+        np.testing.assert_array_equal(cna[g], z["cna"][i])  # includes a NaN score (constant profile)
