@@ -183,6 +183,24 @@ int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, con
  * Needs 4*n*(n + k) bytes of temporary device memory. */
 int icv_corr_iqr(const float *x, int64_t n, int32_t k, int64_t ld, double *h_iqr, void *stream);
 
+/* ---- cell-level hierarchical clustering behind the heatmap dendrogram (BASELINE.json config 5) ----
+ * No call site in the reference (scanpy's `dendrogram=True` of sc.pl.heatmap, forwarded by
+ * pl/_chromosome_heatmap.py:74-85, clusters category means); the oracle is scipy pdist + linkage("ward").
+ *
+ * icv_pairwise_sqeuclidean: out[(i - row_begin)*ldo + j] = ||x_i - x_j||^2 for row_begin <= i < row_end and
+ * all 0 <= j < n (float32; the full symmetric n x n matrix with a zero diagonal for row range [0, n); a row
+ * block is what one GPU of a row-sharded job computes).  x is a dense float32 n x d matrix in HBM; columns are
+ * centred first (translation invariant), the contraction runs on fp32 MFMA tiles.  Needs 4*n*d + 8*n bytes
+ * of temporary device memory.
+ *
+ * icv_ward_linkage: Ward linkage of the n points whose squared distances are in dist_sq (n x n float32 in
+ * HBM, symmetric; OVERWRITTEN).  h_linkage is a HOST array of (n-1) x 4 doubles in scipy's linkage-matrix
+ * format (cluster ids, height, size; rows sorted by height).  Synchronous; *h_rounds (optional) returns
+ * the number of reciprocal-nearest-neighbour rounds.  ICV_ERR_INVALID if a distance is NaN. */
+int icv_pairwise_sqeuclidean(const float *x, int64_t n, int32_t d, int64_t ld, int64_t row_begin, int64_t row_end,
+                             float *out, int64_t ldo, void *stream);
+int icv_ward_linkage(float *dist_sq, int64_t n, int64_t ld, double *h_linkage, int32_t *h_rounds, void *stream);
+
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);

@@ -214,3 +214,33 @@ def corr_iqr(x):
     out = C.c_double()
     _lib.check(lib.icv_corr_iqr(_ptr(x), x.shape[0], x.shape[1], x.stride(0), C.byref(out), _stream_ptr(torch)))
     return float(out.value)
+
+
+def pairwise_sqeuclidean(x, out=None, rows=None):
+    """float32 squared Euclidean distances between the rows of a device matrix: the full n x n matrix, or the
+    row block ``rows = (begin, end)`` against all n rows."""
+    torch = _torch()
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    n = x.shape[0]
+    r0, r1 = (0, n) if rows is None else rows
+    if out is None:
+        out = torch.empty((r1 - r0, n), dtype=torch.float32, device=x.device)
+    assert out.shape[0] >= r1 - r0 and out.shape[1] >= n and out.stride(1) == 1
+    _lib.check(lib.icv_pairwise_sqeuclidean(_ptr(x), n, x.shape[1], x.stride(0), r0, r1, _ptr(out), out.stride(0),
+                                            _stream_ptr(torch)))
+    return out
+
+
+def ward_linkage(dist_sq):
+    """scipy-format Ward linkage matrix from a device n x n squared-distance matrix (overwritten)."""
+    torch = _torch()
+    lib = _lib.load()
+    assert dist_sq.is_cuda and dist_sq.dtype == torch.float32 and dist_sq.dim() == 2 and dist_sq.stride(1) == 1
+    n = dist_sq.shape[0]
+    assert dist_sq.shape[1] == n
+    Z = np.empty((max(n - 1, 0), 4), dtype=np.float64)
+    rounds = C.c_int32(0)
+    _lib.check(lib.icv_ward_linkage(_ptr(dist_sq), n, dist_sq.stride(0), Z.ctypes.data, C.byref(rounds),
+                                    _stream_ptr(torch)))
+    return Z, int(rounds.value)

@@ -23,7 +23,9 @@ ICV_FLAG_ROUND_F32 = 2
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
-    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_corr_iqr", "icv_row_abs_sum", "icv_last_error", "icv_version", "icv_device_count",
+    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_corr_iqr",
+    "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_row_abs_sum", "icv_last_error", "icv_version",
+    "icv_device_count",
 )
 
 
@@ -82,6 +84,8 @@ def load():
     lib.icv_csr_count.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_csr_fill.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp]
     lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
+    lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]
+    lib.icv_ward_linkage.argtypes = [vp, i64, i64, vp, P(i32), vp]
     lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_last_error.restype = C.c_char_p
     lib.icv_last_error.argtypes = []

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,10 +12,12 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
 #include "icv_corr.hpp"
+#include "icv_ward.hpp"
 #include "icv_plan.hpp"
 
 namespace {
@@ -665,7 +668,8 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     HIP_TRY(hipMalloc((void**)&d_cnt, 5 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
     const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
-    hipLaunchKernelGGL(icv::k_gram_mfma, dim3(gt, gt), dim3(256), 0, st, z, n, kz, c);
+    hipLaunchKernelGGL(icv::k_gram_mfma<false>, dim3(gt, gt), dim3(256), 0, st, z, n, kz, c, n, (const double*)nullptr,
+                       (int64_t)0, n);
     HIP_TRY(hipGetLastError());
     // the 25 % and 75 % percentiles interpolate between order statistics floor(pos), floor(pos) + 1
     const double m1 = (double)n * (double)n - 1.0;
@@ -714,6 +718,117 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
         qv[q] = t >= 0.5 ? b - d * (1.0 - t) : a + d * t;  // numpy's _lerp
     }
     *h_iqr = qv[1] - qv[0];
+    return ICV_OK;
+}
+
+int icv_pairwise_sqeuclidean(const float* x, int64_t n, int32_t d, int64_t ld, int64_t row_begin, int64_t row_end,
+                             float* out, int64_t ldo, void* stream) {
+    if (!x || !out || n < 1 || d < 1 || ld < d || ldo < n || row_begin < 0 || row_end > n || row_begin > row_end)
+        return fail(ICV_ERR_INVALID, "bad pairwise arguments");
+    if (row_begin == row_end) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kz = icv::round_up(d, icv::GK);
+    const int n_slabs = (int)std::min<int64_t>(256, (n + 63) / 64);
+    float* z = nullptr;
+    double* work = nullptr;  // partial[n_slabs * d] | mean[d] | norm[n]
+    struct Guard {
+        float*& z;
+        double*& w;
+        ~Guard() {
+            (void)hipFree(z);
+            (void)hipFree(w);
+        }
+    } guard{z, work};
+    HIP_TRY(hipMalloc((void**)&z, (size_t)n * kz * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&work, ((size_t)n_slabs * d + d + n) * sizeof(double)));
+    double *partial = work, *mean = work + (size_t)n_slabs * d, *norm = mean + d;
+    const unsigned gd = (unsigned)((d + 255) / 256);
+    hipLaunchKernelGGL(icv::k_colsum_slabs, dim3(gd, n_slabs), dim3(256), 0, st, x, n, d, ld, n_slabs, partial);
+    hipLaunchKernelGGL(icv::k_colmean_finish, dim3(gd), dim3(256), 0, st, partial, n, d, n_slabs, mean);
+    hipLaunchKernelGGL(icv::k_center_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, d, ld, mean, z, kz,
+                       norm);
+    const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
+    const unsigned gr = (unsigned)((row_end - row_begin + icv::GT - 1) / icv::GT);
+    hipLaunchKernelGGL(icv::k_gram_mfma<true>, dim3(gt, gr), dim3(256), 0, st, z, n, kz, out, ldo, norm, row_begin,
+                       row_end);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // the temporaries are freed on return
+    return ICV_OK;
+}
+
+int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, int32_t* h_rounds, void* stream) {
+    if (!dist_sq || !h_linkage || n < 1 || ld < n || n > 0x7fffffff / 2)
+        return fail(ICV_ERR_INVALID, "bad ward_linkage arguments");
+    if (h_rounds) *h_rounds = 0;
+    if (n == 1) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ni = (int)n;
+    // device bookkeeping: 8 int/float arrays of n + log (4 x n) + alive bytes + counts
+    char* buf = nullptr;
+    struct Guard {
+        char*& b;
+        ~Guard() { (void)hipFree(b); }
+    } guard{buf};
+    const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
+    HIP_TRY(hipMalloc((void**)&buf, arr * 13 + 256));
+    int* live = (int*)(buf + arr * 0);
+    int* role = (int*)(buf + arr * 1);
+    float* pair_d = (float*)(buf + arr * 2);
+    int* size_old = (int*)(buf + arr * 3);
+    int* size_new = (int*)(buf + arr * 4);
+    int* nn = (int*)(buf + arr * 5);
+    float* dmin = (float*)(buf + arr * 6);
+    int* log_i = (int*)(buf + arr * 7);
+    int* log_j = (int*)(buf + arr * 8);
+    float* log_d = (float*)(buf + arr * 9);
+    int* log_size = (int*)(buf + arr * 10);
+    unsigned char* alive = (unsigned char*)(buf + arr * 11);
+    icv::WardCounts* counts = (icv::WardCounts*)(buf + arr * 12);
+    hipLaunchKernelGGL(icv::k_ward_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ni, live, role, size_old,
+                       size_new, alive, counts);
+    int n_live = ni, rounds = 0;
+    while (n_live > 1) {
+        hipLaunchKernelGGL(icv::k_ward_round, dim3((unsigned)n_live), dim3(256), 0, st, dist_sq, ld, live, n_live, role,
+                           pair_d, size_old, size_new, nn, dmin);
+        hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, ni, live, role, pair_d, size_old, size_new,
+                           alive, nn, dmin, log_i, log_j, log_d, log_size, counts);
+        icv::WardCounts h;
+        HIP_TRY(hipMemcpyAsync(&h, counts, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        ++rounds;
+        if (h.n_pairs < 1) return fail(ICV_ERR_INVALID, "ward_linkage: distances are not finite");
+        n_live = h.n_live;
+    }
+    if (h_rounds) *h_rounds = rounds;
+    // merge log -> scipy linkage matrix: monotone heights, stable sort, union-find relabelling
+    const size_t m = (size_t)n - 1;
+    std::vector<int> li(m), lj(m), ls(m);
+    std::vector<float> ldq(m);
+    HIP_TRY(hipMemcpy(li.data(), log_i, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lj.data(), log_j, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ls.data(), log_size, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ldq.data(), log_d, m * 4, hipMemcpyDeviceToHost));
+    std::vector<double> height(m), slot_h((size_t)n, 0.0);
+    for (size_t p = 0; p < m; ++p) {
+        double h = std::sqrt((double)ldq[p]);
+        h = std::max(h, std::max(slot_h[li[p]], slot_h[lj[p]]));  // a parent never sorts before its children
+        height[p] = h;
+        slot_h[li[p]] = h;
+    }
+    std::vector<size_t> order(m);
+    for (size_t p = 0; p < m; ++p) order[p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return height[a] < height[b]; });
+    std::vector<int64_t> cluster((size_t)n);  // current scipy id of the cluster kept in each slot
+    for (int64_t s = 0; s < n; ++s) cluster[s] = s;
+    for (size_t q = 0; q < m; ++q) {
+        const size_t p = order[q];
+        const int64_t a = cluster[li[p]], b = cluster[lj[p]];
+        h_linkage[4 * q + 0] = (double)std::min(a, b);
+        h_linkage[4 * q + 1] = (double)std::max(a, b);
+        h_linkage[4 * q + 2] = height[p];
+        h_linkage[4 * q + 3] = (double)ls[p];
+        cluster[li[p]] = n + (int64_t)q;
+    }
     return ICV_OK;
 }
 

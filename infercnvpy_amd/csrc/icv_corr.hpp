@@ -43,19 +43,30 @@ __global__ void __launch_bounds__(256) k_row_normalize(const float* x, int64_t n
 // 2 x 2 MFMA tiles of 32 x 32; K advances 16 per LDS stage.  mfma_f32_32x32x2f32 operand layout:
 // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; D: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// DIST = false: C = clip(Z Z^T, -1, 1) (np.corrcoef); DIST = true: C[i][j] = max(0, |z_i|^2 + |z_j|^2 - 2 z_i.z_j),
+// 0 on the diagonal (squared Euclidean distances; norm[] float64 from k_center_rows).
 constexpr int GT = 128, GK = 16, GLD = GK + 1;  // +1: conflict-free column reads
-__global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, int kz, float* c) {
+// Rows [row0, row0 + gridDim.y * 128) of the result are produced (row block of a sharded matrix); c points at
+// the first of them.  Accumulation is two-level: the MFMA chain runs over GSEG columns of K, then is added to
+// a second float32 accumulator -- the rounding walk of a K = 5000 chain is ~6x shorter.
+constexpr int GSEG = 128;
+template <bool DIST>
+__global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, int kz, float* c, int64_t ldc,
+                                                   const double* norm, int64_t row0, int64_t row1) {
     __shared__ float sa[GT * GLD], sb[GT * GLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+    const int64_t i0 = row0 + (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
     const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                acc[a][b][r] = 0.0f;
+                tot[a][b][r] = 0.0f;
+            }
 
     for (int k0 = 0; k0 < kz; k0 += GK) {
         // stage 128 rows x 16 columns of both panels: 2048 floats each, 8 per thread (two float4)
@@ -64,7 +75,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
             const int idx = t + h * 256;       // 0..511: row = idx / 4, quarter = idx % 4
             const int r = idx >> 2, qd = idx & 3;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (i0 + r < n) va = *reinterpret_cast<const float4*>(z + (i0 + r) * (int64_t)kz + k0 + qd * 4);
+            if (i0 + r < row1) va = *reinterpret_cast<const float4*>(z + (i0 + r) * (int64_t)kz + k0 + qd * 4);
             if (j0 + r < n) vb = *reinterpret_cast<const float4*>(z + (j0 + r) * (int64_t)kz + k0 + qd * 4);
             float* pa = sa + r * GLD + qd * 4;
             float* pb = sb + r * GLD + qd * 4;
@@ -87,6 +98,17 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
+        if (((k0 + GK) & (GSEG - 1)) == 0 || k0 + GK >= kz) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tot[a][b][r] += acc[a][b][r];
+                        acc[a][b][r] = 0.0f;
+                    }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -96,10 +118,15 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = i0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t col = j0 + wj + b * 32 + (lane & 31);
-                if (row < n && col < n) {
-                    float v = acc[a][b][r];
-                    v = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);  // np.corrcoef clips to [-1, 1]
-                    c[row * n + col] = v;
+                if (row < row1 && col < n) {
+                    float v = tot[a][b][r];
+                    if (DIST) {
+                        const double d2 = norm[row] + norm[col] - 2.0 * (double)v;
+                        v = (row == col || !(d2 > 0.0)) ? (d2 != d2 ? (float)d2 : 0.0f) : (float)d2;
+                    } else {
+                        v = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);  // np.corrcoef clips to [-1, 1]
+                    }
+                    c[(row - row0) * ldc + col] = v;
                 }
             }
 }

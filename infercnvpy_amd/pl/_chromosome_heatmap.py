@@ -20,7 +20,7 @@ def _sorted_chr_pos(adata, use_rep):
 
 
 def _draw(matrix, labels, chr_names, chr_pos, *, groupby, cmap, figsize, vmin, vmax, show, save, ymin_lines,
-          dendrogram_order=None, **kwargs):
+          dendrogram_order=None, cell_rank=None, **kwargs):
     import matplotlib.pyplot as plt
     from matplotlib.colors import TwoSlopeNorm
 
@@ -33,6 +33,9 @@ def _draw(matrix, labels, chr_names, chr_pos, *, groupby, cmap, figsize, vmin, v
     except TypeError:
         pass
     order = np.concatenate([np.flatnonzero(labels == c) for c in cats]) if len(cats) else np.arange(0)
+    if cell_rank is not None:  # cells of a group in dendrogram (Ward leaf) order
+        order = np.concatenate([g[np.argsort(cell_rank[g], kind="stable")]
+                                for g in (np.flatnonzero(labels == c) for c in cats)]) if len(cats) else order
     mat = matrix[order]
     sizes = [int((labels == c).sum()) for c in cats]
 
@@ -98,6 +101,18 @@ def chromosome_heatmap(adata, *, groupby: str = "cnv_leiden", use_rep: str = "cn
         vmax = np.nanmax(data)
 
     dense = x.toarray() if sp.issparse(x) else np.asarray(x)
+    # `dendrogram=True` (forwarded to sc.pl.heatmap by the reference, :83): here the cells of every group are
+    # ordered by the leaves of the GPU Ward linkage of all cells (tl.cell_linkage, BASELINE config 5)
+    cell_rank = None
+    if kwargs.pop("dendrogram", False):
+        from ..tl._linkage import cell_linkage
+
+        key = f"{use_rep}_linkage"
+        if key not in adata.uns or len(adata.uns[key]["leaves"]) != dense.shape[0]:
+            cell_linkage(adata, use_rep=use_rep)
+        cell_rank = np.empty(dense.shape[0], dtype=np.int64)
+        cell_rank[np.asarray(adata.uns[key]["leaves"])] = np.arange(dense.shape[0])
+    kwargs["cell_rank"] = cell_rank
     return _draw(dense, adata.obs[groupby].values, chr_names, chr_pos, groupby=groupby, cmap=cmap,
                  figsize=figsize, vmin=vmin, vmax=vmax, show=bool(show), save=save, ymin_lines=0, **kwargs)
 

@@ -42,6 +42,7 @@ __all__ = [
     "gene_values_from_windows",
     "cnv_score",
     "ith_score",
+    "ward_linkage",
 ]
 
 
@@ -351,3 +352,15 @@ def ith_score(X, groups):
         q75, q25 = np.percentile(pcorr, [75, 25])
         out[g] = q75 - q25
     return out
+
+
+def ward_linkage(X):
+    """Build-defined oracle of BASELINE config 5 (SURVEY.md 8(c) iii): the reference has no call site for
+    cell-level clustering, so parity is anchored on scipy (1.15.3 here): pdist (float64 Euclidean) +
+    linkage(method="ward").  PARITY UNPINNED against the reference."""
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import pdist
+
+    if sp.issparse(X):
+        X = X.toarray()
+    return linkage(pdist(np.asarray(X, dtype=np.float64)), method="ward")

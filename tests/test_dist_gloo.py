@@ -118,3 +118,59 @@ def test_chunk_moments_segments():
                 continue
             assert m[k, 0] == hi - lo
             np.testing.assert_allclose(m[k, 1:], stats[lo:hi].sum(dim=0).numpy(), rtol=1e-14)
+
+
+# --------------------------------------------------------------------------- #
+# config 5: row-block distances on every rank -> gathered on rank 0 -> Ward -> broadcast
+# --------------------------------------------------------------------------- #
+def _cpu_distance_rows(x_all, r0, r1, out):
+    x = x_all.numpy().astype(np.float64)
+    d = ((x[r0:r1, None, :] - x[None, :, :]) ** 2).sum(-1)
+    out[: r1 - r0] = torch.from_numpy(d.astype(np.float32))
+    return out
+
+
+def _cpu_ward(dist_sq):
+    from scipy.cluster.hierarchy import linkage
+    from scipy.spatial.distance import squareform
+
+    d = np.sqrt(dist_sq.numpy().astype(np.float64))
+    return linkage(squareform((d + d.T) / 2, checks=False), method="ward")
+
+
+def _ward_worker(rank, world, port, ragged, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(8)
+        n = 61 if ragged else 60
+        X = (rng.standard_normal((n, 12)) + 3 * rng.randint(0, 3, (n, 1))).astype(np.float32)
+        bounds = [(0, 25), (25, n)] if ragged else [(0, 30), (30, 60)]
+        r0, r1 = bounds[rank]
+        Z = icd.ward_linkage_sharded(torch.from_numpy(X[r0:r1]), distance_rows=_cpu_distance_rows, ward=_cpu_ward)
+        Zs = O.ward_linkage(X)
+        np.testing.assert_allclose(Z[:, 2], Zs[:, 2], rtol=1e-5)
+        np.testing.assert_array_equal(Z[:, [0, 1, 3]], Zs[:, [0, 1, 3]])
+        q.put((rank, "ok", None))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_two_rank_sharded_ward_linkage(ragged):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ward_worker, args=(r, 2, port, ragged, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"

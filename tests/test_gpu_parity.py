@@ -597,3 +597,122 @@ def test_ith_scores_known_answers_golden_and_oracle():
         got = cnv.tl.ithcna(SimpleAnnData(np.zeros((n, 1)), obs=pd.DataFrame({"g": ["a"] * n}), obsm={"X_cnv": Xr}),
                             "g", inplace=False)["a"]
         assert got == pytest.approx(O.ith_score(Xr, ["a"] * n)["a"], abs=1e-5)
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE config 5: pairwise Euclidean (fp32 MFMA) + Ward linkage; oracle = scipy (parity unpinned
+# against the reference, which has no call site for cell-level clustering)
+# --------------------------------------------------------------------------- #
+def _blobs(n, d, k, seed, spread=4.0):
+    rng = np.random.RandomState(seed)
+    centres = rng.standard_normal((k, d)) * spread
+    return (centres[rng.randint(0, k, n)] + rng.standard_normal((n, d))).astype(np.float32)
+
+
+def _cluster_hashes(Z):
+    n = Z.shape[0] + 1
+    key = np.random.RandomState(0).randint(1, 2 ** 62, size=n, dtype=np.int64).astype(np.uint64)
+    h = np.concatenate([key, np.zeros(n - 1, dtype=np.uint64)])
+    for q in range(n - 1):
+        h[n + q] = h[int(Z[q, 0])] + h[int(Z[q, 1])]  # wraps mod 2^64
+    return set(h[n:].tolist())
+
+
+@pytest.mark.parametrize("n,d", [(2, 3), (3, 1), (129, 17), (700, 64), (1500, 1802)])
+def test_pairwise_sqeuclidean_matches_float64(n, d):
+    import torch
+    from infercnvpy_amd import _engine
+
+    X = _blobs(n, d, 5, seed=n) + 3.0  # off-centre on purpose: the kernel centres the columns
+    got = _engine.pairwise_sqeuclidean(torch.from_numpy(X).cuda()).cpu().numpy()
+    x64 = X.astype(np.float64)
+    exp = ((x64[:, None, :] - x64[None, :, :]) ** 2).sum(-1) if n <= 700 else None
+    if exp is None:
+        g = x64 @ x64.T
+        exp = np.maximum(np.diag(g)[:, None] + np.diag(g)[None, :] - 2 * g, 0)
+    np.testing.assert_array_equal(got, got.T)  # bit-exact symmetry (the Ward rounds rely on it)
+    assert (np.diag(got) == 0).all()
+    # tolerance: 1e-5 relative to the scale of the squared norms entering the difference
+    scale = exp.max()
+    np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("n,d,k", [(2, 4, 1), (3, 2, 1), (10, 3, 2), (257, 20, 6), (1000, 50, 8), (3000, 300, 12)])
+def test_ward_linkage_matches_scipy(n, d, k):
+    import infercnvpy_amd as cnv
+    from oracle import infercnv_oracle as O
+    from scipy.cluster.hierarchy import fcluster, is_valid_linkage
+
+    X = _blobs(n, d, k, seed=100 + n)
+    Z, rounds = cnv.tl.ward_linkage(X, return_rounds=True)
+    Zs = O.ward_linkage(X)
+    assert Z.shape == Zs.shape == (n - 1, 4) and is_valid_linkage(Z)
+    assert rounds <= n - 1
+    # heights: float32 distance matrix vs scipy's float64 -> 1e-4 relative (documented in DESIGN.md)
+    np.testing.assert_allclose(Z[:, 2], Zs[:, 2], rtol=1e-4)
+    np.testing.assert_array_equal(np.sort(Z[:, 3]), np.sort(Zs[:, 3]))
+    # same tree: identical flat clusterings at several cuts (merge ids can only permute between
+    # merges whose heights agree to rounding)
+    for kk in {2, 3, min(k, n), min(2 * k, n), min(50, n)}:
+        a = fcluster(Z, kk, "maxclust")
+        b = fcluster(Zs, kk, "maxclust")
+        assert len(set(zip(a, b))) == len(set(a)) == len(set(b))
+    # same tree topology: the leaf set of every merged cluster (hashed) appears in scipy's tree too; cluster ids
+    # themselves may permute between merges whose heights agree to rounding
+    mine, ref = _cluster_hashes(Z), _cluster_hashes(Zs)
+    assert len(mine & ref) >= (0.999 if n > 500 else 1.0) * (n - 1)
+
+
+def test_ward_linkage_duplicates_sparse_and_errors():
+    import infercnvpy_amd as cnv
+    from oracle import infercnv_oracle as O
+
+    X = _blobs(60, 8, 3, seed=4)
+    X[10:20] = X[10]  # duplicate cells: zero distances, ties
+    Z = cnv.tl.ward_linkage(sp.csr_matrix(X))
+    Zs = O.ward_linkage(X)
+    np.testing.assert_allclose(Z[:, 2], Zs[:, 2], rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(np.sort(Z[:, 3]), np.sort(Zs[:, 3]))
+    bad = X.copy()
+    bad[3, 2] = np.nan
+    with pytest.raises(ValueError):
+        cnv.tl.ward_linkage(bad)
+    with pytest.raises(ValueError):
+        cnv.tl.ward_linkage(X[:1])
+
+
+def test_cell_linkage_and_heatmap_dendrogram():
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from scipy.cluster.hierarchy import leaves_list
+
+    X = _blobs(300, 40, 4, seed=9)
+    X[np.abs(X) < 0.5] = 0
+    ad = SimpleAnnData(np.zeros((300, 2)), obs=pd.DataFrame({"g": np.repeat(["a", "b", "c"], 100)}),
+                       obsm={"X_cnv": sp.csr_matrix(X.astype(np.float64))},
+                       uns={"cnv": {"chr_pos": {"chr1": 0, "chr2": 25}}})
+    cnv.tl.cell_linkage(ad)
+    Z = ad.uns["cnv_linkage"]["linkage"]
+    np.testing.assert_array_equal(ad.uns["cnv_linkage"]["leaves"], leaves_list(Z))
+    axes = cnv.pl.chromosome_heatmap(ad, groupby="g", dendrogram=True, show=False)
+    assert "heatmap_ax" in axes
+
+
+def test_distance_row_blocks_and_single_process_sharded_driver():
+    """Row blocks (what each GPU of a sharded job computes) are bit-identical to the rows of the full matrix."""
+    import torch
+    from infercnvpy_amd import _engine, dist as icd
+
+    X = _blobs(777, 130, 5, seed=3)
+    xd = torch.from_numpy(X).cuda()
+    full = _engine.pairwise_sqeuclidean(xd)
+    for r0, r1 in ((0, 1), (100, 389), (389, 777), (640, 777)):
+        blk = _engine.pairwise_sqeuclidean(xd, rows=(r0, r1))
+        assert torch.equal(blk, full[r0:r1])
+    Z = icd.ward_linkage_sharded(xd)  # world size 1: same code path as tl.ward_linkage
+    import infercnvpy_amd as cnv
+
+    np.testing.assert_array_equal(Z, cnv.tl.ward_linkage(X))
