@@ -16,9 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libinfercnv_hip.so")
 SOURCES = [os.path.join(CSRC, "icv_api.hip")]
-DEPS = SOURCES + [
-    os.path.join(CSRC, "icv_kernels.hpp"),
-    os.path.join(CSRC, "icv_plan.hpp"),
+DEPS = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))) + [
     os.path.join(os.path.dirname(HERE), "include", "infercnv_hip.h"),
 ]
 
@@ -45,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         "-ffp-contract=off",  # float64 evaluation order is part of the parity contract
         "-Wall", "-Wno-unused-function",
         "-o", LIB + ".tmp",
-    ] + SOURCES
+    ] + os.environ.get("ICV_EXTRA_HIPCC_FLAGS", "").split() + SOURCES
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

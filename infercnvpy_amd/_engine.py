@@ -97,10 +97,11 @@ def to_device_matrix(X, dtype=None, device="cuda"):
             X = X.copy()
             X.sum_duplicates()
         data = X.data if np_dtype is None else X.data.astype(np_dtype, copy=False)
+        indptr64 = X.indptr.astype(np.int64, copy=False)
         return DeviceMatrix(
-            indptr_host=X.indptr.astype(np.int64),
-            indptr=torch.from_numpy(X.indptr.astype(np.int64)).to(device),
-            indices=torch.from_numpy(X.indices.astype(np.int32)).to(device),
+            indptr_host=indptr64,
+            indptr=torch.from_numpy(np.ascontiguousarray(indptr64)).to(device),
+            indices=torch.from_numpy(np.ascontiguousarray(X.indices.astype(np.int32, copy=False))).to(device),
             data=torch.from_numpy(np.ascontiguousarray(data)).to(device),
             shape=X.shape,
         )

@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinfercnv_hip.so")
+# INFERCNV_HIP_LIB: developer override (kernel variants built side by side for A/B timing)
+LIB_PATH = os.environ.get("INFERCNV_HIP_LIB") or os.path.join(_HERE, "libinfercnv_hip.so")
 
 ICV_OK, ICV_ERR_INVALID, ICV_ERR_UNSUPPORTED, ICV_ERR_HIP, ICV_ERR_NOMEM = range(5)
 ICV_F32, ICV_F64 = 0, 1

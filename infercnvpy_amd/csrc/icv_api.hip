@@ -455,7 +455,7 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
             else
                 hipLaunchKernelGGL(kd, grid, block, lds, st, (const double*)m->values, m->indptr, m->indices, m->n_rows,
                                    nc, row_group, g, rows_per_slab, partial);
-            hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 255) / 256), dim3(256), 0, st, partial, (int)n_slabs, nc,
+            hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 63) / 64), dim3(1024), 0, st, partial, (int)n_slabs, nc,
                                sums + (int64_t)g * nc);
         }
         HIP_TRY(hipGetLastError());
@@ -474,7 +474,7 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         else
             hipLaunchKernelGGL(icv::k_colsum_dense<double>, grid, block, 0, st, (const double*)m->values,
                                m->n_rows, m->ld, nc, row_group, g, rows_per_slab, partial);
-        hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 255) / 256), block, 0, st, partial, (int)n_slabs, nc,
+        hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 63) / 64), dim3(1024), 0, st, partial, (int)n_slabs, nc,
                            sums + (int64_t)g * nc);
     }
     HIP_TRY(hipGetLastError());

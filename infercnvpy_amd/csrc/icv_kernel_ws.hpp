@@ -264,6 +264,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                                             __uint_as_float((HI).w), cap, BND, P.trunc);                         \
     }
             if (!P.bounded) {
+                // one reference row: y = x - ref, clip with v_med3_f32.  v_med3 drops NaNs, np.clip keeps
+                // them: pairs are checked with an unordered compare and a fix-up pass (never taken on real
+                // data) rewrites the NaN slots.
+                bool any_nan = false;
 #pragma unroll
                 for (int h = 0; h < UMAX; h += UH) {
                     u32x4 lo[UH];
@@ -274,8 +278,33 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                         dd[k] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, (h + k) * NT * 8, 0);
                     }
 #pragma unroll
-                    for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], dd[k], 0)
+                    for (int k = 0; k < UH; ++k) {
+                        const float y0 = __uint_as_float(xq[h + k].x) - __uint_as_float(lo[k].x);
+                        const float y1 = __uint_as_float(xq[h + k].y) - __uint_as_float(lo[k].y);
+                        const float y2 = __uint_as_float(xq[h + k].z) - __uint_as_float(lo[k].z);
+                        const float y3 = __uint_as_float(xq[h + k].w) - __uint_as_float(lo[k].w);
+                        any_nan |= __builtin_isunordered(y0, y1) | __builtin_isunordered(y2, y3);
+                        row[dd[k].x & 0xffffu] = __builtin_amdgcn_fmed3f(y0, -cap, cap);
+                        row[dd[k].x >> 16] = __builtin_amdgcn_fmed3f(y1, -cap, cap);
+                        row[dd[k].y & 0xffffu] = __builtin_amdgcn_fmed3f(y2, -cap, cap);
+                        row[dd[k].y >> 16] = __builtin_amdgcn_fmed3f(y3, -cap, cap);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if (__builtin_expect(any_nan, 0)) {
+#pragma unroll
+                    for (int u = 0; u < UMAX; ++u) {
+                        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * NT * 16, 0);
+                        const u32x2 dq = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, u * NT * 8, 0);
+                        const float y0 = __uint_as_float(xq[u].x) - __uint_as_float(lo.x);
+                        const float y1 = __uint_as_float(xq[u].y) - __uint_as_float(lo.y);
+                        const float y2 = __uint_as_float(xq[u].z) - __uint_as_float(lo.z);
+                        const float y3 = __uint_as_float(xq[u].w) - __uint_as_float(lo.w);
+                        if (y0 != y0) row[dq.x & 0xffffu] = y0;
+                        if (y1 != y1) row[dq.x >> 16] = y1;
+                        if (y2 != y2) row[dq.y & 0xffffu] = y2;
+                        if (y3 != y3) row[dq.y >> 16] = y3;
+                    }
                 }
             } else {
 #pragma unroll

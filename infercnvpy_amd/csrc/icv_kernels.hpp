@@ -1188,12 +1188,23 @@ __global__ void __launch_bounds__(256) k_colsum_dense(const T* x, int64_t n_rows
     }
 }
 
-__global__ void __launch_bounds__(256) k_colsum_finish(const double* partial, int n_slabs, int n_cols, double* sums) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= n_cols) return;
+// sums[col] += sum over slabs, in a fixed order: 16 lanes per column each add every 16th slab, then the 16
+// partial sums are added in lane order (deterministic; 64 columns x 16 slab lanes per workgroup)
+__global__ void __launch_bounds__(1024) k_colsum_finish(const double* partial, int n_slabs, int n_cols, double* sums) {
+    __shared__ double part[16][64];
+    const int c = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
     double acc = 0.0;
-    for (int s = 0; s < n_slabs; ++s) acc += partial[(int64_t)s * n_cols + col];
-    sums[col] += acc;
+    if (col < n_cols)
+        for (int s = l; s < n_slabs; s += 16) acc += partial[(int64_t)s * n_cols + col];
+    part[l][c] = acc;
+    __syncthreads();
+    if (l == 0 && col < n_cols) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += part[q][c];
+        sums[col] += tot;
+    }
 }
 
 // CSR: a workgroup owns (row slab) x (tile of 8192 columns): float64 accumulators in LDS (ds_add_f64),

@@ -164,7 +164,8 @@ def infercnv(
             if len(bounds) > 1:
                 cache.clear()
             r0, r1 = bounds[i]
-            cache[i] = _engine.to_device_matrix(X[r0:r1], dtype=tdtype)
+            rows = X if (r0 == 0 and r1 == n_obs) else X[r0:r1]  # slicing a CSR matrix copies it
+            cache[i] = _engine.to_device_matrix(rows, dtype=tdtype)
         return cache[i]
 
     def dm_slabs():
