@@ -668,7 +668,7 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     HIP_TRY(hipMalloc((void**)&d_cnt, 5 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
     const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
-    hipLaunchKernelGGL(icv::k_gram_mfma<false>, dim3(gt, gt), dim3(256), 0, st, z, n, kz, c, n, (const double*)nullptr,
+    hipLaunchKernelGGL((icv::k_gram_mfma<false, true>), dim3(gt, gt), dim3(256), 0, st, z, n, kz, c, n, (const double*)nullptr,
                        (int64_t)0, n);
     HIP_TRY(hipGetLastError());
     // the 25 % and 75 % percentiles interpolate between order statistics floor(pos), floor(pos) + 1
@@ -749,8 +749,12 @@ int icv_pairwise_sqeuclidean(const float* x, int64_t n, int32_t d, int64_t ld, i
                        norm);
     const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
     const unsigned gr = (unsigned)((row_end - row_begin + icv::GT - 1) / icv::GT);
-    hipLaunchKernelGGL(icv::k_gram_mfma<true>, dim3(gt, gr), dim3(256), 0, st, z, n, kz, out, ldo, norm, row_begin,
-                       row_end);
+    if (row_begin == 0 && row_end == n)
+        hipLaunchKernelGGL((icv::k_gram_mfma<true, true>), dim3(gt, gt), dim3(256), 0, st, z, n, kz, out, ldo, norm,
+                           (int64_t)0, n);
+    else
+        hipLaunchKernelGGL((icv::k_gram_mfma<true, false>), dim3(gt, gr), dim3(256), 0, st, z, n, kz, out, ldo, norm,
+                           row_begin, row_end);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // the temporaries are freed on return
     return ICV_OK;

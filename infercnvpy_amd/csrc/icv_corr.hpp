@@ -38,22 +38,29 @@ __global__ void __launch_bounds__(256) k_row_normalize(const float* x, int64_t n
     for (int j = lane; j < kz; j += 64) zr[j] = j < k ? (float)(((double)xr[j] - mean) * inv) : 0.0f;
 }
 
-// C = Z Z^T, Z row-major n x kz (kz multiple of 16, zero padded), C row-major n x n float32.
+// C = Z Z^T, Z row-major n x kz (kz multiple of 16, zero padded), C row-major float32.
 // Workgroup = 256 threads = 4 wavefronts, 128 x 128 output tile, each wavefront a 64 x 64 quadrant as
-// 2 x 2 MFMA tiles of 32 x 32; K advances 16 per LDS stage.  mfma_f32_32x32x2f32 operand layout:
+// 2 x 2 MFMA tiles of 32 x 32; K advances 16 per LDS stage, the next stage's global loads are in flight
+// (registers) while the current one is multiplied.  mfma_f32_32x32x2f32 operand layout:
 // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; D: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 // DIST = false: C = clip(Z Z^T, -1, 1) (np.corrcoef); DIST = true: C[i][j] = max(0, |z_i|^2 + |z_j|^2 - 2 z_i.z_j),
 // 0 on the diagonal (squared Euclidean distances; norm[] float64 from k_center_rows).
+// SYM = true (square result, row0 = 0): only tiles on or above the diagonal are computed; an off-diagonal tile
+// is also written transposed (through a 32 x 33 LDS patch per wavefront, so both writes are coalesced) --
+// half the flops and a bit-exactly symmetric matrix.  SYM = false: rows [row0, row1) against all columns (the
+// row block of a sharded matrix; c points at row row0).
+// Accumulation is two-level: the MFMA chain runs over GSEG columns of K, then is added to a second float32
+// accumulator -- the rounding walk of a K = 5000 chain is ~6x shorter.
 constexpr int GT = 128, GK = 16, GLD = GK + 1;  // +1: conflict-free column reads
-// Rows [row0, row0 + gridDim.y * 128) of the result are produced (row block of a sharded matrix); c points at
-// the first of them.  Accumulation is two-level: the MFMA chain runs over GSEG columns of K, then is added to
-// a second float32 accumulator -- the rounding walk of a K = 5000 chain is ~6x shorter.
 constexpr int GSEG = 128;
-template <bool DIST>
+template <bool DIST, bool SYM>
 __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, int kz, float* c, int64_t ldc,
                                                    const double* norm, int64_t row0, int64_t row1) {
-    __shared__ float sa[GT * GLD], sb[GT * GLD];
+    __shared__ float smem[2 * GT * GLD];
+    if (SYM && blockIdx.x < blockIdx.y) return;  // the mirror image of tile (x, y) is written by tile (y, x)
+    float* sa = smem;
+    float* sb = smem + GT * GLD;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t i0 = row0 + (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
     const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
@@ -68,21 +75,32 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                 tot[a][b][r] = 0.0f;
             }
 
-    for (int k0 = 0; k0 < kz; k0 += GK) {
-        // stage 128 rows x 16 columns of both panels: 2048 floats each, 8 per thread (two float4)
+    // this thread stages rows r = idx / 4 (idx = t, t + 256), columns k0 + 4 (idx % 4) .. + 3 of both panels
+    float4 va[2], vb[2];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int idx = t + h * 256;       // 0..511: row = idx / 4, quarter = idx % 4
+            const int idx = t + h * 256;
             const int r = idx >> 2, qd = idx & 3;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (i0 + r < row1) va = *reinterpret_cast<const float4*>(z + (i0 + r) * (int64_t)kz + k0 + qd * 4);
-            if (j0 + r < n) vb = *reinterpret_cast<const float4*>(z + (j0 + r) * (int64_t)kz + k0 + qd * 4);
+            va[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[h] = va[h];
+            if (i0 + r < row1) va[h] = *reinterpret_cast<const float4*>(z + (i0 + r) * (int64_t)kz + k0 + qd * 4);
+            if (j0 + r < n) vb[h] = *reinterpret_cast<const float4*>(z + (j0 + r) * (int64_t)kz + k0 + qd * 4);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < kz; k0 += GK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = t + h * 256;
+            const int r = idx >> 2, qd = idx & 3;
             float* pa = sa + r * GLD + qd * 4;
             float* pb = sb + r * GLD + qd * 4;
-            pa[0] = va.x; pa[1] = va.y; pa[2] = va.z; pa[3] = va.w;
-            pb[0] = vb.x; pb[1] = vb.y; pb[2] = vb.z; pb[3] = vb.w;
+            pa[0] = va[h].x; pa[1] = va[h].y; pa[2] = va[h].z; pa[3] = va[h].w;
+            pb[0] = vb[h].x; pb[1] = vb[h].y; pb[2] = vb[h].z; pb[3] = vb[h].w;
         }
         __syncthreads();
+        if (k0 + GK < kz) fetch(k0 + GK);
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 2) {
             const int kc = kk + (lane >> 5);
@@ -110,16 +128,19 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                     }
         }
     }
+    const bool mirror = SYM && blockIdx.x != blockIdx.y;
+    float* patch = smem + wave * (32 * 33);  // 4 x 4224 B <= the operand panels (dead after the last barrier)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = i0 + wi + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t row = i0 + wi + a * 32 + rl;
                 const int64_t col = j0 + wj + b * 32 + (lane & 31);
+                float v = tot[a][b][r];
                 if (row < row1 && col < n) {
-                    float v = tot[a][b][r];
                     if (DIST) {
                         const double d2 = norm[row] + norm[col] - 2.0 * (double)v;
                         v = (row == col || !(d2 > 0.0)) ? (d2 != d2 ? (float)d2 : 0.0f) : (float)d2;
@@ -128,7 +149,20 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                     }
                     c[(row - row0) * ldc + col] = v;
                 }
+                if (mirror) patch[rl * 33 + (lane & 31)] = v;
             }
+            if (mirror) {
+                // transposed copy: output row = column cl of the sub-tile, 32 contiguous entries (two rows per pass)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int cl = 2 * q + (lane >> 5);
+                    const int64_t orow = j0 + wj + b * 32 + cl;           // a column of the tile above the diagonal
+                    const int64_t ocol = i0 + wi + a * 32 + (lane & 31);  // its row index
+                    const float v = patch[(lane & 31) * 33 + cl];
+                    if (orow < n && ocol < row1) c[orow * ldc + ocol] = v;
+                }
+            }
+        }
 }
 
 __device__ __forceinline__ unsigned ordered_key32(float x) {
