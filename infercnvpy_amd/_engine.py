@@ -225,8 +225,8 @@ def pairwise_sqeuclidean(x, out=None, rows=None):
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     n = x.shape[0]
     r0, r1 = (0, n) if rows is None else rows
-    if out is None:
-        out = torch.empty((r1 - r0, n), dtype=torch.float32, device=x.device)
+    if out is None:  # row stride padded to 16 bytes: the Ward rounds use vector loads then
+        out = torch.empty((r1 - r0, (n + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :n]
     assert out.shape[0] >= r1 - r0 and out.shape[1] >= n and out.stride(1) == 1
     _lib.check(lib.icv_pairwise_sqeuclidean(_ptr(x), n, x.shape[1], x.stride(0), r0, r1, _ptr(out), out.stride(0),
                                             _stream_ptr(torch)))

@@ -77,53 +77,38 @@ __device__ __forceinline__ float ward_lw(float dac, float dbc, float dab, int na
     return v > 0.0 ? (float)v : 0.0f;
 }
 
-// One workgroup per live row r (slot index): bring the row up to date with the merges of the previous
-// round (role[c] >= 0: column c absorbed column role[c]; role[r] >= 0: row r absorbed row role[r]) and
-// find the nearest live neighbour.  size_old = sizes before those merges, size_new = after.
-__global__ void __launch_bounds__(256) k_ward_round(float* D, int64_t ld, const int* live, int n_live, const int* role,
-                                                    const float* pair_d, const int* size_old, const int* size_new,
-                                                    int* nn, float* dmin) {
-    const int r = live[blockIdx.x];
-    const int rj = role[r];
-    float* Dr = D + (int64_t)r * ld;
-    const float* Dj = rj >= 0 ? D + (int64_t)rj * ld : nullptr;
-    const float pdr = rj >= 0 ? pair_d[r] : 0.0f;
-    const int so_r = size_old[r], sn_r = size_new[r], so_j = rj >= 0 ? size_old[rj] : 0;
-
-    float best = __builtin_inff();
-    int best_c = -1;
-    for (int idx = threadIdx.x; idx < n_live; idx += 256) {
-        const int c = live[idx];
-        if (c == r) continue;
-        const int cl = role[c];
-        float v;
-        if (rj < 0) {
-            if (cl < 0) {
-                v = Dr[c];
-            } else {
-                v = ward_lw(Dr[c], Dr[cl], pair_d[c], size_old[c], size_old[cl], sn_r);
-                Dr[c] = v;
-            }
-        } else {
-            if (cl < 0) {
-                v = ward_lw(Dr[c], Dj[c], pdr, so_r, so_j, size_old[c]);
-            } else if (r < c) {  // row merge first, then the column merge
-                const float xk = ward_lw(Dr[c], Dj[c], pdr, so_r, so_j, size_old[c]);
-                const float xl = ward_lw(Dr[cl], Dj[cl], pdr, so_r, so_j, size_old[cl]);
-                v = ward_lw(xk, xl, pair_d[c], size_old[c], size_old[cl], sn_r);
-            } else {  // mirrored entry: the same expression as row c evaluates for column r
-                const float ui = ward_lw(Dr[c], Dr[cl], pair_d[c], size_old[c], size_old[cl], so_r);
-                const float uj = ward_lw(Dj[c], Dj[cl], pair_d[c], size_old[c], size_old[cl], so_j);
-                v = ward_lw(ui, uj, pdr, so_r, so_j, size_new[c]);
-            }
-            Dr[c] = v;
+// Updated value of entry (r, c) after the merges of the previous round (role[x] >= 0: x absorbed role[x]);
+// changed = the stored value has to be rewritten.  rj = role[r], cl = role[c].
+struct WardRow {
+    const float* Dr;
+    const float* Dj;
+    int r, rj, so_r, sn_r, so_j;
+    float pdr;
+};
+__device__ __forceinline__ float ward_entry(const WardRow& R, int c, int cl, float drc, const float* pair_d,
+                                            const int* size_old, const int* size_new, bool& changed) {
+    changed = true;
+    if (R.rj < 0) {
+        if (cl < 0) {
+            changed = false;
+            return drc;
         }
-        if (v < best) {  // c ascends within a thread: strict < keeps the lowest index on ties
-            best = v;
-            best_c = c;
-        }
+        return ward_lw(drc, R.Dr[cl], pair_d[c], size_old[c], size_old[cl], R.sn_r);
     }
-    // (value, index) lexicographic minimum over the workgroup
+    if (cl < 0) return ward_lw(drc, R.Dj[c], R.pdr, R.so_r, R.so_j, size_old[c]);
+    if (R.r < c) {  // row merge first, then the column merge
+        const float xk = ward_lw(drc, R.Dj[c], R.pdr, R.so_r, R.so_j, size_old[c]);
+        const float xl = ward_lw(R.Dr[cl], R.Dj[cl], R.pdr, R.so_r, R.so_j, size_old[cl]);
+        return ward_lw(xk, xl, pair_d[c], size_old[c], size_old[cl], R.sn_r);
+    }
+    // mirrored entry: the same expression as row c evaluates for column r
+    const float ui = ward_lw(drc, R.Dr[cl], pair_d[c], size_old[c], size_old[cl], R.so_r);
+    const float uj = ward_lw(R.Dj[c], R.Dj[cl], pair_d[c], size_old[c], size_old[cl], R.so_j);
+    return ward_lw(ui, uj, R.pdr, R.so_r, R.so_j, size_new[c]);
+}
+
+__device__ __forceinline__ void ward_argmin_publish(float best, int best_c, int r, int* nn, float* dmin) {
+    // (value, index) lexicographic minimum over the 256-thread workgroup
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oc = __shfl_xor(best_c, o, 64);
@@ -151,10 +136,117 @@ __global__ void __launch_bounds__(256) k_ward_round(float* D, int64_t ld, const 
     }
 }
 
+// One workgroup per live row r (slot index): bring the row up to date with the merges of the previous
+// round and find the nearest live neighbour.  size_old = sizes before those merges, size_new = after.
+// List form: iterates the compacted live list (late rounds, few live columns).
+__global__ void __launch_bounds__(256) k_ward_round(float* D, int64_t ld, const int* live, int n_live, const int* role,
+                                                    const float* pair_d, const int* size_old, const int* size_new,
+                                                    int* nn, float* dmin) {
+    const int r = live[blockIdx.x];
+    WardRow R;
+    R.r = r;
+    R.rj = role[r];
+    float* Dr = D + (int64_t)r * ld;
+    R.Dr = Dr;
+    R.Dj = R.rj >= 0 ? D + (int64_t)R.rj * ld : nullptr;
+    R.pdr = R.rj >= 0 ? pair_d[r] : 0.0f;
+    R.so_r = size_old[r];
+    R.sn_r = size_new[r];
+    R.so_j = R.rj >= 0 ? size_old[R.rj] : 0;
+
+    float best = __builtin_inff();
+    int best_c = -1;
+    for (int idx = threadIdx.x; idx < n_live; idx += 256) {
+        const int c = live[idx];
+        if (c == r) continue;
+        bool changed;
+        const float v = ward_entry(R, c, role[c], Dr[c], pair_d, size_old, size_new, changed);
+        if (changed) Dr[c] = v;
+        if (v < best) {  // c ascends within a thread: strict < keeps the lowest index on ties
+            best = v;
+            best_c = c;
+        }
+    }
+    ward_argmin_publish(best, best_c, r, nn, dmin);
+}
+
+// Dense form (early rounds, most columns alive, ld % 4 == 0).  An unchanged row (the common case) is one
+// contiguous float4 stream with a byte mask per four columns (bit i: column 4q + i is alive and did not merge)
+// followed by the few merged columns from the round's merge list; a merged row updates every live column.
+// cstate[c] = -2 dead, -1 unchanged, >= 0 the slot column c absorbed.
+__global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, int n, const int* live,
+                                                          const int* cstate, const unsigned char* qmask,
+                                                          const int* merged, int n_merged, const float* pair_d,
+                                                          const int* size_old, const int* size_new, int* nn,
+                                                          float* dmin) {
+    const int r = live[blockIdx.x];
+    WardRow R;
+    R.r = r;
+    R.rj = cstate[r];
+    float* Dr = D + (int64_t)r * ld;
+    R.Dr = Dr;
+    R.Dj = R.rj >= 0 ? D + (int64_t)R.rj * ld : nullptr;
+    R.pdr = R.rj >= 0 ? pair_d[r] : 0.0f;
+    R.so_r = size_old[r];
+    R.sn_r = size_new[r];
+    R.so_j = R.rj >= 0 ? size_old[R.rj] : 0;
+
+    float best = __builtin_inff();
+    int best_c = -1;
+    const int n4 = (n + 3) >> 2;  // the row stride is padded to a multiple of 4; padding columns have mask 0
+    if (R.rj < 0) {
+        const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
+        const int rq = r >> 2;
+        const unsigned rbit = 1u << (r & 3);
+        auto quad = [&](int q, const float4& d, unsigned m) {
+            if (q == rq) m &= ~rbit;
+            // ascending column order: strict < keeps the lowest index on ties
+            if ((m & 1u) && d.x < best) { best = d.x; best_c = 4 * q; }
+            if ((m & 2u) && d.y < best) { best = d.y; best_c = 4 * q + 1; }
+            if ((m & 4u) && d.z < best) { best = d.z; best_c = 4 * q + 2; }
+            if ((m & 8u) && d.w < best) { best = d.w; best_c = 4 * q + 3; }
+        };
+        int q = threadIdx.x;
+        for (; q + 768 < n4; q += 1024) {  // four loads in flight per thread
+            const float4 d0 = Dr4[q], d1 = Dr4[q + 256], d2 = Dr4[q + 512], d3 = Dr4[q + 768];
+            const unsigned m0 = qmask[q], m1 = qmask[q + 256], m2 = qmask[q + 512], m3 = qmask[q + 768];
+            quad(q, d0, m0);
+            quad(q + 256, d1, m1);
+            quad(q + 512, d2, m2);
+            quad(q + 768, d3, m3);
+        }
+        for (; q < n4; q += 256) quad(q, Dr4[q], qmask[q]);
+        // columns that merged in the previous round (Lance-Williams on this row's two entries)
+        for (int idx = threadIdx.x; idx < n_merged; idx += 256) {
+            const int c = merged[idx], cl = cstate[c];
+            const float v = ward_lw(Dr[c], Dr[cl], pair_d[c], size_old[c], size_old[cl], R.sn_r);
+            Dr[c] = v;
+            if (v < best || (v == best && c < best_c)) {
+                best = v;
+                best_c = c;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < n; c += 256) {
+            const int cl = cstate[c];
+            if (cl == -2 || c == r) continue;
+            bool changed;
+            const float v = ward_entry(R, c, cl, Dr[c], pair_d, size_old, size_new, changed);
+            Dr[c] = v;
+            if (v < best) {
+                best = v;
+                best_c = c;
+            }
+        }
+    }
+    ward_argmin_publish(best, best_c, r, nn, dmin);
+}
+
 // Single workgroup (1024 threads).  Finalises the previous round's bookkeeping, detects the reciprocal
 // nearest-neighbour pairs of this round in ascending slot order, logs them and compacts the live list.
-__global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role, float* pair_d, int* size_old,
-                                                     int* size_new, unsigned char* alive, const int* nn,
+__global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role, int* cstate, unsigned char* qmask,
+                                                     float* pair_d,
+                                                     int* size_old, int* size_new, unsigned char* alive, const int* nn,
                                                      const float* dmin, int* log_i, int* log_j, float* log_d,
                                                      int* log_size, WardCounts* counts) {
     __shared__ int s_scan[1024];
@@ -165,6 +257,7 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
     for (int c = t; c < n; c += 1024) {
         size_old[c] = size_new[c];
         role[c] = -1;
+        cstate[c] = alive[c] ? -1 : -2;
     }
     if (t == 0) s_base = 0;
     __syncthreads();
@@ -202,6 +295,8 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
             log_d[m0 + p] = dmin[r];
             log_size[m0 + p] = sz;
             role[r] = c;
+            cstate[r] = c;
+            cstate[c] = -2;
             pair_d[r] = dmin[r];
             size_new[r] = sz;
             alive[c] = 0;
@@ -211,6 +306,13 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
     const int n_pairs = s_base;
     __syncthreads();
     if (t == 0) s_base = 0;
+    for (int q = t; q < (n + 3) / 4; q += 1024) {  // bit i: column 4q + i takes part in the plain arg-min stream
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * q + i < n && cstate[4 * q + i] == -1) m |= 1u << i;
+        qmask[q] = (unsigned char)m;
+    }
     __syncthreads();
     // live-list compaction in place (writes never pass the chunk being read)
     for (int base = 0; base < n_live; base += 1024) {
@@ -231,12 +333,20 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
     }
 }
 
-__global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* role, int* size_old, int* size_new,
-                                                   unsigned char* alive, WardCounts* counts) {
+__global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* role, int* cstate, unsigned char* qmask,
+                                                   int* size_old, int* size_new, unsigned char* alive,
+                                                   WardCounts* counts) {
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < (n + 3) / 4) {
+        unsigned m = 0;
+        for (int i = 0; i < 4; ++i)
+            if (4 * c + i < n) m |= 1u << i;
+        qmask[c] = (unsigned char)m;
+    }
     if (c < n) {
         live[c] = c;
         role[c] = -1;
+        cstate[c] = -1;
         size_old[c] = 1;
         size_new[c] = 1;
         alive[c] = 1;

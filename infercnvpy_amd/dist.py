@@ -242,8 +242,9 @@ def ward_linkage_sharded(x_local, *, group=None, distance_rows=None, ward=None):
         raise ValueError("at least two cells are needed for a linkage")
     rank, ws = (dist.get_rank(group), dist.get_world_size(group)) if len(bounds) > 1 else (0, 1)
     r0, r1 = bounds[rank]
+    ld = (n + 3) // 4 * 4  # 16-byte row stride (vector loads in the Ward rounds)
     if ws == 1:
-        d2 = torch.empty((n, n), dtype=torch.float32, device=x_all.device)
+        d2 = torch.empty((n, ld), dtype=torch.float32, device=x_all.device)[:, :n]
         distance_rows(x_all, 0, n, d2)
         return np.asarray(ward(d2))
 
@@ -251,17 +252,21 @@ def ward_linkage_sharded(x_local, *, group=None, distance_rows=None, ward=None):
         return dist.get_global_rank(group, r) if group is not None else r
 
     if rank == 0:
-        d2 = torch.empty((n, n), dtype=torch.float32, device=x_all.device)
-        distance_rows(x_all, r0, r1, d2[r0:r1])
+        d2 = torch.empty((n, ld), dtype=torch.float32, device=x_all.device)
+        distance_rows(x_all, r0, r1, d2[r0:r1, :n])
+        # the peers' row blocks arrive with the padded stride, so they land in place as contiguous memory
         reqs = [dist.irecv(d2[a:b], src=peer(r), group=group) for r, (a, b) in enumerate(bounds) if r != 0 and b > a]
         for q in reqs:
             q.wait()
+        d2 = d2[:, :n]
         Z = torch.from_numpy(np.ascontiguousarray(ward(d2), dtype=np.float64))
         del d2
     else:
-        block = torch.empty((r1 - r0, n), dtype=torch.float32, device=x_all.device)
+        block = torch.empty((r1 - r0, ld), dtype=torch.float32, device=x_all.device)
         if r1 > r0:
-            distance_rows(x_all, r0, r1, block)
+            if ld > n:
+                block[:, n:] = 0
+            distance_rows(x_all, r0, r1, block[:, :n])
             dist.send(block, dst=peer(0), group=group)
         del block
         Z = torch.empty((n - 1, 4), dtype=torch.float64)

@@ -126,7 +126,7 @@ def test_chunk_moments_segments():
 def _cpu_distance_rows(x_all, r0, r1, out):
     x = x_all.numpy().astype(np.float64)
     d = ((x[r0:r1, None, :] - x[None, :, :]) ** 2).sum(-1)
-    out[: r1 - r0] = torch.from_numpy(d.astype(np.float32))
+    out[: r1 - r0, : x.shape[0]] = torch.from_numpy(d.astype(np.float32))
     return out
 
 
