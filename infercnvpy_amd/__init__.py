@@ -5,6 +5,6 @@
     cnv.tl.cnv_score(adata, "cnv_leiden")
     cnv.pl.chromosome_heatmap(adata, groupby="cell_type")
 """
-from . import pl, tl  # noqa: F401
+from . import io, pl, tl  # noqa: F401
 
 __version__ = "0.1.0"
