@@ -30,6 +30,8 @@ struct ScratchW {
     int b1, b2;
     int ncand;
     int below;              // windows in bins below b1
+    int c1, c2;             // windows in bin b1 / b2
+    int wtot[NWAVE];        // histogram scan: windows in the 512 bins scanned by each wavefront
     double ma, mb;          // the two middle order statistics of the previous cell, published before B3
     double psum[NWAVE], psq[NWAVE];  // per-wave moments of the previous cell
     double cand[64];
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
     ScratchW* sc = reinterpret_cast<ScratchW*>(smem + P.scratch_off);
 
     const int t = threadIdx.x;
-    const bool selector = __builtin_amdgcn_readfirstlane(t >> 6) == 0;  // wavefront 0 (wave-uniform)
+    static_assert(NBIN == 8 * NT, "the histogram scan gives every thread 8 bins");
     const int W = P.W, NB = P.NB;
     const int B = BT > 0 ? BT : P.B;
     const int k1 = (W - 1) / 2, k2 = W / 2;
@@ -124,7 +126,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
         }
     }
-    constexpr int UH = 5;
+#ifndef ICV_UH
+#define ICV_UH 5  // reference / scatter-table vectors per load group of the L phase (divides UMAX)
+#endif
+    constexpr int UH = ICV_UH;
     static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
     double wv[MAXW];  // this thread's windows of the previous cell (x_res needs its median)
 #pragma unroll
@@ -153,63 +158,77 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         int tl = t;
         asm volatile("" : "+v"(tl));  // see k_smooth_fast: keep thread-derived values out of LICM
 
-        // ---------------- wavefront 0: scan the histogram of the previous cell --------------------
-        if (selector && have_prev) {
-            __builtin_amdgcn_s_setprio(3);  // the other 7 wavefronts of the workgroup wait for this scan
-            const int lane = tl;
-            if (sc->nanflag) {
-                if (lane == 0) {
+        // ---------------- histogram scan of the previous cell, all wavefronts ----------------------
+        // Level 1 before barrier A: thread g sums its 8 bins [8 g, 8 g + 8) (one ds_read_b128), a DPP prefix
+        // sum inside the wavefront, the wavefront's total goes to LDS.  Level 2 after A, from registers (the
+        // histogram itself is overwritten by the L phase): the wavefront whose 512 bins contain rank k1 (k2)
+        // locates the lane and then the bin, and publishes it for the candidate gather after B1.
+        int4 hv = make_int4(0, 0, 0, 0);
+        int htot = 0, hincl = 0, nanf = 0;
+        if (have_prev) {
+            nanf = sc->nanflag;
+            hv = reinterpret_cast<const int4*>(hist)[tl];
+            const int s4 = (hv.x + hv.y) + (hv.z + hv.w);  // no carry between halves: counts <= W < 65536
+            htot = (s4 & 0xffff) + ((unsigned)s4 >> 16);
+            hincl = wave_scan_dpp(htot);
+            if ((tl & 63) == 63) sc->wtot[tl >> 6] = hincl;
+        }
+        __syncthreads();  // A: histogram consumed, row free; wavefront totals published
+        if (have_prev) {
+            if (nanf) {
+                if (tl == 0) {
                     sc->nanflag = 0;
                     sc->ma = __builtin_nan("");
                     sc->mb = __builtin_nan("");
                     sc->mode = 1;
                 }
             } else {
-                // level 1: lane l sums bins [64 l, 64 l + 64) (two 16-bit bins per word); which lanes
-                // hold ranks k1 / k2
-                const int4* h4 = reinterpret_cast<const int4*>(hist) + lane * 8;
-                int tot = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int4 v = h4[q];
-                    const int s = (v.x + v.y) + (v.z + v.w);  // no carry between halves: counts <= W < 65536
-                    tot += (s & 0xffff) + ((unsigned)s >> 16);
+                if (tl == 0) {
+                    sc->mode = 0;
+                    sc->ncand = 0;
                 }
-                const int incl = wave_scan_dpp(tot);
-                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(incl > k1);
-                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(incl > k2);
-                const int l1 = m1 ? (int)__builtin_ctzll(m1) : 63, l2 = m2 ? (int)__builtin_ctzll(m2) : 63;
-                const int ex1 = __builtin_amdgcn_readlane(incl - tot, l1), ex2 = __builtin_amdgcn_readlane(incl - tot, l2);
-                // level 2: lane i looks at bin 64 l + i of the located group
-                const int c1 = (hist[l1 * 32 + (lane >> 1)] >> ((lane & 1) * 16)) & 0xffff;
-                const int c2 = (hist[l2 * 32 + (lane >> 1)] >> ((lane & 1) * 16)) & 0xffff;
-                const int in1 = wave_scan_dpp(c1) + ex1, in2 = wave_scan_dpp(c2) + ex2;
-                const unsigned long long n1 = __builtin_amdgcn_ballot_w64(in1 > k1);
-                const unsigned long long n2 = __builtin_amdgcn_ballot_w64(in2 > k2);
-                const int j1 = n1 ? (int)__builtin_ctzll(n1) : 63, j2 = n2 ? (int)__builtin_ctzll(n2) : 63;
-                const int b1 = l1 * 64 + j1, b2 = l2 * 64 + j2;
-                const int below = __builtin_amdgcn_readlane(in1 - c1, j1);
-                const int n = __builtin_amdgcn_readlane(c1, j1) + (b2 != b1 ? __builtin_amdgcn_readlane(c2, j2) : 0);
-                if (lane == 0) {
-                    if (n <= 64) {
-                        sc->b1 = b1;
-                        sc->b2 = b2;
-                        sc->below = below;
-                        sc->ncand = 0;
-                        sc->mode = 0;
-                    } else {
-                        // too many windows share the median bins: hand the cell back to k_smooth
-                        const int slot = atomicAdd(P.row_count, 1);
-                        P.row_list[slot] = pcell;
-                        sc->ma = 0.0;
-                        sc->mb = 0.0;
-                        sc->mode = 2;
+                const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
+                int base = 0;
+#pragma unroll
+                for (int u = 0; u < NWAVE; ++u) base += (u < wv_id) ? sc->wtot[u] : 0;
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int mine = __builtin_amdgcn_readlane(hincl, 63);
+                const int lane = tl & 63;
+#pragma unroll
+                for (int which = 0; which < 2; ++which) {
+                    const int k = which == 0 ? k1 : k2;
+                    if (k >= base && k < base + mine) {  // wave-uniform: this wavefront holds rank k
+                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hincl + base > k);
+                        const int L = (int)__builtin_ctzll(m);
+                        const int ex = __builtin_amdgcn_readlane(hincl - htot, L) + base;  // windows below lane L's bins
+                        const int w0 = __builtin_amdgcn_readlane(hv.x, L), w1 = __builtin_amdgcn_readlane(hv.y, L);
+                        const int w2 = __builtin_amdgcn_readlane(hv.z, L), w3 = __builtin_amdgcn_readlane(hv.w, L);
+                        // lanes 0..7: count of bin i of the located group, prefix over 8 lanes (one DPP row)
+                        const int word = (lane & 6) == 0 ? w0 : ((lane & 6) == 2 ? w1 : ((lane & 6) == 4 ? w2 : w3));
+                        const int cnt = lane < 8 ? ((word >> ((lane & 1) * 16)) & 0xffff) : 0;
+                        int inc = cnt;
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);  // row_shr:1
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);  // row_shr:2
+                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);  // row_shr:4
+                        const unsigned long long mj = __builtin_amdgcn_ballot_w64(lane < 8 && inc + ex > k);
+                        const int j = (int)__builtin_ctzll(mj);
+                        const int bin = ((wv_id << 6) + L) * 8 + j;
+                        const int below = __builtin_amdgcn_readlane(inc - cnt, j) + ex;
+                        const int cj = __builtin_amdgcn_readlane(cnt, j);
+                        if (lane == 0) {
+                            if (which == 0) {
+                                sc->b1 = bin;
+                                sc->below = below;
+                                sc->c1 = cj;
+                            } else {
+                                sc->b2 = bin;
+                                sc->c2 = cj;
+                            }
+                        }
                     }
                 }
             }
         }
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();  // A: histogram consumed, row free; b1/b2 published
         ICV_PHASE(0)
         int w_pack[MAXW];
         if (more) {
@@ -331,18 +350,28 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         __syncthreads();  // B1: row scattered
         ICV_PHASE(2)
         asm volatile("" : "+v"(tl));
-        if (have_prev && sc->mode == 0) {
-            // windows of the previous cell in the bins of its two middle order statistics -> cand[]
+        if (have_prev && !nanf) {
             const int b1 = sc->b1, b2 = sc->b2;
+            const int n_in_bins = sc->c1 + (b2 != b1 ? sc->c2 : 0);
+            if (n_in_bins <= 64) {
+                // windows of the previous cell in the bins of its two middle order statistics -> cand[]
 #pragma unroll
-            for (int i = 0; i < MAXW; ++i) {
-                if (tl + i * NT < W) {
-                    const int b = hist_bin(wv[i], inv_bound);
-                    if (b == b1 || b == b2) {
-                        const int idx = atomicAdd(&sc->ncand, 1);
-                        if (idx < 64) sc->cand[idx] = wv[i];
+                for (int i = 0; i < MAXW; ++i) {
+                    if (tl + i * NT < W) {
+                        const int b = hist_bin(wv[i], inv_bound);
+                        if (b == b1 || b == b2) {
+                            const int idx = atomicAdd(&sc->ncand, 1);
+                            if (idx < 64) sc->cand[idx] = wv[i];
+                        }
                     }
                 }
+            } else if (tl == 0) {
+                // too many windows share the median bins: hand the cell back to k_smooth
+                const int slot = atomicAdd(P.row_count, 1);
+                P.row_list[slot] = pcell;
+                sc->ma = 0.0;
+                sc->mb = 0.0;
+                sc->mode = 2;
             }
         }
         // ---------------- S: block partial sums (registers) ---------------------------------------
