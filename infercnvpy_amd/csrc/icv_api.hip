@@ -256,6 +256,10 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     }
     int per_cu = icv::kLdsLimit / p.fast_lds;
     if (per_cu > 4) per_cu = 4;
+    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
+        const int v = std::atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
     int64_t grid = (int64_t)pl->n_cu * per_cu;
     if (grid > K.n_rows) grid = K.n_rows;
     if (grid < 1) return ICV_OK;

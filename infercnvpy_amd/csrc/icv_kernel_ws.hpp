@@ -132,8 +132,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
     constexpr int UH = ICV_UH;
     static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
     double wv[MAXW];  // this thread's windows of the previous cell (x_res needs its median)
+    unsigned wbin[(MAXW + 1) / 2];  // their histogram bins, two 16-bit bins per register
 #pragma unroll
     for (int i = 0; i < MAXW; ++i) wv[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < (MAXW + 1) / 2; ++i) wbin[i] = 0;
     __syncthreads();
 
     // phase timers cost ~18 VGPRs for every lane: compiled in only with -DICV_WS_PROFILE
@@ -236,6 +239,9 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             // ---------------- L (CSR): zero row, then the cell's prepared entries ------------------
             const int nvec_row = P.scratch_off >> 4;  // 16-byte vectors of the LDS row region
 #pragma unroll
+            for (int i = 0; i < MAXW; ++i)
+                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+#pragma unroll
             for (int h = 0; h < UMAX; h += UH) {
                 u32x4 z[UH];
 #pragma unroll
@@ -252,9 +258,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             for (int i = 0; i < kCsrPF; ++i)
                 if (e0 + tl + i * NT < e1) row[epos[i]] = eval[i];
             for (int64_t k = e0 + tl + (int64_t)kCsrPF * NT; k < e1; k += NT) row[P.pos16[k]] = P.cvals[k];
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i)
-                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see the dense path
             const int64_t nxt = cell + gridDim.x;
             if (nxt < P.n_rows) {
                 const int64_t n0 = P.indptr[nxt], n1 = P.indptr[nxt + 1];
@@ -269,6 +273,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
           } else {
             // ---------------- L: centre, clip, scatter the prefetched row -------------------------
+            // window descriptors first: they are the oldest loads of the phase, complete when the tables are
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i)  // out-of-range windows read 0 (buffer bounds check)
+                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
             for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
 #define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
     {                                                                                                            \
@@ -335,9 +343,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                 }
             }
 #undef ICV_SCATTER4
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i)  // out-of-range windows read 0 (buffer bounds check)
-                w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+            // Every load issued so far has been consumed or is about to be (window descriptors): drain the
+            // counter HERE, so that from now on only the row prefetch below is outstanding.  Without this the
+            // compiler's conservative per-path bookkeeping puts s_waitcnt vmcnt(small) in front of later uses
+            // of these registers (S, O and W phases), which can stall on the HBM prefetch and on the stores.
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
             const int64_t nxt = cell + gridDim.x;
             if (nxt < P.n_rows) {
                 const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + nxt * P.ld, row_bytes);
@@ -358,7 +368,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #pragma unroll
                 for (int i = 0; i < MAXW; ++i) {
                     if (tl + i * NT < W) {
-                        const int b = hist_bin(wv[i], inv_bound);
+                        const int b = (int)((wbin[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
                         if (b == b1 || b == b2) {
                             const int idx = atomicAdd(&sc->ncand, 1);
                             if (idx < 64) sc->cand[idx] = wv[i];
@@ -421,13 +431,18 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             const int n = sc->ncand < 64 ? sc->ncand : 64;
             const int below = sc->below;
             const int ci = tl >> 3, part = tl & 7;
-            const double mine = (ci < n) ? sc->cand[ci] : __builtin_inf();
+            // branch-free: all reads unconditional (cand[] is always allocated), 4 x ds_read_b128 in flight
+            const double mine_raw = sc->cand[ci];
+            const double2* cp = reinterpret_cast<const double2*>(sc->cand + part * 8);
+            const double2 o01 = cp[0], o23 = cp[1], o45 = cp[2], o67 = cp[3];
+            const double o[8] = {o01.x, o01.y, o23.x, o23.y, o45.x, o45.y, o67.x, o67.y};
+            const double mine = (ci < n) ? mine_raw : __builtin_inf();
             int r = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int jj = part * 8 + q;
-                const double o = sc->cand[jj];
-                r += (jj < n && (o < mine || (o == mine && jj < ci))) ? 1 : 0;
+                const int hit = (int)(o[q] < mine) | ((int)(o[q] == mine) & (int)(jj < ci));
+                r += hit & (int)(jj < n);
             }
             r += dpp_move_i<0xB1>(r);   // lanes ^1
             r += dpp_move_i<0x4E>(r);   // lanes ^2
@@ -524,6 +539,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     wv[i] = v;
                     lnan |= (v != v);
                     const int hb = hist_bin(v, inv_bound);
+                    wbin[i >> 1] = (i & 1) ? (wbin[i >> 1] | ((unsigned)hb << 16)) : (unsigned)hb;
                     atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));  // 16-bit bins, two per word
                 }
             }
