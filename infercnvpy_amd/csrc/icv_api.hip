@@ -16,6 +16,7 @@
 
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
+#include "icv_kernel_sp.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_plan.hpp"
@@ -165,19 +166,27 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     return ICV_OK;
 }
 
-int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const icv::KParams& K, hipStream_t st) {
+int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const icv::KParams& K, hipStream_t st,
+               int block = icv::NT) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (std::getenv("ICV_PHASE_PROFILE")) {
         // developer diagnostic: shader cycles per phase, summed over workgroups (thread 0 of each)
         unsigned long long* d = nullptr;
-        HIP_TRY(hipMalloc((void**)&d, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&d, 32 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d, 0, 32 * sizeof(unsigned long long)));
         icv::KParams K2 = K;
         K2.dbg = d;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K2);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, K2);
         HIP_TRY(hipStreamSynchronize(st));
-        unsigned long long h[8];
+        unsigned long long h[32];
         HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+        if (block == icv::SPT) {  // k_smooth_sp (-DICV_SP_PROFILE): work / wait cycles per segment and half
+            std::fprintf(stderr, "[icv sp profile] cycles per cell: segment, producer work / wait, consumer work / wait\n");
+            for (int i = 0; i < 5; ++i)
+                std::fprintf(stderr, "  seg %d  P %8.0f / %8.0f   C %8.0f / %8.0f\n", i, (double)h[i] / (double)K.n_rows,
+                             (double)h[5 + i] / (double)K.n_rows, (double)h[10 + i] / (double)K.n_rows,
+                             (double)h[15 + i] / (double)K.n_rows);
+        }
         (void)hipFree(d);
         const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
                                 "M1 pivot search"};
@@ -193,7 +202,7 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
                      (double)h[6] / (double)K.n_rows, (double)h[7] / (double)K.n_rows);
         return ICV_OK;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(icv::NT), lds, st, K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, K);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }
@@ -263,7 +272,22 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     int64_t grid = (int64_t)pl->n_cu * per_cu;
     if (grid > K.n_rows) grid = K.n_rows;
     if (grid < 1) return ICV_OK;
-    int rc = run_kernel(kern, grid, p.fast_lds, K, st);
+    int rc;
+    // ICV_SP=1 (experimental, see icv_kernel_sp.hpp): dense, window 100 / step 10 geometry, one reference row:
+    // the split producer / consumer kernel, one 1024-thread workgroup per CU
+    const bool use_sp = use_ws && !csr && p.sp_ok && p.B == 10 && p.window == 100 && !K.bounded &&
+                        (p.NB + icv::kThreads - 1) / icv::kThreads <= 4 && std::getenv("ICV_SP");
+    if (use_sp) {
+        icv::KParams S = K;
+        S.win_off = p.sp_s01_off;
+        S.hist_off = p.sp_hist_off;
+        S.scratch_off = p.sp_scratch_off;
+        int64_t gsp = pl->n_cu;
+        if (gsp > K.n_rows) gsp = K.n_rows;
+        rc = run_kernel(icv::k_smooth_sp<icv::kFastUMax, 4, 10, 10>, gsp, p.sp_lds, S, st, icv::SPT);
+    } else {
+        rc = run_kernel(kern, grid, p.fast_lds, K, st);
+    }
     if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
     if (rc || !use_ws) return rc;
     // cells whose median bins held more than 64 windows: recompute them with the generic kernel

@@ -56,6 +56,9 @@ struct Plan {
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
     bool ws_ok = false;              // ... and the wave-specialised k_smooth_ws
     int fast_lds = 0, fast_scratch_off = 0, ws_win_off = 0, ws_hist_off = 0;
+    // k_smooth_sp (one 1024-thread workgroup per CU): row | {S0,S1} | histogram | scratch, nothing aliased
+    bool sp_ok = false;
+    int sp_s01_off = 0, sp_hist_off = 0, sp_scratch_off = 0, sp_lds = 0;
     Layout lay32, lay64;
 };
 
@@ -220,6 +223,11 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
                   p.W <= kThreads * 4;
         for (int g = 0; g < n_cols_all; ++g)
             if (p.dst[g] >= 0) p.dst16[g] = (uint16_t)p.dst[g];
+        p.sp_s01_off = round_up((p.Gp + 1) * 4, 16);
+        p.sp_hist_off = p.sp_s01_off + 2 * 16 * p.NB;  // {S0,S1} double buffered
+        p.sp_scratch_off = p.sp_hist_off + 4096 * 2;
+        p.sp_lds = p.sp_scratch_off + kFastScratchBytes;
+        p.sp_ok = p.ws_ok && p.sp_lds <= kLdsLimit && p.NB <= kThreads * 4 && p.W <= kThreads * 4;
     }
     return "";
 }

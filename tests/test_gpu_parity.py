@@ -361,7 +361,7 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
     from infercnvpy_amd._plan import GenePlan
 
     def run(plan, dm, ref, env):
-        for k in ("ICV_FORCE_GENERIC", "ICV_NO_WS"):
+        for k in ("ICV_FORCE_GENERIC", "ICV_NO_WS", "ICV_SP"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -386,7 +386,10 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm = _engine.DeviceMatrix(dense=X)
         gen = run(plan, dm, ref, ["ICV_FORCE_GENERIC"])
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
-        for env, mat in (([], dm), (["ICV_NO_WS"], dm), ([], dm_csr), (["ICV_FORCE_GENERIC"], dm_csr)):
+        # default k_smooth_ws, previous generation k_smooth_fast, experimental split kernel k_smooth_sp
+        # (window 100 / step 10 geometry only, otherwise the default runs), prepared-entry CSR, generic CSR
+        for env, mat in (([], dm), (["ICV_NO_WS"], dm), (["ICV_SP"], dm), ([], dm_csr),
+                         (["ICV_FORCE_GENERIC"], dm_csr)):
             fast = run(plan, mat, ref, env)
             for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median)):
                 assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)), env
