@@ -208,7 +208,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 in / f64 accumulate",
+        "dtype": "f64",  # arithmetic type from the block sums on (np.convolve is float64); I/O is float32
         "data": "synthetic",
         "config": {
             "workload": ("BASELINE config 2: dense fp32" if args.format == "dense" else
@@ -217,6 +217,7 @@ def main():
                         f"window {args.window}, step {args.step}, chunksize {args.chunksize}, lfc_clip 3, "
                         f"dynamic_threshold 1.5, reference = all-cell mean"
                         + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)"),
+            "io_dtype": "f32 matrix in, f32 x_res out",
             "cells_total": cells_total,
             "n_windows": W,
             "parallelism": f"row shards x{n_gpus}, all-reduce of the [G] float64 reference sums only",
