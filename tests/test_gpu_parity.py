@@ -719,3 +719,92 @@ def test_distance_row_blocks_and_single_process_sharded_driver():
     import infercnvpy_amd as cnv
 
     np.testing.assert_array_equal(Z, cnv.tl.ward_linkage(X))
+
+
+# --------------------------------------------------------------------------- #
+# randomized sweep over geometries / dtypes / formats / reference kinds, and the multi-slab driver
+# --------------------------------------------------------------------------- #
+def _sweep_case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    n_chr = rng.randint(2, 8)
+    sizes = [int(rng.choice([5, 17, 40, 99, 100, 101, 180, 333])) for _ in range(n_chr)]
+    names = [f"chr{i}" for i in rng.choice(np.arange(1, 23), size=n_chr, replace=False)]
+    extra = [("chrX", int(rng.randint(3, 40))), ("chrM", 4), (None, int(rng.randint(1, 6)))][: rng.randint(0, 4)]
+    v = cases.synthetic_var(sizes, names=names, extra=tuple(extra), seed_start=seed, seed_perm=seed + 1)
+    G = len(v["names"])
+    n_obs = int(rng.randint(25, 140))
+    kind = rng.choice(["f32", "f64", "int"])
+    if kind == "int":
+        X = rng.poisson(1.3, size=(n_obs, G)).astype(np.int64)
+    else:
+        X = cases.synthetic_expr(n_obs, G, seed=seed + 7, dtype=np.float32 if kind == "f32" else np.float64)
+    fmt = rng.choice(["dense", "csr", "csc"])
+    labels = rng.choice(["a", "b", "c"], size=n_obs)
+    labels[:3] = ["a", "b", "c"]
+    kw = dict(window_size=int(rng.choice([4, 6, 10, 20, 50, 100, 101])), step=int(rng.choice([1, 2, 5, 10])),
+              lfc_clip=float(rng.choice([0.5, 1.0, 3.0])), chunksize=int(rng.choice([7, 32, 5000])),
+              dynamic_threshold=[None, 0.5, 1.5][rng.randint(0, 3)],
+              exclude_chromosomes=[("chrX", "chrY"), None, (names[0],)][rng.randint(0, 3)])
+    ref_kind = rng.choice(["none", "array", "cat1", "cat2"])
+    return v, X, fmt, labels, kw, ref_kind, rng
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sweep_public_api_against_oracle(seed):
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v, X, fmt, labels, kw, ref_kind, rng = _sweep_case(seed)
+    Xin = {"dense": X, "csr": sp.csr_matrix(X), "csc": sp.csc_matrix(X)}[fmt]
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    ad = SimpleAnnData(Xin, obs=pd.DataFrame({"group": labels}), var=var)
+    mean_dtype = np.float32 if X.dtype == np.float32 else np.float64
+    api = dict(kw)
+    if ref_kind == "array":
+        ref = (X.mean(axis=0) + rng.normal(0, 0.05, X.shape[1])).astype(mean_dtype)
+        api["reference"] = ref
+    elif ref_kind == "none":
+        ref = (X.sum(axis=0, dtype=np.float64) / X.shape[0]).astype(mean_dtype)  # correctly rounded mean
+    else:
+        cats = ["a"] if ref_kind == "cat1" else ["b", "c"]
+        api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
+        ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in cats]).astype(
+            mean_dtype)
+    chr_pos, res, _ = cnv.tl.infercnv(ad, inplace=False, **api)
+    e_pos, e_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, **kw)
+    assert {k: int(p) for k, p in chr_pos.items()} == {k: int(p) for k, p in e_pos.items()}
+    got, exp = res.toarray(), e_res.toarray()
+    assert got.shape == exp.shape
+    np.testing.assert_array_equal(got == 0, exp == 0)
+    np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_public_api_multi_slab_equals_single_slab(fmt, monkeypatch):
+    """Matrices larger than the HBM budget are processed in row slabs (multiples of chunksize): the
+    reference means are accumulated over the slabs and the result must equal the single-slab run."""
+    import torch
+
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+
+    v = cases.synthetic_var([300, 120, 101, 60])
+    X = cases.synthetic_expr(230, len(v["names"]), seed=5)
+    labels = np.array(["n1"] * 40 + ["n2"] * 30 + ["t"] * 160)[np.random.RandomState(2).permutation(230)]
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+
+    def run(**kw):
+        ad = SimpleAnnData(sp.csr_matrix(X) if fmt == "csr" else X, obs=pd.DataFrame({"group": labels}), var=var)
+        return cnv.tl.infercnv(ad, inplace=False, chunksize=50, **kw)
+
+    variants = (dict(), dict(reference_key="group", reference_cat=["n1", "n2"]), dict(calculate_gene_values=True))
+    single = [run(**kw) for kw in variants]
+    real = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (200_000, real()[1]))  # ~1 chunk per slab
+    for kw, (pos1, res1, gv1) in zip(variants, single):
+        pos, res, gv = run(**kw)
+        assert pos == pos1
+        np.testing.assert_array_equal(res.toarray(), res1.toarray())
+        if gv1 is not None:
+            np.testing.assert_array_equal(gv, gv1)
