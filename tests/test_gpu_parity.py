@@ -808,3 +808,19 @@ def test_public_api_multi_slab_equals_single_slab(fmt, monkeypatch):
         np.testing.assert_array_equal(res.toarray(), res1.toarray())
         if gv1 is not None:
             np.testing.assert_array_equal(gv, gv1)
+
+
+def test_np_matrix_input():
+    """`np.matrix` input (what sparse - dense arithmetic yields; reference `_ensure_array`, _util.py:4-9)."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+
+    v = cases.synthetic_var([120, 60])
+    X = cases.synthetic_expr(40, len(v["names"]), seed=3)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    ref = X.mean(axis=0)
+    a = cnv.tl.infercnv(SimpleAnnData(X, var=var), reference=ref, window_size=20, step=5, inplace=False)
+    b = cnv.tl.infercnv(SimpleAnnData(np.matrix(X), var=var), reference=np.matrix(ref), window_size=20, step=5,
+                        inplace=False)
+    assert a[0] == b[0]
+    np.testing.assert_array_equal(a[1].toarray(), b[1].toarray())
