@@ -802,7 +802,7 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
         ~Guard() { (void)hipFree(b); }
     } guard{buf};
     const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
-    HIP_TRY(hipMalloc((void**)&buf, arr * 15 + 256));
+    HIP_TRY(hipMalloc((void**)&buf, arr * 19 + 256));
     int* live = (int*)(buf + arr * 0);
     int* role = (int*)(buf + arr * 1);
     float* pair_d = (float*)(buf + arr * 2);
@@ -818,6 +818,7 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
     icv::WardCounts* counts = (icv::WardCounts*)(buf + arr * 12);
     int* cstate = (int*)(buf + arr * 13);
     unsigned char* qmask = (unsigned char*)(buf + arr * 14);
+    int4* mdesc = (int4*)(buf + arr * 15);  // n x 16 bytes: one packed descriptor per merge
     hipLaunchKernelGGL(icv::k_ward_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ni, live, role, cstate,
                        qmask, size_old, size_new, alive, counts);
     const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist_sq) & 15) == 0);
@@ -825,12 +826,13 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
     while (n_live > 1) {
         if (vec_ok && (int64_t)n_live * 4 >= n)  // most columns alive: contiguous vector loads over all columns
             hipLaunchKernelGGL(icv::k_ward_round_dense, dim3((unsigned)n_live), dim3(256), 0, st, dist_sq, ld, ni, live,
-                               cstate, qmask, log_i + merged_begin, merged_count, pair_d, size_old, size_new, nn, dmin);
+                               cstate, qmask, mdesc + merged_begin, log_d + merged_begin, merged_count, pair_d, size_old, size_new,
+                               nn, dmin);
         else
             hipLaunchKernelGGL(icv::k_ward_round, dim3((unsigned)n_live), dim3(256), 0, st, dist_sq, ld, live, n_live,
                                role, pair_d, size_old, size_new, nn, dmin);
-        hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, ni, live, role, cstate, qmask, pair_d,
-                           size_old, size_new, alive, nn, dmin, log_i, log_j, log_d, log_size, counts);
+        hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, ni, live, role, cstate, qmask, mdesc,
+                           pair_d, size_old, size_new, alive, nn, dmin, log_i, log_j, log_d, log_size, counts);
         icv::WardCounts h;
         HIP_TRY(hipMemcpyAsync(&h, counts, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

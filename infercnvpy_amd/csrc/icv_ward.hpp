@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(256) k_ward_round(float* D, int64_t ld, const 
 // cstate[c] = -2 dead, -1 unchanged, >= 0 the slot column c absorbed.
 __global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, int n, const int* live,
                                                           const int* cstate, const unsigned char* qmask,
-                                                          const int* merged, int n_merged, const float* pair_d,
-                                                          const int* size_old, const int* size_new, int* nn,
-                                                          float* dmin) {
+                                                          const int4* mdesc, const float* mdist, int n_merged,
+                                                          const float* pair_d, const int* size_old,
+                                                          const int* size_new, int* nn, float* dmin) {
     const int r = live[blockIdx.x];
     WardRow R;
     R.r = r;
@@ -216,27 +216,66 @@ __global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, 
             quad(q + 768, d3, m3);
         }
         for (; q < n4; q += 256) quad(q, Dr4[q], qmask[q]);
-        // columns that merged in the previous round (Lance-Williams on this row's two entries)
-        for (int idx = threadIdx.x; idx < n_merged; idx += 256) {
-            const int c = merged[idx], cl = cstate[c];
-            const float v = ward_lw(Dr[c], Dr[cl], pair_d[c], size_old[c], size_old[cl], R.sn_r);
-            Dr[c] = v;
-            if (v < best || (v == best && c < best_c)) {
+        // columns that merged in the previous round (Lance-Williams on this row's two entries).  The round's
+        // merges are packed as {column, absorbed column, their sizes} + distance, so that the only dependent
+        // accesses are the two gathers from this row; two merges per thread are in flight.
+        auto merged_col = [&](const int4& m, float pd, float drc, float drl) {
+            const float v = ward_lw(drc, drl, pd, m.z, m.w, R.sn_r);
+            Dr[m.x] = v;
+            if (v < best || (v == best && m.x < best_c)) {
                 best = v;
-                best_c = c;
+                best_c = m.x;
             }
+        };
+        int idx = threadIdx.x;
+        for (; idx + 256 < n_merged; idx += 512) {
+            const int4 ma = mdesc[idx], mb = mdesc[idx + 256];
+            const float pa = mdist[idx], pb = mdist[idx + 256];
+            const float a0 = Dr[ma.x], a1 = Dr[ma.y], b0 = Dr[mb.x], b1 = Dr[mb.y];
+            merged_col(ma, pa, a0, a1);
+            merged_col(mb, pb, b0, b1);
+        }
+        for (; idx < n_merged; idx += 256) {
+            const int4 ma = mdesc[idx];
+            merged_col(ma, mdist[idx], Dr[ma.x], Dr[ma.y]);
         }
     } else {
-        for (int c = threadIdx.x; c < n; c += 256) {
-            const int cl = cstate[c];
-            if (cl == -2 || c == r) continue;
-            bool changed;
-            const float v = ward_entry(R, c, cl, Dr[c], pair_d, size_old, size_new, changed);
-            Dr[c] = v;
+        // a row that merged: every live column is updated.  Vector loads of both rows, the column states and
+        // the column sizes; only columns that merged as well need gathers.
+        const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
+        const float4* Dj4 = reinterpret_cast<const float4*>(R.Dj);
+        const int4* cs4 = reinterpret_cast<const int4*>(cstate);
+        const int4* so4 = reinterpret_cast<const int4*>(size_old);
+        const int nq = n >> 2;
+        auto elem = [&](int c, int cl, float drc, float djc, int so_c, float& out) {
+            if (cl == -2 || c == r) return;
+            float v;
+            if (cl < 0) {
+                v = ward_lw(drc, djc, R.pdr, R.so_r, R.so_j, so_c);
+            } else {
+                bool changed;
+                v = ward_entry(R, c, cl, drc, pair_d, size_old, size_new, changed);
+            }
+            out = v;
             if (v < best) {
                 best = v;
                 best_c = c;
             }
+        };
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const float4 d = Dr4[q], e = Dj4[q];
+            const int4 cs = cs4[q], so = so4[q];
+            float4 o = d;
+            elem(4 * q, cs.x, d.x, e.x, so.x, o.x);
+            elem(4 * q + 1, cs.y, d.y, e.y, so.y, o.y);
+            elem(4 * q + 2, cs.z, d.z, e.z, so.z, o.z);
+            elem(4 * q + 3, cs.w, d.w, e.w, so.w, o.w);
+            reinterpret_cast<float4*>(Dr)[q] = o;
+        }
+        for (int c = 4 * nq + threadIdx.x; c < n; c += 256) {
+            float o = Dr[c];
+            elem(c, cstate[c], o, R.Dj[c], size_old[c], o);
+            Dr[c] = o;
         }
     }
     ward_argmin_publish(best, best_c, r, nn, dmin);
@@ -245,7 +284,7 @@ __global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, 
 // Single workgroup (1024 threads).  Finalises the previous round's bookkeeping, detects the reciprocal
 // nearest-neighbour pairs of this round in ascending slot order, logs them and compacts the live list.
 __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role, int* cstate, unsigned char* qmask,
-                                                     float* pair_d,
+                                                     int4* mdesc, float* pair_d,
                                                      int* size_old, int* size_new, unsigned char* alive, const int* nn,
                                                      const float* dmin, int* log_i, int* log_j, float* log_d,
                                                      int* log_size, WardCounts* counts) {
@@ -294,6 +333,7 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
             log_j[m0 + p] = c;
             log_d[m0 + p] = dmin[r];
             log_size[m0 + p] = sz;
+            mdesc[m0 + p] = make_int4(r, c, size_old[r], size_old[c]);
             role[r] = c;
             cstate[r] = c;
             cstate[c] = -2;
