@@ -227,9 +227,11 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         const bool u10 = (p.B == 10 && p.window == 100);
         if (!csr) {
             if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, false> : icv::k_smooth_ws<U, 4, 4, 0, 0, false>;
+            else if (p.B == 5 && p.window == 250) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, false>;
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, false> : icv::k_smooth_ws<U, 8, 4, 0, 0, false>;
         } else {
             if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
+            else if (p.B == 5 && p.window == 250) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
             // zero row + prepared entries {LDS position, centred and clipped value}
             const int nz = (int)pl->zrow_elems;

@@ -494,30 +494,30 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     double v;
                     if constexpr (BT > 0 && NBW > 0) {
                         if (ln == NBW * BT) {
-                            // same operation order as window_from_blocks; two half-windows so that only
-                            // 5 x ds_read_b128 results are live at a time (register budget)
-                            constexpr int HB = NBW > 0 ? NBW / 2 : 1;
+                            // same operation order as window_from_blocks, fully unrolled in batches of five
+                            // {S0,S1} pairs (only 5 x ds_read_b128 results live at a time: register budget)
+                            constexpr int HB = NBW / 2, CH = 5;
                             v = 0.0;
-                            {
-                                double2 sb[HB];
 #pragma unroll
-                                for (int m = 0; m < HB; ++m) sb[m] = sp[m];
+                            for (int m0 = 0; m0 < NBW; m0 += CH) {
+                                double2 sb[CH];
 #pragma unroll
-                                for (int m = 0; m < HB; ++m) {
-                                    v = fma((double)(m * BT + 1), sb[m].x, v);
-                                    v = v + sb[m].y;
+                                for (int u = 0; u < CH; ++u)
+                                    if (m0 + u < NBW) sb[u] = sp[m0 + u];
+#pragma unroll
+                                for (int u = 0; u < CH; ++u) {
+                                    const int m = m0 + u;
+                                    if (m < NBW) {
+                                        if (m < HB) {
+                                            v = fma((double)(m * BT + 1), sb[u].x, v);
+                                            v = v + sb[u].y;
+                                        } else {
+                                            v = fma((double)(NBW * BT - m * BT), sb[u].x, v);
+                                            v = v - sb[u].y;
+                                        }
+                                    }
                                 }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            {
-                                double2 sb[HB];
-#pragma unroll
-                                for (int m = 0; m < HB; ++m) sb[m] = sp[HB + m];
-#pragma unroll
-                                for (int m = 0; m < HB; ++m) {
-                                    v = fma((double)(NBW * BT - (HB + m) * BT), sb[m].x, v);
-                                    v = v - sb[m].y;
-                                }
+                                __builtin_amdgcn_sched_barrier(0);
                             }
                         } else {
                             v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
