@@ -53,6 +53,8 @@ struct icv_plan_s {
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
+    double* d_cell_part = nullptr;  // per-wavefront partial moments of the ws / sp kernels
+    int64_t cell_part_cap = 0;
     uint16_t* d_dst16 = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
@@ -186,6 +188,8 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
                 std::fprintf(stderr, "  seg %d  P %8.0f / %8.0f   C %8.0f / %8.0f\n", i, (double)h[i] / (double)K.n_rows,
                              (double)h[5 + i] / (double)K.n_rows, (double)h[10 + i] / (double)K.n_rows,
                              (double)h[15 + i] / (double)K.n_rows);
+            std::fprintf(stderr, "  consumer A0 detail: moments %8.0f  histogram %8.0f\n", (double)h[20] / (double)K.n_rows,
+                         (double)h[21] / (double)K.n_rows);
         }
         (void)hipFree(d);
         const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
@@ -258,6 +262,13 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             HIP_TRY(hipMalloc((void**)&pl->d_row_list, (size_t)K.n_rows * sizeof(int64_t)));
             pl->row_list_cap = K.n_rows;
         }
+        if (pl->cell_part_cap < K.n_rows) {
+            (void)hipFree(pl->d_cell_part);
+            pl->d_cell_part = nullptr;
+            HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 16 * sizeof(double)));
+            pl->cell_part_cap = K.n_rows;
+        }
+        K.cell_part = pl->d_cell_part;
         if (!pl->d_row_count) HIP_TRY(hipMalloc((void**)&pl->d_row_count, sizeof(int)));
         HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
         K.row_list = pl->d_row_list;
@@ -292,6 +303,9 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     }
     if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
     if (rc || !use_ws) return rc;
+    // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)
+    hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
+                       K.n_rows, K.cell_stats);
     // cells whose median bins held more than 64 windows: recompute them with the generic kernel
     // (reads the device-side count; exits at once when the list is empty)
     icv::KParams G = K;
@@ -421,6 +435,7 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_cov_cnt);
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
+        (void)hipFree(pl->d_cell_part);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_zrow);
     }

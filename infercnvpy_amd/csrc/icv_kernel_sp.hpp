@@ -206,8 +206,6 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
         unsigned wbin[2] = {0u, 0u};
 #pragma unroll
         for (int i = 0; i < MAXW; ++i) wv[i] = 0.0;
-        double med_prev = 0.0;  // median / mode of the cell whose moments are still to be written (seg A0)
-        int mode_prev = 2;
         __syncthreads();  // initialisation visible
         for (int64_t it = 0; it < n_mine + 2; ++it) {
             const bool have_med = it >= 2;                     // cell it-2: its median is found in A0..A2
@@ -216,18 +214,13 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
             int tl = tg;
             asm volatile("" : "+v"(tl));
             // ---- seg A0: moments of cell it-3 to HBM; histogram of cell it-2 --------------------------------
-            if (it >= 3 && tl == 0 && mode_prev != 2) {
-                const int64_t pc = mcell - gridDim.x;
-                double s = 0.0, q = 0.0;
-#pragma unroll
-                for (int i = 0; i < NWAVE; ++i) {
-                    s += sc->psum[i];
-                    q += sc->psq[i];
-                }
-                P.cell_stats[2 * pc] = s;
-                P.cell_stats[2 * pc + 1] = q;
-                P.cell_median[pc] = med_prev;
-            }
+#ifdef ICV_SP_PROFILE
+            const unsigned long long f0_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef ICV_SP_PROFILE
+            const unsigned long long f1_ = __builtin_amdgcn_s_memtime();
+            if (P.dbg && t == SPH) atomicAdd(P.dbg + 20, f1_ - f0_);
+#endif
             if (have_med) {
                 int lnan = 0;
 #pragma unroll
@@ -243,6 +236,12 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
                 if (lnan) sc->nanflag = 1;  // benign race: every writer stores 1
                 if (tl == 0) sc->ncand = 0;
             }
+#ifdef ICV_SP_PROFILE
+            {
+                const unsigned long long f2_ = __builtin_amdgcn_s_memtime();
+                if (P.dbg && t == SPH) atomicAdd(P.dbg + 21, f2_ - f1_);
+            }
+#endif
             SP_BAR(0)
             // ---- seg A1: EVERY consumer wavefront scans the whole histogram (no publish step, no barrier
             //      between scan and gather), then the windows in the two median bins go to cand[] ----------
@@ -333,8 +332,6 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
                 double med = (k1 == k2) ? sc->ma : (sc->ma + sc->mb) / 2.0;
                 if (mode == 1) med = __builtin_nan("");  // a NaN window: the whole cell is NaN
                 if (mode == 2) med = 0.0;
-                med_prev = med;
-                mode_prev = mode;
                 double sum = 0.0, sq = 0.0;
                 float* orow = P.out + mcell * P.ldo;
 #pragma unroll
@@ -349,10 +346,9 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
                 }
                 sum = wave_sum_dpp(sum);
                 sq = wave_sum_dpp(sq);
-                if ((tl & 63) == 0) {
-                    sc->psum[tl >> 6] = sum;
-                    sc->psq[tl >> 6] = sq;
-                }
+                if ((tl & 63) == 0)  // this wavefront's share of the cell's moments, straight to HBM
+                    reinterpret_cast<double2*>(P.cell_part)[mcell * NWAVE + (tl >> 6)] = make_double2(sum, sq);
+                if (tl == 0) P.cell_median[mcell] = med;
             }
             if (have_win) {
                 const double2* S2 = reinterpret_cast<const double2*>(S01 + (size_t)((it - 1) & 1) * 2 * NB);
@@ -440,19 +436,6 @@ __global__ void __launch_bounds__(SPT) k_smooth_sp(const KParams P) {
                 }
             }
             SP_BAR(3)
-        }
-        // moments of the last cell
-        if (n_mine >= 1 && tg == 0 && mode_prev != 2) {
-            const int64_t pc = (int64_t)blockIdx.x + (n_mine - 1) * gridDim.x;
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < NWAVE; ++i) {
-                s += sc->psum[i];
-                q += sc->psq[i];
-            }
-            P.cell_stats[2 * pc] = s;
-            P.cell_stats[2 * pc + 1] = q;
-            P.cell_median[pc] = med_prev;
         }
 #ifdef ICV_SP_PROFILE
         if (P.dbg && t == SPH)

@@ -455,12 +455,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         __syncthreads();  // B3: {S0,S1} ready, histogram cleared, median of the previous cell published
         ICV_PHASE(4)
         asm volatile("" : "+v"(tl));
-        double med = 0.0;    // kept in registers for the write-out after B4: by then wavefront 0 may
-        int prev_mode = 1;   // already be publishing the next cell's state in the same LDS words
         if (have_prev) {
-            // x_res of the previous cell from the windows still in registers
-            med = (k1 == k2) ? sc->ma : (sc->ma + sc->mb) / 2.0;
-            prev_mode = sc->mode;
+            // x_res of the previous cell from the windows still in registers (a cell that was handed back gets
+            // med = 0 here and is rewritten, with its median and moments, by k_smooth afterwards)
+            const double med = (k1 == k2) ? sc->ma : (sc->ma + sc->mb) / 2.0;
             double sum = 0.0, sq = 0.0;
             float* orow = P.out + pcell * P.ldo;
 #pragma unroll
@@ -475,10 +473,9 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
             sum = wave_sum_dpp(sum);
             sq = wave_sum_dpp(sq);
-            if ((tl & 63) == 0) {
-                sc->psum[tl >> 6] = sum;
-                sc->psq[tl >> 6] = sq;
-            }
+            if ((tl & 63) == 0)  // this wavefront's share of the cell's moments, straight to HBM
+                reinterpret_cast<double2*>(P.cell_part)[pcell * NWAVE + (tl >> 6)] = make_double2(sum, sq);
+            if (tl == 0) P.cell_median[pcell] = med;
         }
         // ---------------- W: windows (registers) + histogram --------------------------------------
         if (more) {
@@ -547,17 +544,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         __syncthreads();  // B4: histogram complete; moments of the previous cell complete
         ICV_PHASE(5)
-        if (have_prev && tl == 64 && prev_mode != 2) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < NWAVE; ++i) {
-                s += sc->psum[i];
-                q += sc->psq[i];
-            }
-            P.cell_stats[2 * pcell] = s;
-            P.cell_stats[2 * pcell + 1] = q;
-            P.cell_median[pcell] = med;
-        }
     }
 #ifdef ICV_WS_PROFILE
     if (P.dbg && t == 64)

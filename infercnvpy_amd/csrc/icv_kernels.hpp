@@ -69,6 +69,10 @@ struct KParams {
     int64_t* row_list;
     int* row_count;
     double* win_out;  // k_smooth only (optional): float64 smoothed windows before centring, n_rows x W
+    // k_smooth_ws / k_smooth_sp: per-wavefront partial moments, n_rows x 8 x {sum, sum of squares}; lane 0 of every
+    // wavefront stores its pair straight to HBM (no LDS round trip, no single-thread reduction on the per-cell
+    // critical path) and k_stats_finish adds the eight pairs in a fixed order
+    double* cell_part;
 };
 
 struct Scratch {
@@ -1155,6 +1159,22 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
             if (fabs(yd) < th) orow[j] = 0.0f;
         }
     }
+}
+
+// cell_stats[c] = sum over the 8 per-wavefront partial moment pairs of cell c, fixed order (deterministic)
+__global__ void __launch_bounds__(256) k_stats_finish(const double* part, int64_t n_rows, double* cell_stats) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_rows) return;
+    const double2* p = reinterpret_cast<const double2*>(part) + c * 8;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const double2 v = p[w];
+        s += v.x;
+        q += v.y;
+    }
+    cell_stats[2 * c] = s;
+    cell_stats[2 * c + 1] = q;
 }
 
 // ---------------------------------------------------------------------------------------
