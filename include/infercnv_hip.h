@@ -157,6 +157,14 @@ int icv_infercnv_run(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, c
                      int32_t flags, float *out, int64_t ldo, double *cell_median, double *cell_stats,
                      double *thr, icv_profile *h_profile, void *stream);
 
+/* Deferred timing for back-to-back runs: after icv_profile_begin every icv_infercnv_run on this plan (called
+ * with h_profile == NULL) records HIP events around its stages on its stream WITHOUT synchronising;
+ * icv_profile_collect waits for the recorded runs, fills up to max_records structs in call order, returns the
+ * count and ends the deferred mode.  (bench.py: kernel time measured over the timed region with no host
+ * synchronisation between steps.) */
+int icv_profile_begin(icv_plan_t plan);
+int icv_profile_collect(icv_plan_t plan, icv_profile *out, int32_t max_records, int32_t *n_records);
+
 /* ---- calculate_gene_values=True (reference :247-298, :443-453) -------------------------------
  * Per-gene CNV values: mean of the kept windows that contain the gene, minus the per-cell median
  * over the covered genes, zeroed below the chunk's noise threshold (`thr` from

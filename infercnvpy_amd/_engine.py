@@ -245,3 +245,16 @@ def ward_linkage(dist_sq):
     _lib.check(lib.icv_ward_linkage(_ptr(dist_sq), n, dist_sq.stride(0), Z.ctypes.data, C.byref(rounds),
                                     _stream_ptr(torch)))
     return Z, int(rounds.value)
+
+
+def profile_begin(plan: GenePlan):
+    """Start deferred timing: later run_hot_path calls on this plan record HIP events without synchronising."""
+    _lib.check(_lib.load().icv_profile_begin(plan.handle))
+
+
+def profile_collect(plan: GenePlan, max_records=4096):
+    """End deferred timing; returns the list of _lib.Profile records of the runs since profile_begin."""
+    arr = (_lib.Profile * max_records)()
+    n = C.c_int32(0)
+    _lib.check(_lib.load().icv_profile_collect(plan.handle, arr, max_records, C.byref(n)))
+    return [arr[i] for i in range(n.value)]

@@ -24,6 +24,7 @@ ICV_FLAG_ROUND_F32 = 2
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
+    "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_row_abs_sum", "icv_last_error", "icv_version",
     "icv_device_count",
@@ -81,6 +82,8 @@ def load():
     lib.icv_apply_threshold.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp]
     lib.icv_infercnv_run.argtypes = [vp, P(Matrix), vp, vp, dbl, dbl, i64, i64, i32, vp, i64, vp, vp, vp,
                                      P(Profile), vp]
+    lib.icv_profile_begin.argtypes = [vp]
+    lib.icv_profile_collect.argtypes = [vp, P(Profile), i32, P(i32)]
     lib.icv_gene_values.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, i64, vp, i64, vp]
     lib.icv_csr_count.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_csr_fill.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp]

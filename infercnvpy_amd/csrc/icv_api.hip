@@ -53,6 +53,9 @@ struct icv_plan_s {
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
+    // deferred profiling (icv_profile_begin / icv_profile_collect): event quadruples of the runs since begin
+    bool prof_deferred = false;
+    std::vector<hipEvent_t> prof_events;
     double* d_cell_part = nullptr;  // per-wavefront partial moments of the ws / sp kernels
     int64_t cell_part_cap = 0;
     uint16_t* d_dst16 = nullptr;
@@ -585,21 +588,25 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
         return rc;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (prof) {
+    const bool deferred = !prof && pl->prof_deferred;
+    const bool timed = prof || deferred;
+    if (timed) {
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     if ((rc = launch_smooth(pl, m, K, *lay, st))) return rc;
-    if (prof) HIP_TRY(hipEventRecord(ev[1], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[1], st));
     if (do_thr) {
         rc = icv_chunk_thresholds(cell_stats, m->n_rows, chunksize, row_phase, pl->p.W, dynamic_threshold, thr,
                                   stream);
         if (rc) return rc;
     }
-    if (prof) HIP_TRY(hipEventRecord(ev[2], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], st));
     if (do_thr && (rc = launch_apply(m, K, thr, chunksize, row_phase, st))) return rc;
-    if (prof) {
-        HIP_TRY(hipEventRecord(ev[3], st));
+    if (timed) HIP_TRY(hipEventRecord(ev[3], st));
+    if (deferred) {  // no synchronisation here: the times are read by icv_profile_collect
+        for (auto& e : ev) pl->prof_events.push_back(e);
+    } else if (prof) {
         HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&prof->smooth_ms, ev[0], ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->thresholds_ms, ev[1], ev[2]));
@@ -607,6 +614,36 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         HIP_TRY(hipEventElapsedTime(&prof->total_ms, ev[0], ev[3]));
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
+    return ICV_OK;
+}
+
+int icv_profile_begin(icv_plan_t pl) {
+    if (!pl) return fail(ICV_ERR_INVALID, "null plan");
+    for (auto& e : pl->prof_events) (void)hipEventDestroy(e);
+    pl->prof_events.clear();
+    pl->prof_deferred = true;
+    return ICV_OK;
+}
+
+int icv_profile_collect(icv_plan_t pl, icv_profile* out, int32_t max_records, int32_t* n_records) {
+    if (!pl || !n_records || (max_records > 0 && !out)) return fail(ICV_ERR_INVALID, "bad profile_collect arguments");
+    const int n = (int)(pl->prof_events.size() / 4);
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t* ev = pl->prof_events.data() + 4 * i;
+        if (k < max_records) {
+            HIP_TRY(hipEventSynchronize(ev[3]));
+            HIP_TRY(hipEventElapsedTime(&out[k].smooth_ms, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&out[k].thresholds_ms, ev[1], ev[2]));
+            HIP_TRY(hipEventElapsedTime(&out[k].apply_ms, ev[2], ev[3]));
+            HIP_TRY(hipEventElapsedTime(&out[k].total_ms, ev[0], ev[3]));
+            ++k;
+        }
+    }
+    for (auto& e : pl->prof_events) (void)hipEventDestroy(e);
+    pl->prof_events.clear();
+    pl->prof_deferred = false;
+    *n_records = k;
     return ICV_OK;
 }
 
