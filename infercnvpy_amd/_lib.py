@@ -67,6 +67,12 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m infercnvpy_amd._build` "
             "(hipcc --offload-arch=gfx950).  infercnvpy_amd has no CPU fallback."
         )
+    # PyTorch ships its own copy of the HIP runtime (same SONAME as /opt/rocm's): it has to be the one the
+    # process loads first, otherwise this library pulls in the system copy, torch is bound to it as well, and
+    # device allocations from here fail with hipErrorNoDevice.  torch is a hard dependency (device memory,
+    # streams) anyway.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     i32, i64, vp, dbl = C.c_int32, C.c_int64, C.c_void_p, C.c_double
     P = C.POINTER

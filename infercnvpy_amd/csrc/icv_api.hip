@@ -56,6 +56,8 @@ struct icv_plan_s {
     // deferred profiling (icv_profile_begin / icv_profile_collect): event quadruples of the runs since begin
     bool prof_deferred = false;
     std::vector<hipEvent_t> prof_events;
+    double* d_win_scratch = nullptr;  // Layout::win_global: per-workgroup window lines of k_smooth
+    int64_t win_scratch_cap = 0;
     double* d_cell_part = nullptr;  // per-wavefront partial moments of the ws / sp kernels
     int64_t cell_part_cap = 0;
     uint16_t* d_dst16 = nullptr;
@@ -267,6 +269,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         }
         if (pl->cell_part_cap < K.n_rows) {
             (void)hipFree(pl->d_cell_part);
+        (void)hipFree(pl->d_win_scratch);
             pl->d_cell_part = nullptr;
             HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 16 * sizeof(double)));
             pl->cell_part_cap = K.n_rows;
@@ -350,6 +353,18 @@ int launch_smooth_t(icv_plan_t pl, const icv::KParams& K, const icv::Layout& lay
         const int n = (int)pl->zrow_elems;
         hipLaunchKernelGGL(icv::k_zero_row<T>, dim3((n + 255) / 256), dim3(256), 0, st, K,
                            static_cast<T*>(pl->d_zrow), n);
+    }
+    if (lay.win_global) {
+        const int64_t need = grid * (int64_t)p.W;
+        if (pl->win_scratch_cap < need) {
+            (void)hipFree(pl->d_win_scratch);
+            pl->d_win_scratch = nullptr;
+            HIP_TRY(hipMalloc((void**)&pl->d_win_scratch, (size_t)need * sizeof(double)));
+            pl->win_scratch_cap = need;
+        }
+        icv::KParams K2 = K;
+        K2.win_scratch = pl->d_win_scratch;
+        return run_kernel(kern, grid, lay.total, K2, st);
     }
     return run_kernel(kern, grid, lay.total, K, st);
 }
@@ -439,6 +454,7 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_cell_part);
+        (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_zrow);
     }

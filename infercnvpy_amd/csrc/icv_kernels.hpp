@@ -73,6 +73,8 @@ struct KParams {
     // wavefront stores its pair straight to HBM (no LDS round trip, no single-thread reduction on the per-cell
     // critical path) and k_stats_finish adds the eight pairs in a fixed order
     double* cell_part;
+    // k_smooth, Layout::win_global: gridDim.x lines of W float64 windows in HBM instead of the LDS window array
+    double* win_scratch;
 };
 
 struct Scratch {
@@ -283,7 +285,8 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* row = reinterpret_cast<T*>(smem);
     double* S01 = reinterpret_cast<double*>(smem);
-    double* win = reinterpret_cast<double*>(smem + P.win_off);
+    double* win = P.win_scratch ? P.win_scratch + (int64_t)blockIdx.x * P.W
+                                : reinterpret_cast<double*>(smem + P.win_off);
     Scratch* sc = reinterpret_cast<Scratch*>(smem + P.scratch_off);
 
     using V = typename Vec16<T>::type;

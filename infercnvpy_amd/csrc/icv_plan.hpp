@@ -30,6 +30,9 @@ struct Layout {
     int scratch_off = 0;
     int total = 0;
     bool fits = false;
+    // the float64 window array (8 W bytes) does not fit next to the row: k_smooth keeps it in a per-workgroup
+    // HBM scratch line instead (L2 resident; e.g. 20 000 genes at step 1 = 17 822 windows)
+    bool win_global = false;
 };
 
 struct Plan {
@@ -82,6 +85,18 @@ inline Layout make_layout(const Plan& p, int elem_bytes) {
     l.scratch_off = round_up(data, 16);
     l.total = l.scratch_off + kScratchBytes;
     l.fits = l.total <= kLdsLimit;
+    if (!l.fits) {  // retry without the window array in LDS
+        int data2 = l.row_bytes;
+        if (p.B > 1 && 16 * p.NB > data2) data2 = 16 * p.NB;
+        const int total2 = round_up(data2, 16) + kScratchBytes;
+        if (total2 <= kLdsLimit) {
+            l.win_global = true;
+            l.win_off = 0;  // unused
+            l.scratch_off = round_up(data2, 16);
+            l.total = total2;
+            l.fits = true;
+        }
+    }
     return l;
 }
 

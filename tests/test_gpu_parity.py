@@ -824,3 +824,56 @@ def test_np_matrix_input():
                         inplace=False)
     assert a[0] == b[0]
     np.testing.assert_array_equal(a[1].toarray(), b[1].toarray())
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_many_windows_step1_at_20k_genes(fmt):
+    """20 000 genes at step 1 = 17 822 windows: the float64 window array (142 KB) does not fit LDS next to the
+    row; the generic kernel keeps it in a per-workgroup HBM line instead (config-1 style call on a full gene set)."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    X = cases.synthetic_expr(12, len(v["names"]), seed=77)
+    X[3, 5] = np.nan
+    ref = X[4:].mean(axis=0)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    ad = SimpleAnnData(sp.csr_matrix(X) if fmt == "csr" else X, var=var)
+    chr_pos, res, gv = cnv.tl.infercnv(ad, reference=ref, window_size=100, step=1, chunksize=5, inplace=False,
+                                       calculate_gene_values=(fmt == "dense"))
+    e_pos, e_res, e_gv, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, window_size=100, step=1,
+                                       chunksize=5, calculate_gene_values=(fmt == "dense"))
+    assert res.shape == (12, 17822) and {k: int(p) for k, p in chr_pos.items()} == {k: int(p) for k, p in e_pos.items()}
+    got, exp = res.toarray(), e_res.toarray()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    np.testing.assert_array_equal((got == 0)[ok], (exp == 0)[ok])
+    np.testing.assert_allclose(got[ok], exp[ok], rtol=0, atol=ATOL_TIGHT)
+    if gv is not None:
+        np.testing.assert_allclose(gv, e_gv, rtol=0, atol=1e-9, equal_nan=True)
+
+
+def test_fresh_process_without_importing_torch_first():
+    """Regression: the C ABI library links the HIP runtime by SONAME; PyTorch bundles its own copy under the same
+    SONAME.  If this package's library were loaded before torch, the process would end up on the system copy
+    and device allocations would fail (hipErrorNoDevice).  `_lib.load()` therefore imports torch first; a
+    fresh interpreter that calls the public API straight away must work."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, pandas as pd\n"
+        "import infercnvpy_amd as cnv\n"
+        "from infercnvpy_amd._compat import SimpleAnnData\n"
+        "import cases\n"
+        "v = cases.synthetic_var([120, 60])\n"
+        "X = cases.synthetic_expr(30, len(v['names']), seed=3)\n"
+        "var = pd.DataFrame({'chromosome': v['chromosome'], 'start': v['start'], 'end': v['end']}, index=v['names'])\n"
+        "ad = SimpleAnnData(X, var=var)\n"
+        "cnv.tl.infercnv(ad, window_size=20, step=5)\n"
+        "print('OK', ad.obsm['X_cnv'].shape)\n"
+    ) % (os.path.join(os.path.dirname(__file__), ".."), os.path.join(os.path.dirname(__file__), "golden"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK (30," in out.stdout, out.stderr[-2000:]
