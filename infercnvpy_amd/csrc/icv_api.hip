@@ -63,6 +63,12 @@ struct icv_plan_s {
     uint16_t* d_dst16 = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
+    // Gene sets whose padded row does not fit LDS (float32: > ~40 000 genes, float64: > ~20 000): the
+    // chromosomes are dealt into groups that do fit, each group is a plan of its own (windows only), and the
+    // median / centring run on the float64 windows collected in HBM (smooth_split).
+    std::vector<icv_plan_s*> parts;
+    std::vector<int> part_woff;  // first window of every group in the full window list
+    int parts_elem = 0;          // element size the groups were sized for (0: not built)
 };
 
 namespace {
@@ -116,6 +122,63 @@ int check_matrix(const icv_plan_t pl, const icv_matrix* m) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Chromosome groups whose rows fit LDS at `elem_bytes` per gene (see icv_plan_s::parts).
+int build_parts(icv_plan_t pl, int elem_bytes) {
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (pl->parts_elem >= elem_bytes) return ICV_OK;
+    for (auto* q : pl->parts) icv_plan_destroy(q);
+    pl->parts.clear();
+    pl->part_woff.clear();
+    pl->parts_elem = 0;
+    const icv::Plan& p = pl->p;
+    std::vector<int32_t> col_pos((size_t)p.n_cols_all, -1);
+    {
+        int rank = 0;
+        for (int q = 0; q < p.Gp; ++q)
+            if (p.src[q] >= 0) col_pos[p.src[q]] = rank++;
+    }
+    const int budget = (icv::kLdsLimit - icv::kScratchBytes - 64) / elem_bytes;  // padded genes per group
+    int c0 = 0;
+    while (c0 < p.n_chr) {
+        int c1 = c0, genes = 0;
+        while (c1 < p.n_chr) {
+            const int g = p.chrom_off[c1 + 1] - p.chrom_off[c1];
+            const int padded = (g + p.B - 1) / p.B * p.B;
+            if (c1 > c0 && genes + padded > budget) break;
+            genes += padded;
+            ++c1;
+        }
+        const int lo = p.chrom_off[c0], hi = p.chrom_off[c1];
+        std::vector<int32_t> cp((size_t)p.n_cols_all, -1), off((size_t)(c1 - c0 + 1));
+        for (int g = 0; g < p.n_cols_all; ++g)
+            if (col_pos[g] >= lo && col_pos[g] < hi) cp[g] = col_pos[g] - lo;
+        for (int c = c0; c <= c1; ++c) off[c - c0] = p.chrom_off[c] - lo;
+        icv_plan_s* part = new (std::nothrow) icv_plan_s();
+        if (!part) return fail(ICV_ERR_NOMEM, "out of host memory");
+        const std::string err =
+            icv::build_plan(part->p, p.n_cols_all, cp.data(), c1 - c0, off.data(), p.window, p.step, p.B);
+        if (!err.empty()) {
+            delete part;
+            return fail(ICV_ERR_INVALID, err);
+        }
+        const icv::Layout& pl_lay = elem_bytes == 4 ? part->p.lay32 : part->p.lay64;
+        if (!pl_lay.fits) {
+            icv_plan_destroy(part);
+            for (auto* q : pl->parts) icv_plan_destroy(q);
+            pl->parts.clear();
+            pl->part_woff.clear();
+            return fail(ICV_ERR_UNSUPPORTED,
+                        "a single chromosome needs " + std::to_string(pl_lay.total) +
+                            " bytes of LDS per workgroup (limit 163840): too many genes on one chromosome");
+        }
+        pl->parts.push_back(part);
+        pl->part_woff.push_back(p.chr_pos[c0]);
+        c0 = c1;
+    }
+    pl->parts_elem = elem_bytes;
+    return ICV_OK;
+}
+
 int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
                 int32_t flags, float* out, int64_t ldo, double* cell_median, double* cell_stats, icv::KParams& K,
                 const icv::Layout*& lay) {
@@ -124,10 +187,10 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     if (!(lfc_clip >= 0.0)) return fail(ICV_ERR_INVALID, "lfc_clip must be >= 0");
     if (!out || ldo < p.W) return fail(ICV_ERR_INVALID, "out is null or ldo < n_windows");
     lay = (m->dtype == ICV_F32) ? &p.lay32 : &p.lay64;
-    if (!lay->fits)
-        return fail(ICV_ERR_UNSUPPORTED,
-                    "configuration needs " + std::to_string(lay->total) +
-                        " bytes of LDS per workgroup (limit 163840): too many genes/windows for one LDS-resident row");
+    if (!lay->fits) {  // chromosome-group fallback (smooth_split); fails if a single chromosome is too large
+        const int rc = build_parts(pl, m->dtype == ICV_F32 ? 4 : 8);
+        if (rc) return rc;
+    }
     std::memset(&K, 0, sizeof(K));
     K.values = m->values;
     K.indptr = m->indptr;
@@ -369,8 +432,74 @@ int launch_smooth_t(icv_plan_t pl, const icv::KParams& K, const icv::Layout& lay
     return run_kernel(kern, grid, lay.total, K, st);
 }
 
+// float64 windows of all cells, chromosome group by chromosome group (every pass re-reads the rows and keeps only
+// its group's genes), into win[n_rows x W].  K: parameters of the full plan (fill_params).
+int split_windows(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, double* win, hipStream_t st) {
+    const bool f32 = m->dtype == ICV_F32;
+    for (size_t k = 0; k < pl->parts.size(); ++k) {
+        icv_plan_t part = pl->parts[k];
+        int rc = ensure_device(part);
+        if (rc) return rc;
+        const icv::Plan& q = part->p;
+        const icv::Layout& lay = f32 ? q.lay32 : q.lay64;
+        icv::KParams P = K;
+        P.dst = part->d_dst;
+        P.src = part->d_src;
+        P.w_start = part->d_wstart;
+        P.w_len = part->d_wlen;
+        P.w_denom = part->d_wdenom;
+        P.dst16 = part->d_dst16;
+        P.pad_idx = part->d_pad;
+        P.w_pack = part->d_wpack;
+        P.n_pad = (int32_t)q.pad_idx.size();
+        P.B = q.B;
+        P.NB = q.NB;
+        P.Gp = q.Gp;
+        P.W = q.W;
+        P.win_off = lay.win_off;
+        P.scratch_off = lay.scratch_off;
+        P.zrow = part->d_zrow;
+        P.zrow_bytes = (int64_t)part->zrow_elems * (f32 ? 4 : 8);
+        P.win_out = win + pl->part_woff[k];
+        P.win_ld = pl->p.W;
+        P.win_only = 1;
+        P.row_list = nullptr;
+        P.row_count = nullptr;
+        if (f32)
+            rc = m->format == ICV_DENSE ? launch_smooth_t<float, false>(part, P, lay, st)
+                                        : launch_smooth_t<float, true>(part, P, lay, st);
+        else
+            rc = m->format == ICV_DENSE ? launch_smooth_t<double, false>(part, P, lay, st)
+                                        : launch_smooth_t<double, true>(part, P, lay, st);
+        if (rc) return rc;
+    }
+    return ICV_OK;
+}
+
+// steps 1-4 for a gene set whose row does not fit LDS: windows by chromosome group, then median and centring
+// on the float64 windows in HBM
+int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipStream_t st) {
+    const int64_t n = K.n_rows;
+    if (n < 1) return ICV_OK;
+    const int W = pl->p.W;
+    double *win = nullptr, *med = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&win, (size_t)n * W * sizeof(double), st));
+    HIP_TRY(hipMallocAsync((void**)&med, (size_t)n * sizeof(double), st));
+    int rc = split_windows(pl, m, K, win, st);
+    if (!rc) {
+        hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, win, n, W, med);
+        hipLaunchKernelGGL(icv::k_win_finish, dim3((unsigned)n), dim3(256), 0, st, win, n, W, med, K.out, K.ldo,
+                           K.cell_median, K.cell_stats);
+        if (hipGetLastError() != hipSuccess) rc = fail(ICV_ERR_HIP, "split smoothing launch failed");
+    }
+    (void)hipFreeAsync(win, st);
+    (void)hipFreeAsync(med, st);
+    return rc;
+}
+
 int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
                   hipStream_t st) {
+    if (!lay.fits) return smooth_split(pl, m, K, st);
     if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.fast_ok && K.vec_ok && std::isfinite(K.cap) &&
         !std::getenv("ICV_FORCE_GENERIC"))
         return launch_smooth_fast(pl, K, st, false, 0, 0);
@@ -440,6 +569,8 @@ int icv_plan_create(int32_t n_cols_all, const int32_t* h_col_pos, int32_t n_chr,
 
 void icv_plan_destroy(icv_plan_t pl) {
     if (!pl) return;
+    for (auto* q : pl->parts) icv_plan_destroy(q);
+    pl->parts.clear();
     if (pl->device >= 0) {
         (void)hipFree(pl->d_dst);
         (void)hipFree(pl->d_src);
@@ -689,7 +820,10 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out32, W, cmed, cstat, K, lay))) return rc;
     K.win_out = win;
-    if (m->dtype == ICV_F32)
+    K.win_ld = W;
+    if (!lay->fits)
+        rc = split_windows(pl, m, K, win, st);
+    else if (m->dtype == ICV_F32)
         rc = m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, *lay, st)
                                     : launch_smooth_t<float, true>(pl, K, *lay, st);
     else

@@ -75,6 +75,10 @@ struct KParams {
     double* cell_part;
     // k_smooth, Layout::win_global: gridDim.x lines of W float64 windows in HBM instead of the LDS window array
     double* win_scratch;
+    // k_smooth, chromosome-group passes of a gene set whose row does not fit LDS (icv_api.hip: smooth_split):
+    // win_only != 0: write the float64 windows to win_out[cell * win_ld + j] and stop there (no median, no x_res)
+    int64_t win_ld;
+    int32_t win_only, _pad3;
 };
 
 struct Scratch {
@@ -411,7 +415,8 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
                     b2 = sp[2 * m + 1];
                 });
                 v = finish_window(v, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
-                win[j] = v;
+                if (P.win_only) P.win_out[cell * P.win_ld + j] = v;
+                else win[j] = v;
                 lmin = v < lmin ? v : lmin;
                 lmax = v > lmax ? v : lmax;
                 lnan |= (v != v);
@@ -422,11 +427,20 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
                 const T* rp = row + st;
                 double v = window_direct(ln, [&](int k) { return (double)rp[k]; });
                 v = finish_window(v, ln, P.pyr_den, P.pyr_rcp, P.w_denom[j]);
-                win[j] = v;
+                if (P.win_only) P.win_out[cell * P.win_ld + j] = v;
+                else win[j] = v;
                 lmin = v < lmin ? v : lmin;
                 lmax = v > lmax ? v : lmax;
                 lnan |= (v != v);
             }
+        }
+        if (P.win_only) {  // one chromosome group of a split gene set: the windows are all this pass produces
+            if constexpr (MAXB > 0) {
+                __syncthreads();
+                for (int i = t; i < P.n_pad; i += NT) row[P.pad_idx[i]] = T(0);
+            }
+            __syncthreads();
+            continue;
         }
         lmin = wave_min(lmin);
         lmax = wave_max(lmax);
@@ -534,7 +548,7 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
         for (int j = t; j < W; j += NT) {
             const double y = win[j] - med;
             orow[j] = (float)y;
-            if (P.win_out) P.win_out[cell * (int64_t)W + j] = win[j];
+            if (P.win_out) P.win_out[cell * P.win_ld + j] = win[j];
             sum = sum + y;
             sq = fma(y, y, sq);
         }
@@ -1161,6 +1175,37 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
                               P.cell_median[cell];
             if (fabs(yd) < th) orow[j] = 0.0f;
         }
+    }
+}
+
+// x_res = window - median (float32), per-cell moments and median, from float64 windows resident in HBM (the
+// last step of the chromosome-group fallback; same DPP reduction tree as the smoothing kernels)
+__global__ void __launch_bounds__(256) k_win_finish(const double* win, int64_t n_rows, int W, const double* med,
+                                                    float* out, int64_t ldo, double* cell_median,
+                                                    double* cell_stats) {
+    __shared__ double ps[4], pq[4];
+    const int64_t cell = blockIdx.x;
+    const double m = med[cell];
+    const double* w = win + cell * (int64_t)W;
+    float* orow = out + cell * ldo;
+    double sum = 0.0, sq = 0.0;
+    for (int j = threadIdx.x; j < W; j += 256) {
+        const double y = w[j] - m;
+        orow[j] = (float)y;
+        sum = sum + y;
+        sq = fma(y, y, sq);
+    }
+    sum = wave_sum_dpp(sum);
+    sq = wave_sum_dpp(sq);
+    if ((threadIdx.x & 63) == 0) {
+        ps[threadIdx.x >> 6] = sum;
+        pq[threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cell_stats[2 * cell] = ((ps[0] + ps[1]) + ps[2]) + ps[3];
+        cell_stats[2 * cell + 1] = ((pq[0] + pq[1]) + pq[2]) + pq[3];
+        cell_median[cell] = m;
     }
 }
 

@@ -101,8 +101,10 @@ inline Layout make_layout(const Plan& p, int elem_bytes) {
 }
 
 // Returns "" on success, an error message otherwise.
+// force_B > 0: use this block size (the chromosome groups of a split gene set evaluate their windows in the same
+// canonical order as the full plan, whose window table the exact tie-break of the threshold kernel uses)
 inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, int n_chr,
-                              const int32_t* chrom_off, int window, int step) {
+                              const int32_t* chrom_off, int window, int step, int force_B = 0) {
     if (n_cols_all <= 0) return "n_cols_all must be positive";
     if (n_chr <= 0) return "no chromosome with genes to smooth (need names starting with 'chr')";
     if (window < 1 || step < 1) return "window and step must be >= 1";
@@ -137,6 +139,7 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         return nb;
     };
     if (B > 1 && count_blocks(B) > (long)kThreads * kMaxBlocksPerThread) B = 1;
+    if (force_B > 0) B = force_B;
     p.B = B;
 
     // padded layout + window table

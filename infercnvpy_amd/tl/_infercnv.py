@@ -151,6 +151,7 @@ def infercnv(
         per_row = max(1.0, X.nnz / max(n_obs, 1)) * (esz + 4) + 8 + 4 * plan.n_windows + 64
     else:
         per_row = n_vars * esz + 4 * plan.n_windows + 64
+    per_row += 8 * plan.n_windows  # float64 window scratch of the chromosome-group fallback (rows that exceed LDS)
     if calculate_gene_values:  # float64 gene matrix + float64 windows + covered-gene means
         per_row += 8 * (2 * n_vars + plan.n_windows) + 4 * plan.n_windows
     slab_rows = int((0.45 * free_b) // per_row)

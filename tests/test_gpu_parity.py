@@ -877,3 +877,43 @@ def test_fresh_process_without_importing_torch_first():
     ) % (os.path.join(os.path.dirname(__file__), ".."), os.path.join(os.path.dirname(__file__), "golden"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK (30," in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype,genes_per_chrom,fmt", [
+    (np.float64, [2600, 2400, 2300, 2200, 2100, 2000, 1900, 1800, 1700, 1600, 1500, 1400, 900, 800], "dense"),  # 25 200
+    (np.float64, [2600, 2400, 2300, 2200, 2100, 2000, 1900, 1800, 1700, 1600, 1500, 1400, 900, 800], "csr"),
+    (np.float32, [4100, 3900, 3700, 3500, 3300, 3100, 2900, 2700, 2500, 2300, 2100, 1900, 1700, 1500, 1300, 1100,
+                  900, 700, 500, 300, 100], "dense"),                                                           # 44 100
+    (np.int64, [2600, 2400, 2300, 2200, 2100, 2000, 1900, 1800, 1700, 1600, 1500, 1400, 900, 800], "csr"),
+])
+def test_gene_sets_larger_than_lds_split_by_chromosome_group(dtype, genes_per_chrom, fmt):
+    """More genes than one LDS-resident row holds (float64: ~20 000, float32: ~40 000): the chromosomes are
+    processed in groups, median and centring run on the collected float64 windows."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var(genes_per_chrom, extra=(("chrX", 50), (None, 7)))
+    G = len(v["names"])
+    n = 23
+    if dtype == np.int64:
+        X = np.random.RandomState(4).poisson(0.8, size=(n, G)).astype(np.int64)
+    else:
+        X = cases.synthetic_expr(n, G, seed=11, dtype=dtype)
+    labels = np.array(["a"] * 8 + ["b"] * 7 + ["c"] * 8)
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    ad = SimpleAnnData(sp.csr_matrix(X) if fmt == "csr" else X, obs=pd.DataFrame({"group": labels}), var=var)
+    gvals = dtype == np.float64 and fmt == "dense"
+    mean_dtype = np.float32 if dtype == np.float32 else np.float64
+    ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in ("a", "b")]).astype(
+        mean_dtype)
+    chr_pos, res, gv = cnv.tl.infercnv(ad, reference_key="group", reference_cat=["a", "b"], chunksize=10,
+                                       inplace=False, calculate_gene_values=gvals)
+    e_pos, e_res, e_gv, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, chunksize=10,
+                                       calculate_gene_values=gvals)
+    assert {k: int(p) for k, p in chr_pos.items()} == {k: int(p) for k, p in e_pos.items()}
+    got, exp = res.toarray(), e_res.toarray()
+    np.testing.assert_array_equal(got == 0, exp == 0)
+    np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
+    if gvals:
+        np.testing.assert_allclose(gv, e_gv, rtol=0, atol=1e-9, equal_nan=True)
