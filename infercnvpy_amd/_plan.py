@@ -29,11 +29,13 @@ def natural_key(name: str):
 
 
 def _null_mask(values: np.ndarray) -> np.ndarray:
-    """pandas-style isnull for an object / float / string column."""
+    """pandas-style isnull for an object / float / string column (None, NaN, pd.NA, NaT)."""
     if values.dtype.kind == "f":
         return np.isnan(values)
     if values.dtype.kind == "O":
-        return np.fromiter(((v is None) or (v != v) for v in values), dtype=bool, count=len(values))
+        import pandas as pd
+
+        return np.asarray(pd.isna(values), dtype=bool)
     return np.zeros(len(values), dtype=bool)
 
 
@@ -55,8 +57,10 @@ class GenePlan:
             chrom = chrom.astype(object)
         chrom = chrom.astype(object)
         start = np.asarray(start)
-        if start.dtype.kind == "O":
-            start = start.astype(np.float64)
+        if start.dtype.kind == "O":  # e.g. a nullable integer column with pd.NA: missing starts sort last (NaN)
+            import pandas as pd
+
+            start = pd.to_numeric(pd.Series(start), errors="coerce").to_numpy(dtype=np.float64, na_value=np.nan)
         n_all = len(chrom)
         if len(start) != n_all:
             raise ValueError("chromosome and start must have the same length")

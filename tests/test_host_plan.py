@@ -100,3 +100,23 @@ def test_plan_info_benchmark_geometry():
     assert plan250.n_windows == 1472 and plan250.info.block == 5
     plan1 = GenePlan(v["chromosome"], v["start"], window_size=100, step=1)
     assert plan1.n_windows == 17822 and plan1.info.block == 1
+
+
+def test_plan_accepts_pandas_nullable_and_categorical_columns():
+    """`adata.var` columns as pandas gives them: Categorical chromosome with missing values, nullable Int64 start
+    with pd.NA (the reference's `sort_values("start")` puts missing starts last, tl/_infercnv.py:350)."""
+    import pandas as pd
+    from infercnvpy_amd._plan import GenePlan
+
+    chrom = ["chr1", "chr2", None, "chr1", "chr1", "chr2", "chrX", "chr1"]
+    start = [30, 5, 7, None, 10, 1, 2, 20]
+    plain = GenePlan(np.array(chrom, dtype=object), np.array([np.nan if s is None else s for s in start]),
+                     window_size=2, step=1)
+    df = pd.DataFrame({"chromosome": pd.Categorical(chrom), "start": pd.array(start, dtype="Int64")})
+    fancy = GenePlan(df["chromosome"].to_numpy(), df["start"].to_numpy(), window_size=2, step=1)
+    assert fancy.chromosomes == plain.chromosomes == ["chr1", "chr2"]
+    np.testing.assert_array_equal(fancy.col_pos, plain.col_pos)
+    assert list(plain.col_pos) == [2, 5, -1, 3, 0, 4, -1, 1]  # chr1: 10, 20, 30, NaN; chr2: 1, 5
+    assert fancy.n_without_position == 1
+    plain.close()
+    fancy.close()
