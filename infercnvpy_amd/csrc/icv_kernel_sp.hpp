@@ -31,8 +31,11 @@
 // for k_smooth_ws.  With one workgroup per CU only one row (80 KB) is in flight per CU, and the knock-out runs
 // (everything but the loads, barriers and stores removed: still 1.94 ms) show that the path is bound by memory
 // level parallelism -- bytes in flight x ~5 us loaded HBM latency -- before any LDS / VALU balance matters;
-// see DESIGN.md section 4 "what binds the smoothing kernel".  The next step for this design is a deeper row
-// prefetch using the consumer half's spare registers (two to three rows in flight per CU).
+// see DESIGN.md section 4 "what binds the smoothing kernel".  A partial two-rows-ahead prefetch (the first 2 / 4 of
+// the 10 row vectors requested one iteration earlier, +20 / +40 % bytes in flight) was measured afterwards and
+// changed nothing (2.54 ms; the 4-vector version spills and is slower), so the floor is not the number of rows in
+// flight alone: the four 16-wavefront barriers per cell, the consumers' serial chain (about 14 k cycles per cell
+// against 5 k for the producers) and the texture path are the open questions for the next round.
 #pragma once
 #include "icv_kernel_ws.hpp"
 
