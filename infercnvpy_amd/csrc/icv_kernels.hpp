@@ -1138,12 +1138,11 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
     float* orow = P.out + cell * P.ldo;
     if (threadIdx.x == 0) tie_n = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < P.W; j += 256) {
-        const float y = orow[j];
+    // returns the value to store for window j (0 below the threshold); ties are queued / resolved exactly
+    auto decide = [&](int j, float y) -> float {
         const float a = fabsf(y);
-        if (a < thf) {
-            orow[j] = 0.0f;
-        } else if (a == thf) {
+        if (a < thf) return 0.0f;
+        if (a == thf) {
             // float32 cannot decide: queue the window for an exact float64 recomputation
             const int idx = atomicAdd(&tie_n, 1);
             if (idx < 32) {
@@ -1152,8 +1151,28 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
                 const int st = P.w_start[j];
                 const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
                                   P.cell_median[cell];
-                if (fabs(yd) < th) orow[j] = 0.0f;
+                if (fabs(yd) < th) return 0.0f;
             }
+        }
+        return y;
+    };
+    if ((reinterpret_cast<uintptr_t>(orow) & 7) == 0) {  // 8-byte aligned row: two windows per load / store
+        float2* o2 = reinterpret_cast<float2*>(orow);
+        const int half = P.W >> 1;
+        for (int q = threadIdx.x; q < half; q += 256) {
+            const float2 y = o2[q];
+            const float2 z = make_float2(decide(2 * q, y.x), decide(2 * q + 1, y.y));
+            if (z.x != y.x || z.y != y.y) o2[q] = z;
+        }
+        if ((P.W & 1) && threadIdx.x == 0) {
+            const int j = P.W - 1;
+            const float y = orow[j], z = decide(j, y);
+            if (z != y) orow[j] = z;
+        }
+    } else {
+        for (int j = threadIdx.x; j < P.W; j += 256) {
+            const float y = orow[j], z = decide(j, y);
+            if (z != y) orow[j] = z;
         }
     }
     __syncthreads();
