@@ -280,7 +280,10 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
 }
 
 // float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
-int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, int64_t csr_begin, int64_t csr_end) {
+// kernel_done (optional): recorded right after the smoothing kernel itself, before the moment finish / hand-back
+// launches, so that profiling reports the dominant kernel's own duration
+int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, int64_t csr_begin, int64_t csr_end,
+                       hipEvent_t kernel_done = nullptr) {
     const icv::Plan& p = pl->p;
     const int need_b = (p.NB + icv::kThreads - 1) / icv::kThreads;
     const int need_w = (p.W + icv::kThreads - 1) / icv::kThreads;
@@ -353,7 +356,10 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     }
     int64_t grid = (int64_t)pl->n_cu * per_cu;
     if (grid > K.n_rows) grid = K.n_rows;
-    if (grid < 1) return ICV_OK;
+    if (grid < 1) {
+        if (kernel_done) HIP_TRY(hipEventRecord(kernel_done, st));
+        return ICV_OK;
+    }
     int rc;
     // ICV_SP=1 (experimental, see icv_kernel_sp.hpp): dense, window 100 / step 10 geometry, one reference row:
     // the split producer / consumer kernel, one 1024-thread workgroup per CU
@@ -370,6 +376,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     } else {
         rc = run_kernel(kern, grid, p.fast_lds, K, st);
     }
+    if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
     if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
     if (rc || !use_ws) return rc;
     // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)
@@ -498,15 +505,22 @@ int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipS
 }
 
 int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
-                  hipStream_t st) {
+                  hipStream_t st, hipEvent_t kernel_done = nullptr, bool* recorded = nullptr) {
+    if (recorded) *recorded = false;
     if (!lay.fits) return smooth_split(pl, m, K, st);
     if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.fast_ok && K.vec_ok && std::isfinite(K.cap) &&
         !std::getenv("ICV_FORCE_GENERIC"))
-        return launch_smooth_fast(pl, K, st, false, 0, 0);
+    {
+        if (recorded) *recorded = kernel_done != nullptr;
+        return launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
+    }
     if (m->dtype == ICV_F32 && m->format == ICV_CSR && pl->p.ws_ok && std::isfinite(K.cap) &&
         m->csr_end > m->csr_begin && aligned16(K.ref_lo) && !std::getenv("ICV_FORCE_GENERIC")) {
-        const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end);
-        if (rc >= 0) return rc;
+        const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
+        if (rc >= 0) {
+            if (recorded) *recorded = kernel_done != nullptr;
+            return rc;
+        }
     }
     if (m->dtype == ICV_F32)
         return m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, lay, st)
@@ -741,8 +755,9 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipEventRecord(ev[0], st));
     }
-    if ((rc = launch_smooth(pl, m, K, *lay, st))) return rc;
-    if (timed) HIP_TRY(hipEventRecord(ev[1], st));
+    bool ev1_done = false;
+    if ((rc = launch_smooth(pl, m, K, *lay, st, timed ? ev[1] : nullptr, &ev1_done))) return rc;
+    if (timed && !ev1_done) HIP_TRY(hipEventRecord(ev[1], st));
     if (do_thr) {
         rc = icv_chunk_thresholds(cell_stats, m->n_rows, chunksize, row_phase, pl->p.W, dynamic_threshold, thr,
                                   stream);
