@@ -69,13 +69,17 @@ __device__ __forceinline__ int wave_scan_dpp(int v) {
 // resolved by 3072 bins (medians of centred, smoothed expression live there), the tails by 512 each.
 __device__ __forceinline__ int hist_bin(double v, float inv_bound) {
     const float u = (float)v * inv_bound;  // in [-1, 1]
+    // central segment first (almost every window of centred, smoothed expression): one fma, floor, two clamps
+    if (__builtin_expect(fabsf(u) < 0.125f, 1)) {
+        const int b = (int)floorf(fmaf(u, 3072.0f / 0.25f, 512.0f + 0.125f * (3072.0f / 0.25f)));
+        return b < 512 ? 512 : (b > 3583 ? 3583 : b);  // segments stay disjoint under rounding
+    }
     float f;
     int lo_b, hi_b;
-    if (u < -0.125f) { f = (u + 1.0f) * (512.0f / 0.875f); lo_b = 0; hi_b = 511; }
-    else if (u < 0.125f) { f = fmaf(u + 0.125f, 3072.0f / 0.25f, 512.0f); lo_b = 512; hi_b = 3583; }
+    if (u < 0.0f) { f = (u + 1.0f) * (512.0f / 0.875f); lo_b = 0; hi_b = 511; }
     else { f = fmaf(u - 0.125f, 512.0f / 0.875f, 3584.0f); lo_b = 3584; hi_b = NBIN - 1; }
     const int b = (int)floorf(f);
-    return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);  // segments stay disjoint under rounding
+    return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);
 }
 
 // CSR input (k_csr_prepare has turned every stored entry into {LDS position, centred+clipped value}):
