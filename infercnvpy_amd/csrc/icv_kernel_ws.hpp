@@ -149,6 +149,26 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
         }
     }
+// wave priority by phase (s_setprio): the arbiter of a SIMD prefers the wavefronts of the workgroup that is in
+// its compute phases over the one that is issuing / waiting for loads
+#ifndef ICV_PA
+#define ICV_PA 0  // histogram scan
+#endif
+#ifndef ICV_PL
+#define ICV_PL 0  // L phase
+#endif
+#ifndef ICV_PLI
+#define ICV_PLI 0  // L phase while it issues loads
+#endif
+#ifndef ICV_PS
+#define ICV_PS 2  // S phase, candidate gather
+#endif
+#ifndef ICV_PO
+#define ICV_PO 2  // B2..B3 segment and x_res output
+#endif
+#ifndef ICV_PW
+#define ICV_PW 2  // W phase
+#endif
 #ifndef ICV_UH
 #define ICV_UH 5  // reference / scatter-table vectors per load group of the L phase (divides UMAX)
 #endif
@@ -183,6 +203,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         const int64_t pcell = cell - gridDim.x;
         int tl = t;
         asm volatile("" : "+v"(tl));  // see k_smooth_fast: keep thread-derived values out of LICM
+        __builtin_amdgcn_s_setprio(ICV_PA);
 
         // ---------------- histogram scan of the previous cell, all wavefronts ----------------------
         // Level 1 before barrier A: thread g sums its 8 bins [8 g, 8 g + 8) (one ds_read_b128), a DPP prefix
@@ -257,6 +278,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         ICV_PHASE(0)
         int w_pack[MAXW];
+        if (ICV_PL != ICV_PA) __builtin_amdgcn_s_setprio(ICV_PL);
         if (more) {
           if constexpr (CSR) {
             // ---------------- L (CSR): zero row, then the cell's prepared entries ------------------
@@ -324,11 +346,13 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                 for (int h = 0; h < UMAX; h += UH) {
                     u32x4 lo[UH];
                     u32x2 dd[UH];
+                    if (ICV_PLI != ICV_PL) __builtin_amdgcn_s_setprio(ICV_PLI);
 #pragma unroll
                     for (int k = 0; k < UH; ++k) {
                         lo[k] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, (h + k) * NT * 16, 0);
                         dd[k] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, (h + k) * NT * 8, 0);
                     }
+                    if (ICV_PLI != ICV_PL) __builtin_amdgcn_s_setprio(ICV_PL);
 #pragma unroll
                     for (int k = 0; k < UH; ++k) {
                         const float y0 = __uint_as_float(xq[h + k].x) - __uint_as_float(lo[k].x);
@@ -374,6 +398,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             // of these registers (S, O and W phases), which can stall on the HBM prefetch and on the stores.
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
             const int64_t nxt = cell + gridDim.x;
+            if (ICV_PLI != ICV_PL) __builtin_amdgcn_s_setprio(ICV_PLI);
             if (nxt < P.n_rows) {
                 const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + nxt * P.ld, row_bytes);
 #pragma unroll
@@ -411,6 +436,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         // ---------------- S: block partial sums (registers) ---------------------------------------
         double s0[MAXB], s1[MAXB];
+        __builtin_amdgcn_s_setprio(ICV_PS);
         if (more) {
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
@@ -440,6 +466,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         ICV_PHASE(3)
         __syncthreads();  // B2: row dead; candidates of the previous cell complete
         asm volatile("" : "+v"(tl));
+        if (ICV_PO != ICV_PS) __builtin_amdgcn_s_setprio(ICV_PO);
         if (more) {
             int4* h4 = reinterpret_cast<int4*>(hist);  // clear the histogram (dead part of the row)
             for (int i = tl; i < NBIN / 8; i += NT) h4[i] = make_int4(0, 0, 0, 0);
@@ -503,6 +530,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             if (tl == 0) P.cell_median[pcell] = med;
         }
         // ---------------- W: windows (registers) + histogram --------------------------------------
+        if (ICV_PW != ICV_PO) __builtin_amdgcn_s_setprio(ICV_PW);
         if (more) {
             int lnan = 0;
 #pragma unroll
