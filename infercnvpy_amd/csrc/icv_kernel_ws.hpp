@@ -169,8 +169,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #ifndef ICV_PW
 #define ICV_PW 2  // W phase
 #endif
+#ifndef ICV_WCH
+#define ICV_WCH 5  // {S0,S1} pairs of a window read per batch in the W phase (register budget)
+#endif
 #ifndef ICV_UH
-#define ICV_UH 5  // reference / scatter-table vectors per load group of the L phase (divides UMAX)
+#define ICV_UH 2  // reference / scatter-table vectors per load group of the L phase (divides UMAX)
 #endif
     constexpr int UH = ICV_UH;
     static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                         if (ln == NBW * BT) {
                             // same operation order as window_from_blocks, fully unrolled in batches of five
                             // {S0,S1} pairs (only 5 x ds_read_b128 results live at a time: register budget)
-                            constexpr int HB = NBW / 2, CH = 5;
+                            constexpr int HB = NBW / 2, CH = ICV_WCH;
                             v = 0.0;
 #pragma unroll
                             for (int m0 = 0; m0 < NBW; m0 += CH) {
