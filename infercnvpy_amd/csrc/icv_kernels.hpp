@@ -1159,10 +1159,19 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
     if ((reinterpret_cast<uintptr_t>(orow) & 7) == 0) {  // 8-byte aligned row: two windows per load / store
         float2* o2 = reinterpret_cast<float2*>(orow);
         const int half = P.W >> 1;
-        for (int q = threadIdx.x; q < half; q += 256) {
-            const float2 y = o2[q];
-            const float2 z = make_float2(decide(2 * q, y.x), decide(2 * q + 1, y.y));
-            if (z.x != y.x || z.y != y.y) o2[q] = z;
+        // batches of four pairs per thread: all loads of a batch are in flight before the first store
+        for (int q0 = threadIdx.x; q0 < half; q0 += 4 * 256) {
+            float2 y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[u] = (q0 + u * 256 < half) ? o2[q0 + u * 256] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * 256;
+                if (q < half) {
+                    const float2 z = make_float2(decide(2 * q, y[u].x), decide(2 * q + 1, y[u].y));
+                    if (z.x != y[u].x || z.y != y[u].y) o2[q] = z;
+                }
+            }
         }
         if ((P.W & 1) && threadIdx.x == 0) {
             const int j = P.W - 1;
