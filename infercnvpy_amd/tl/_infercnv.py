@@ -9,7 +9,6 @@ gene order, moves data and writes the result fields.
 from __future__ import annotations
 
 import logging
-import math
 from collections.abc import Sequence
 
 import numpy as np
