@@ -3,11 +3,14 @@
 // the median of cell k is resolved while cell k+1 flows through the same barriers:
 //   W(k)          every window value also increments one bin of a 4096-bin LDS histogram
 //                 (monotone piecewise-linear binning, so bins keep the rank order)
-//   before A(k+1) wavefront 0 scans the histogram (DPP prefix sums): bins b1, b2 of the two middle
-//                 order statistics, number of windows in lower bins
+//   before A(k+1) every thread sums 8 bins, DPP prefix sums per wavefront, wavefront totals to LDS
+//   after A(k+1)  the wavefront whose 512 bins hold a middle rank resolves its bin (b1, b2) and the number of
+//                 windows in lower bins
 //   after B1(k+1) every thread appends its windows of cell k that fall in b1 / b2 to cand[] (<= 64)
-//   before B3(k+1) wavefront 0 ranks the candidates exactly in float64 -> median
+//   before B3(k+1) all wavefronts rank the candidates exactly in float64 -> median
 //   after B3(k+1) x_res = window - median from the windows still in registers, store, moments
+// Wave priority: the S, output and W phases (the serial chain of a cell) run at s_setprio 2, the scan and the L
+// phase (table loads, scatter: throughput work) at 0 -- the co-resident workgroup fills the gaps (-8 % kernel time).
 // A cell whose bins hold more than 64 candidates is handed back (row_list) and recomputed by the
 // generic k_smooth right after this kernel; NaN cells are final here (median NaN).
 // 5 workgroup barriers per cell (k_smooth_fast: ~10, with 2-3 data-dependent search rounds):
