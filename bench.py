@@ -223,8 +223,8 @@ def main():
             "parallelism": f"row shards x{n_gpus}, all-reduce of the [G] float64 reference sums only",
         },
         "roofline": {
-            "kernel": "k_smooth_ws<10,4,4,10,10> (dense fp32 fast path)" if args.format == "dense" and args.window == 100
-                      else "k_smooth (generic / k_smooth_fast)",
+            "kernel": ("k_smooth_ws<10,4,4,10,10> (dense fp32 fast path)" if args.format == "dense" and args.window == 100
+                       else "k_smooth_ws (variant for this window / format; generic k_smooth if the plan does not fit)"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
