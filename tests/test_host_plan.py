@@ -120,3 +120,18 @@ def test_plan_accepts_pandas_nullable_and_categorical_columns():
     assert fancy.n_without_position == 1
     plain.close()
     fancy.close()
+
+
+@pytest.mark.parametrize("method", ["ward", "single", "average"])
+@pytest.mark.parametrize("n", [2, 3, 17, 200])
+def test_leaves_list_matches_scipy(n, method):
+    """Host side of `pl.chromosome_heatmap(dendrogram=True)` / `tl.cell_linkage`: the leaf order read off a scipy
+    style linkage matrix (iterative, left child first) is scipy's."""
+    from scipy.cluster.hierarchy import leaves_list as scipy_leaves
+    from scipy.cluster.hierarchy import linkage
+
+    from infercnvpy_amd.tl._linkage import leaves_list
+
+    rng = np.random.default_rng(n)
+    Z = linkage(rng.normal(size=(n, 5)), method=method)
+    np.testing.assert_array_equal(leaves_list(Z), scipy_leaves(Z))
