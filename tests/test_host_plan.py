@@ -135,3 +135,38 @@ def test_leaves_list_matches_scipy(n, method):
     rng = np.random.default_rng(n)
     Z = linkage(rng.normal(size=(n, 5)), method=method)
     np.testing.assert_array_equal(leaves_list(Z), scipy_leaves(Z))
+
+
+def _toy_adata(names=("a", "b", "c"), **var_cols):
+    from infercnvpy_amd._compat import SimpleAnnData
+
+    cols = {"chromosome": ["chr1"] * len(names), "start": list(range(len(names))),
+            "end": [s + 10 for s in range(len(names))]}
+    cols.update(var_cols)
+    cols = {k: v for k, v in cols.items() if v is not None}
+    var = pd.DataFrame(cols, index=pd.Index(list(names)))
+    return SimpleAnnData(np.ones((4, len(names)), dtype=np.float32), var=var)
+
+
+def test_public_api_validation_errors_come_before_any_gpu_work():
+    """The reference raises ValueError for duplicate var_names (tl/_infercnv.py:97-98) and for missing genomic
+    position columns (:99-102) before it touches the matrix; so does the drop-in (no GPU in this test)."""
+    import infercnvpy_amd as cnv
+
+    with pytest.raises(ValueError, match="unique"):
+        cnv.tl.infercnv(_toy_adata(names=("a", "a", "b")))
+    for missing in ("chromosome", "start", "end"):
+        with pytest.raises(ValueError, match="Genomic positions"):
+            cnv.tl.infercnv(_toy_adata(**{missing: None}))
+
+
+def test_cnv_score_argument_errors_come_before_any_gpu_work():
+    """`tl.cnv_score`: ValueError when the default groupby is absent (reference tl/_scores.py:63-64); the
+    deprecated `obs_key` spelling warns (:54-61) and then takes the same route."""
+    import infercnvpy_amd as cnv
+
+    ad = _toy_adata()
+    with pytest.raises(ValueError, match="cnv_leiden"):
+        cnv.tl.cnv_score(ad)
+    with pytest.warns(FutureWarning), pytest.raises(ValueError, match="cnv_leiden"):
+        cnv.tl.cnv_score(ad, obs_key="cnv_leiden")
