@@ -170,3 +170,28 @@ def test_cnv_score_argument_errors_come_before_any_gpu_work():
         cnv.tl.cnv_score(ad)
     with pytest.warns(FutureWarning), pytest.raises(ValueError, match="cnv_leiden"):
         cnv.tl.cnv_score(ad, obs_key="cnv_leiden")
+
+
+def test_missing_extension_fails_loudly_no_cpu_fallback(tmp_path):
+    """No CPU fallback: with the shared library absent the public entry point raises HipExtensionMissing (a
+    RuntimeError) instead of computing anything.  Fresh interpreter, library path pointed at nothing."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, pandas as pd\n"
+        "import infercnvpy_amd as cnv\n"
+        "from infercnvpy_amd._compat import SimpleAnnData\n"
+        "from infercnvpy_amd._lib import HipExtensionMissing\n"
+        "var = pd.DataFrame({'chromosome': ['chr1'] * 3, 'start': [1, 2, 3], 'end': [2, 3, 4]}, index=list('abc'))\n"
+        "ad = SimpleAnnData(np.ones((2, 3), dtype=np.float32), var=var)\n"
+        "try:\n"
+        "    cnv.tl.infercnv(ad, window_size=2, step=1)\n"
+        "except HipExtensionMissing as e:\n"
+        "    assert isinstance(e, RuntimeError) and 'no CPU fallback' in str(e)\n"
+        "    print('LOUD')\n"
+    )
+    env = dict(os.environ, INFERCNV_HIP_LIB=str(tmp_path / "absent.so"), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "LOUD" in r.stdout, r.stderr[-2000:]
+    assert "X_cnv" not in r.stdout
