@@ -195,3 +195,34 @@ def test_missing_extension_fails_loudly_no_cpu_fallback(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "LOUD" in r.stdout, r.stderr[-2000:]
     assert "X_cnv" not in r.stdout
+
+
+def test_product_package_never_imports_the_oracle():
+    """`oracle/` is test infrastructure: only tests, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg
+    may import it.  Static check of every module of the shipped package (and of the C sources' includes)."""
+    import ast
+
+    pkg = os.path.join(ROOT, "infercnvpy_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(d, f)
+            if f.endswith(".py"):
+                for node in ast.walk(ast.parse(open(path).read())):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    if any(n.split(".")[0] == "oracle" for n in names):
+                        offenders.append(path)
+            elif f.endswith((".hip", ".hpp", ".h")):
+                if re.search(r'#include\s+[<"][^>"]*oracle', open(path).read()):
+                    offenders.append(path)
+    assert not offenders, offenders
+    # bench.py: the oracle appears only inside cpu_baseline()
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle" for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
+    assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in tree.body)
