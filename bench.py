@@ -190,9 +190,13 @@ def main():
     achieved = bytes_per_cell * n_local / (avg_smooth_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    # counters were collected for the default workload (dense, window 100, 100 000 cells per launch); traffic is
+    # proportional to the cells of a launch, other workloads have no counter data
+    if os.path.exists(pmc_path) and args.format == "dense" and args.window == 100 and args.step == 10:
         try:
             traffic = json.load(open(pmc_path)).get("k_smooth_hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic = traffic * (n_local / 100_000.0)
         except Exception:
             traffic = None
 
