@@ -16,7 +16,7 @@
 
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
-#include "icv_kernel_sp.hpp"
+#include "icv_kernel_x16.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_plan.hpp"
@@ -250,14 +250,13 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long h[32];
         HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-        if (block == icv::SPT) {  // k_smooth_sp (-DICV_SP_PROFILE): work / wait cycles per segment and half
-            std::fprintf(stderr, "[icv sp profile] cycles per cell: segment, producer work / wait, consumer work / wait\n");
-            for (int i = 0; i < 5; ++i)
-                std::fprintf(stderr, "  seg %d  P %8.0f / %8.0f   C %8.0f / %8.0f\n", i, (double)h[i] / (double)K.n_rows,
-                             (double)h[5 + i] / (double)K.n_rows, (double)h[10 + i] / (double)K.n_rows,
-                             (double)h[15 + i] / (double)K.n_rows);
-            std::fprintf(stderr, "  consumer A0 detail: moments %8.0f  histogram %8.0f\n", (double)h[20] / (double)K.n_rows,
-                         (double)h[21] / (double)K.n_rows);
+        if (block == icv::XT) {  // k_smooth_x16 (-DICV_X_PROFILE): shader cycles per cell of wavefront 1
+            (void)hipFree(d);
+            std::fprintf(stderr, "[icv x16 profile] grid=%lld rows=%lld lds=%d cycles per cell: phase A %.0f, barrier 1 "
+                                 "%.0f, phase B %.0f, barrier 2 %.0f\n", (long long)grid, (long long)K.n_rows, lds,
+                         (double)h[0] / (double)K.n_rows, (double)h[1] / (double)K.n_rows,
+                         (double)h[2] / (double)K.n_rows, (double)h[3] / (double)K.n_rows);
+            return ICV_OK;
         }
         (void)hipFree(d);
         const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
@@ -286,19 +285,12 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
                        hipEvent_t kernel_done = nullptr) {
     const icv::Plan& p = pl->p;
     const int need_b = (p.NB + icv::kThreads - 1) / icv::kThreads;
-    const int need_w = (p.W + icv::kThreads - 1) / icv::kThreads;
     void (*kern)(const icv::KParams) = nullptr;
     constexpr int U = icv::kFastUMax;
-    if (need_b <= 4 && p.B == 10 && p.window == 100) kern = icv::k_smooth_fast<U, 4, 4, 10, 10>;
-    else if (need_b <= 4 && p.B == 10) kern = icv::k_smooth_fast<U, 4, 4, 10, 0>;
-    else if (need_b <= 4) kern = icv::k_smooth_fast<U, 4, 4, 0, 0>;
-    else if (need_w <= 4 && p.B == 5) kern = icv::k_smooth_fast<U, 8, 4, 5, 0>;
-    else if (need_w <= 4) kern = icv::k_smooth_fast<U, 8, 4, 0, 0>;
-    else kern = icv::k_smooth_fast<U, 8, 8, 0, 0>;
     K.scratch_off = p.fast_scratch_off;
-    bool use_ws = false;
     void* ws_buf = nullptr;
-    if (p.ws_ok && (csr || !std::getenv("ICV_NO_WS"))) {
+    if (!p.ws_ok) return -1;  // caller falls back to the generic kernel
+    {
         const bool u10 = (p.B == 10 && p.window == 100);
         if (!csr) {
             if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, false> : icv::k_smooth_ws<U, 4, 4, 0, 0, false>;
@@ -325,7 +317,6 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
                                    const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
             }
         }
-        use_ws = true;
         K.hist_off = p.ws_hist_off;
         if (pl->row_list_cap < K.n_rows) {
             (void)hipFree(pl->d_row_list);
@@ -335,9 +326,10 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         }
         if (pl->cell_part_cap < K.n_rows) {
             (void)hipFree(pl->d_cell_part);
-        (void)hipFree(pl->d_win_scratch);
             pl->d_cell_part = nullptr;
-            HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 16 * sizeof(double)));
+            pl->cell_part_cap = 0;
+            // 16 wavefront partial pairs per cell (k_smooth_x16; k_smooth_ws uses the first 8)
+            HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 32 * sizeof(double)));
             pl->cell_part_cap = K.n_rows;
         }
         K.cell_part = pl->d_cell_part;
@@ -345,8 +337,6 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
         K.row_list = pl->d_row_list;
         K.row_count = pl->d_row_count;
-    } else if (csr) {
-        return -1;  // caller falls back to the generic CSR kernel
     }
     int per_cu = icv::kLdsLimit / p.fast_lds;
     if (per_cu > 4) per_cu = 4;
@@ -361,27 +351,33 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         return ICV_OK;
     }
     int rc;
-    // ICV_SP=1 (experimental, see icv_kernel_sp.hpp): dense, window 100 / step 10 geometry, one reference row:
-    // the split producer / consumer kernel, one 1024-thread workgroup per CU
-    const bool use_sp = use_ws && !csr && p.sp_ok && p.B == 10 && p.window == 100 && !K.bounded &&
-                        (p.NB + icv::kThreads - 1) / icv::kThreads <= 4 && std::getenv("ICV_SP");
-    if (use_sp) {
-        icv::KParams S = K;
-        S.win_off = p.sp_s01_off;
-        S.hist_off = p.sp_hist_off;
-        S.scratch_off = p.sp_scratch_off;
-        int64_t gsp = pl->n_cu;
-        if (gsp > K.n_rows) gsp = K.n_rows;
-        rc = run_kernel(icv::k_smooth_sp<icv::kFastUMax, 4, 10, 10>, gsp, p.sp_lds, S, st, icv::SPT);
+    // dense float32, one reference row, window 100 / step 10 or window 250 / step 10 geometry: the 16-wavefront
+    // kernel, one 1024-thread workgroup per CU (ICV_NO_X16=1: developer knob, previous generation)
+    void (*xk)(const icv::KParams) = nullptr;
+    if (!csr && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16")) {
+        if (p.B == 10 && p.window == 100 && p.NB <= 2 * icv::XT) xk = icv::k_smooth_x16<2, 2, 10, 10>;
+    }
+    if (xk) {
+        icv::KParams X = K;
+        X.win_off = p.x16_s01_off;
+        X.hist_off = p.x16_hist_off;
+        X.scratch_off = p.x16_scratch_off;
+        int64_t gx = pl->n_cu;
+        if (gx > K.n_rows) gx = K.n_rows;
+        rc = run_kernel(xk, gx, p.x16_lds, X, st, icv::XT);
+        if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
+        if (rc) return rc;
+        hipLaunchKernelGGL(icv::k_stats_finish_n, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
+                           K.cell_part, K.n_rows, icv::XWAVE, K.cell_stats);
     } else {
         rc = run_kernel(kern, grid, p.fast_lds, K, st);
+        if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
+        if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
+        if (rc) return rc;
+        // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)
+        hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
+                           K.cell_part, K.n_rows, K.cell_stats);
     }
-    if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
-    if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
-    if (rc || !use_ws) return rc;
-    // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)
-    hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
-                       K.n_rows, K.cell_stats);
     // cells whose median bins held more than 64 windows: recompute them with the generic kernel
     // (reads the device-side count; exits at once when the list is empty)
     icv::KParams G = K;
@@ -508,11 +504,14 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
                   hipStream_t st, hipEvent_t kernel_done = nullptr, bool* recorded = nullptr) {
     if (recorded) *recorded = false;
     if (!lay.fits) return smooth_split(pl, m, K, st);
-    if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.fast_ok && K.vec_ok && std::isfinite(K.cap) &&
+    if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.ws_ok && K.vec_ok && std::isfinite(K.cap) &&
         !std::getenv("ICV_FORCE_GENERIC"))
     {
-        if (recorded) *recorded = kernel_done != nullptr;
-        return launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
+        const int rc = launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
+        if (rc >= 0) {
+            if (recorded) *recorded = kernel_done != nullptr;
+            return rc;
+        }
     }
     if (m->dtype == ICV_F32 && m->format == ICV_CSR && pl->p.ws_ok && std::isfinite(K.cap) &&
         m->csr_end > m->csr_begin && aligned16(K.ref_lo) && !std::getenv("ICV_FORCE_GENERIC")) {

@@ -584,431 +584,14 @@ __global__ void __launch_bounds__(NT) k_smooth(const KParams P) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Fast path of the smoothing kernel: dense float32, blocked form (B > 1), G <= 20480.
-//   * the NEXT cell's row is prefetched into registers (UMAX 16-byte loads per lane) right
-//     after the current row has been scattered, so HBM latency is covered by the S/W/M/O phases;
-//     no other global load is issued in those phases (a later load's s_waitcnt would drain the
-//     prefetch): window descriptors and the packed scatter table live in registers;
-//   * window values stay in registers: the median bisection counts with v_cmp + s_bcnt1
-//     (ballots), pivots by count interpolation, no LDS window array;
-//   * moments and tie resolution use DPP reductions.
-// Same float64 evaluation order as k_smooth: results are bit-identical.
+// raw buffer descriptors (out-of-range lanes read 0, no traffic) for the register-prefetch kernels
+// (icv_kernel_ws.hpp, icv_kernel_x16.hpp)
 // ---------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     // raw buffer descriptor: base, stride 0, num_records = bytes (out-of-range lanes read 0)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-
-constexpr int NPIV = 6;  // pivots counted per median iteration
-struct ScratchF {
-    int pc[2][NPIV][NWAVE];  // [iteration parity][pivot][wave] partial counts
-    int nanw[NWAVE];
-    int ncand;
-    int r1_found, r2_found;
-    int rank[64];
-    double cand[64];
-    double sel[2];
-    double dsum[NWAVE], dsq[NWAVE];
-    double dmin[NWAVE], dmax[NWAVE];
-};
-static_assert(sizeof(ScratchF) <= 1536, "ScratchF must fit the scratch region");
-
-template <int UMAX, int MAXB, int MAXW, int BT /* compile-time block size, 0 = runtime */,
-          int NBW /* compile-time blocks per pyramid window, 0 = runtime */>
-__global__ void __launch_bounds__(NT, 4) k_smooth_fast(const KParams P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* row = reinterpret_cast<float*>(smem);
-    double* S01 = reinterpret_cast<double*>(smem);
-    ScratchF* sc = reinterpret_cast<ScratchF*>(smem + P.scratch_off);
-
-    const int t = threadIdx.x;
-    const float cap = (float)P.cap;
-    const int W = P.W, NB = P.NB;
-    const int B = BT > 0 ? BT : P.B;
-    const unsigned row_bytes = (unsigned)P.n_cols * 4u;
-    const unsigned voff = (unsigned)t * 16u;  // the only per-lane address register of the row loads
-    const __amdgpu_buffer_rsrc_t lo_rs = make_rsrc(P.ref_lo, row_bytes);
-    const __amdgpu_buffer_rsrc_t hi_rs = make_rsrc(P.bounded ? P.ref_hi : P.ref_lo, row_bytes);
-    const double pyr_den = P.pyr_den, pyr_rcp = P.pyr_rcp;
-    const float* xbase = static_cast<const float*>(P.values);
-
-    // ---- per-thread constants, loaded once --------------------------------------------
-    // scatter table: 4 packed 16-bit LDS positions per 16-byte load, re-read from L2 every cell
-    // (holding it in registers costs 20 VGPRs and pushed the kernel into scratch spills)
-    const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(UMAX * NT * 8));
-    const unsigned voff8 = (unsigned)t * 8u;
-    int w_pack[MAXW];  // start block (low 16) | signed length in genes (high 16)
-    int w_gc[MAXW];    // flat windows: gene count of the chromosome
-#pragma unroll
-    for (int i = 0; i < MAXW; ++i) {
-        const int j = t + i * NT;
-        w_pack[i] = 0;
-        w_gc[i] = 1;
-        if (j < W) {
-            const int st = P.w_start[j], ln = P.w_len[j];
-            w_pack[i] = (int)((unsigned)((st / B) & 0xffff) | ((unsigned)ln << 16));
-            w_gc[i] = (int)P.w_denom[j];
-        }
-    }
-
-    unsigned gi = 0;  // median iterations since kernel start (selects the counter slot)
-
-    // ---- prefetch the first row ----------------------------------------------------------
-    u32x4 xq[UMAX];
-    {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
-    }
-    __syncthreads();
-
-    unsigned long long tlast = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define ICV_PHASE(i)                                            \
-    if (P.dbg && t == 0) {                                      \
-        unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tacc[i] += now_ - tlast;                                \
-        tlast = now_;                                           \
-    }
-    if (P.dbg && t == 0) tlast = __builtin_amdgcn_s_memtime();
-
-    constexpr int UH = 5;  // reference loads in flight per sub-batch (register budget)
-    static_assert(UMAX % UH == 0, "UMAX must be a multiple of UH");
-
-    for (int64_t cell = blockIdx.x; cell < P.n_rows; cell += gridDim.x) {
-        // Everything derived from the thread id below goes through `tl`, a copy laundered by an
-        // empty asm: otherwise the compiler hoists dozens of per-thread addresses and predicates
-        // out of the cell loop, spills them, and the scratch reloads (VMEM, in-order) would
-        // drain the prefetch queue in the middle of the compute phases.
-        int tl = t;
-        asm volatile("" : "+v"(tl));
-        // ---------------- L: centre, clip, scatter the prefetched row ---------------------
-        // (pad slots are clobbered by the aliased S01 of the previous cell: clear them first)
-        for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
-// Masked columns point at a trash slot (index Gp) so the scatter is unconditional.  The packed
-// positions are laundered through an empty asm so that the compiler does not hoist the 40
-// unpacked addresses out of the cell loop (they would cost 40 VGPRs for the whole kernel).
-#define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
-    {                                                                                                            \
-        const unsigned dx_ = (D).x, dy_ = (D).y;                                                                 \
-        row[dx_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).x), __uint_as_float((LO).x),                 \
-                                                __uint_as_float((HI).x), cap, BND, P.trunc);                     \
-        row[dx_ >> 16] = centre_clip<float>(__uint_as_float((X).y), __uint_as_float((LO).y),                     \
-                                            __uint_as_float((HI).y), cap, BND, P.trunc);                         \
-        row[dy_ & 0xffffu] = centre_clip<float>(__uint_as_float((X).z), __uint_as_float((LO).z),                 \
-                                                __uint_as_float((HI).z), cap, BND, P.trunc);                     \
-        row[dy_ >> 16] = centre_clip<float>(__uint_as_float((X).w), __uint_as_float((LO).w),                     \
-                                            __uint_as_float((HI).w), cap, BND, P.trunc);                         \
-    }
-        if (!P.bounded) {
-#pragma unroll
-            for (int h = 0; h < UMAX; h += UH) {
-                u32x4 lo[UH];
-                u32x2 dd[UH];
-#pragma unroll
-                for (int k = 0; k < UH; ++k) {
-                    lo[k] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, (h + k) * NT * 16, 0);
-                    dd[k] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, (h + k) * NT * 8, 0);
-                }
-#pragma unroll
-                for (int k = 0; k < UH; ++k) ICV_SCATTER4(xq[h + k], lo[k], lo[k], dd[k], 0)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < UMAX; ++u) {
-                const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * NT * 16, 0);
-                const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(hi_rs, voff, u * NT * 16, 0);
-                const u32x2 dd = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, voff8, u * NT * 8, 0);
-                ICV_SCATTER4(xq[u], lo, hi, dd, 1)
-            }
-        }
-#undef ICV_SCATTER4
-        // prefetch the next row of this workgroup; in flight until the next L phase
-        {
-            const int64_t nxt = cell + gridDim.x;
-            if (nxt < P.n_rows) {
-                const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + nxt * P.ld, row_bytes);
-#pragma unroll
-                for (int u = 0; u < UMAX; ++u)
-                    xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * NT * 16, 0);
-            }
-        }
-        __syncthreads();
-        ICV_PHASE(0)
-
-        // ---------------- S: block partial sums (registers), then over the dead row -------
-        asm volatile("" : "+v"(tl));
-        {
-            double s0[MAXB], s1[MAXB];
-#pragma unroll
-            for (int i = 0; i < MAXB; ++i) {
-                s0[i] = 0.0;
-                s1[i] = 0.0;
-                const int b = tl + i * NT;
-                if (b < NB) {
-                    const float* rp = row + b * B;
-                    if constexpr (BT > 0 && (BT & 1) == 0) {
-                        const float2* rp2 = reinterpret_cast<const float2*>(rp);
-#pragma unroll
-                        for (int r = 0; r < BT; r += 2) {
-                            const float2 v2 = rp2[r >> 1];
-                            block_accumulate((double)v2.x, r, s0[i], s1[i]);
-                            block_accumulate((double)v2.y, r + 1, s0[i], s1[i]);
-                        }
-                    } else if constexpr (BT > 0) {
-#pragma unroll
-                        for (int r = 0; r < BT; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
-                    } else {
-#pragma unroll 1
-                        for (int r = 0; r < B; ++r) block_accumulate((double)rp[r], r, s0[i], s1[i]);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MAXB; ++i) {
-                const int b = tl + i * NT;
-                if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
-            }
-            __syncthreads();
-        }
-        ICV_PHASE(1)
-
-        // ---------------- W: windows, kept in registers -----------------------------------
-        asm volatile("" : "+v"(tl));
-        double wv[MAXW];
-        int lnan = 0;
-#pragma unroll
-        for (int i = 0; i < MAXW; ++i) {
-            wv[i] = __builtin_inf();  // slots beyond W never count as <= pivot
-            if (tl + i * NT < W) {
-                int wp = w_pack[i], gc = w_gc[i];
-                asm volatile("" : "+v"(wp), "+v"(gc));  // keep the decode inside the loop (register budget)
-                const int ln = wp >> 16;
-                const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
-                double v;
-                if constexpr (BT > 0 && NBW > 0) {
-                  if (ln == NBW * BT) {
-                    // same operation order as window_from_blocks, fully unrolled: all LDS reads first
-                    double2 sb[NBW > 0 ? NBW : 1];
-#pragma unroll
-                    for (int m = 0; m < NBW; ++m) sb[m] = sp[m];
-                    v = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NBW; ++m) {
-                        if (m < NBW / 2) {
-                            v = fma((double)(m * BT + 1), sb[m].x, v);
-                            v = v + sb[m].y;
-                        } else {
-                            v = fma((double)(NBW * BT - m * BT), sb[m].x, v);
-                            v = v - sb[m].y;
-                        }
-                    }
-                  } else {
-                    v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
-                        const double2 s = sp[m];
-                        a = s.x;
-                        b2 = s.y;
-                    });
-                  }
-                } else {
-                    v = window_from_blocks(ln, B, [&](int m, double& a, double& b2) {
-                        const double2 s = sp[m];
-                        a = s.x;
-                        b2 = s.y;
-                    });
-                }
-                v = finish_window(v, ln, pyr_den, pyr_rcp, (double)gc);
-                wv[i] = v;
-                lnan |= (v != v);
-            }
-        }
-        ICV_PHASE(2)
-
-        // ---------------- M: median (np.median, reference :442) ---------------------------
-        // order statistics k1 <= k2 (0-based) stay inside (lo, hi]; cnt_x = #{w <= x}
-        const int k1 = (W - 1) / 2, k2 = W / 2;
-        double lo = -P.med_bound, hi = P.med_bound;
-        int cnt_lo = 0, cnt_hi = W;
-        int it = 0, anynan = 0, split = 0;
-        double med = 0.0, a_val = 0.0, b_val = 0.0;
-        int mode = 0;  // 0: pivots around the count-interpolated position, 1: uniform 7-section
-        const int pl = tl & 7;  // lanes 0..5 of every wavefront each build one pivot
-        while (true) {
-            const int inside = cnt_hi - cnt_lo;
-            if (it >= 1 && inside <= 64) break;
-            const double mid = 0.5 * lo + 0.5 * hi;
-            if (!(mid > lo && mid < hi)) break;  // adjacent doubles: every candidate == hi
-            // NPIV pivots strictly inside (lo, hi); any choice is correct, the choice only sets the
-            // number of iterations (typically 2-3: each costs one workgroup barrier round trip)
-            double x;
-            if (it < 40) {
-                float f;
-                if (mode == 0) {
-                    const float inv = 1.0f / (float)inside;
-                    const float fc = ((float)(k1 - cnt_lo) + 0.5f) * inv, d = 24.0f * inv;
-                    const float mag = ldexpf(0.5f, 2 * (pl < 3 ? 2 - pl : pl - 3));  // .5, 2, 8
-                    f = fc + (pl < 3 ? -mag : mag) * d;
-                } else {
-                    f = (float)(pl + 1) * (1.0f / (float)(NPIV + 1));
-                }
-                f = f < 1e-4f ? 1e-4f : (f > 0.9999f ? 0.9999f : f);
-                x = lo + (hi - lo) * (double)f;
-            } else {
-                const unsigned long long a = ordered_key(lo), b = ordered_key(hi);
-                x = from_ordered_key(a + ((b - a) >> 1));
-            }
-            x = (x > lo && x < hi) ? x : mid;
-            double piv[NPIV];
-#pragma unroll
-            for (int p = 0; p < NPIV; ++p) piv[p] = readlane_d(x, p);
-            int cw[NPIV];
-#pragma unroll
-            for (int p = 0; p < NPIV; ++p) cw[p] = 0;
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i) {
-#pragma unroll
-                for (int p = 0; p < NPIV; ++p)  // slots without a window hold +inf
-                    cw[p] += __popcll(__builtin_amdgcn_ballot_w64(wv[i] <= piv[p]));
-            }
-            const unsigned long long nanmask = (it == 0) ? __builtin_amdgcn_ballot_w64(lnan != 0) : 0ull;
-            const unsigned slot = gi & 1u;
-            {
-                int myc = cw[0];
-#pragma unroll
-                for (int p = 1; p < NPIV; ++p) myc = (pl == p) ? cw[p] : myc;
-                if ((tl & 63) < NPIV) sc->pc[slot][pl][tl >> 6] = myc;
-                if (it == 0 && (tl & 63) == 0) sc->nanw[tl >> 6] = nanmask != 0ull;
-            }
-            __syncthreads();
-            ++gi;
-            if (it == 0) {
-#pragma unroll
-                for (int i = 0; i < NWAVE; ++i) anynan |= sc->nanw[i];
-                if (anynan) break;
-            }
-            // lane l < 8*NPIV reads (pivot l>>3, wave l&7); DPP sum over each group of 8 lanes
-            int cv = ((tl & 63) < 8 * NPIV) ? (&sc->pc[slot][0][0])[tl & 63] : 0;
-            cv += dpp_move_i<0xB1>(cv);
-            cv += dpp_move_i<0x4E>(cv);
-            cv += dpp_move_i<0x141>(cv);
-#pragma unroll
-            for (int p = 0; p < NPIV; ++p) {
-                const int c = __builtin_amdgcn_readlane(cv, 8 * p);
-                const double xp = piv[p];
-                if (c <= k1) {
-                    if (xp > lo) { lo = xp; cnt_lo = c; }
-                } else if (c > k2) {
-                    if (xp < hi) { hi = xp; cnt_hi = c; }
-                } else {  // k1 < c <= k2: this pivot separates the two middle elements
-                    split = 1;
-                    a_val = xp;
-                }
-            }
-            if (split) break;
-            mode = ((cnt_hi - cnt_lo) * 2 > inside) ? 1 : 0;
-            if (++it >= 200) break;
-        }
-        ICV_PHASE(5)
-        if (P.dbg && t == 0) { tacc[6] += (unsigned long long)it; tacc[7] += (unsigned long long)split; }
-        if (anynan) {
-            med = __builtin_nan("");
-        } else if (split) {
-            // a = max{w <= pivot}, b = min{w > pivot}
-            double mx = -__builtin_inf(), mn = __builtin_inf();
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i) {
-                if (tl + i * NT < W) {
-                    if (wv[i] <= a_val) mx = wv[i] > mx ? wv[i] : mx;
-                    else mn = wv[i] < mn ? wv[i] : mn;
-                }
-            }
-            mx = wave_max_dpp(mx);
-            mn = wave_min_dpp(mn);
-            if ((tl & 63) == 0) { sc->dmax[tl >> 6] = mx; sc->dmin[tl >> 6] = mn; }
-            __syncthreads();
-            mx = sc->dmax[0];
-            mn = sc->dmin[0];
-#pragma unroll
-            for (int i = 1; i < NWAVE; ++i) {
-                mx = sc->dmax[i] > mx ? sc->dmax[i] : mx;
-                mn = sc->dmin[i] < mn ? sc->dmin[i] : mn;
-            }
-            med = (mx + mn) / 2.0;
-        } else if (cnt_hi - cnt_lo <= 64) {
-            // rank the <= 64 candidates exactly: thread (i, p) compares candidate i with 8 others
-            if (tl < 64) sc->rank[tl] = 0;
-            if (tl == 0) sc->ncand = 0;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i) {
-                if (tl + i * NT < W && wv[i] > lo && wv[i] <= hi) {
-                    const int idx = atomicAdd(&sc->ncand, 1);
-                    if (idx < 64) sc->cand[idx] = wv[i];
-                }
-            }
-            __syncthreads();
-            const int n = sc->ncand < 64 ? sc->ncand : 64;
-            {
-                const int ci = tl & 63, part = tl >> 6;
-                if (ci < n) {
-                    const double mine = sc->cand[ci];
-                    int r = 0;
-                    for (int jj = part * 8; jj < part * 8 + 8 && jj < n; ++jj) {
-                        const double o = sc->cand[jj];
-                        r += (o < mine || (o == mine && jj < ci)) ? 1 : 0;
-                    }
-                    if (r) atomicAdd(&sc->rank[ci], r);
-                }
-            }
-            __syncthreads();
-            if (tl < n) {
-                const int r = sc->rank[tl];
-                if (r == k1 - cnt_lo) sc->sel[0] = sc->cand[tl];
-                if (r == k2 - cnt_lo) sc->sel[1] = sc->cand[tl];
-            }
-            __syncthreads();
-            a_val = sc->sel[0];
-            b_val = sc->sel[1];
-            med = (k1 == k2) ? a_val : (a_val + b_val) / 2.0;
-        } else {
-            med = hi;  // more than 64 equal values around the median
-        }
-        ICV_PHASE(3)
-
-        // ---------------- O: centre, store, per-cell moments ------------------------------
-        asm volatile("" : "+v"(tl));
-        double sum = 0.0, sq = 0.0;
-        float* orow = P.out + cell * P.ldo;
-#pragma unroll
-        for (int i = 0; i < MAXW; ++i) {
-            const int j = tl + i * NT;
-            if (j < W) {
-                const double y = wv[i] - med;
-                orow[j] = (float)y;
-                sum = sum + y;
-                sq = fma(y, y, sq);
-            }
-        }
-        sum = wave_sum_dpp(sum);
-        sq = wave_sum_dpp(sq);
-        if ((tl & 63) == 0) { sc->dsum[tl >> 6] = sum; sc->dsq[tl >> 6] = sq; }
-        __syncthreads();
-        if (tl == 0) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < NWAVE; ++i) { s += sc->dsum[i]; q += sc->dsq[i]; }
-            P.cell_stats[2 * cell] = s;
-            P.cell_stats[2 * cell + 1] = q;
-            P.cell_median[cell] = med;
-        }
-        ICV_PHASE(4)
-    }
-    if (P.dbg && t == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(P.dbg + i, tacc[i]);
-#undef ICV_PHASE
 }
 
 // ---------------------------------------------------------------------------------------

@@ -21,6 +21,8 @@ constexpr int kFastScratchBytes = 1536;  // struct ScratchF
 constexpr int kFastUMax = 10;          // 16-byte loads per lane held in registers (fast path)
 constexpr int kWsUMax = 12;            // same for the 448 worker threads of k_smooth_ws
 constexpr int kWsMaxB = 5, kWsMaxW = 5, kWsMaxK = 30;
+constexpr int kX16Threads = 1024;      // k_smooth_x16: 16 wavefronts, one workgroup per CU
+constexpr int kX16UMax = 5;            // 16-byte row vectors per lane in flight
 
 struct Layout {
     int elem_bytes = 4;
@@ -62,6 +64,9 @@ struct Plan {
     // k_smooth_sp (one 1024-thread workgroup per CU): row | {S0,S1} | histogram | scratch, nothing aliased
     bool sp_ok = false;
     int sp_s01_off = 0, sp_hist_off = 0, sp_scratch_off = 0, sp_lds = 0;
+    // k_smooth_x16 (one 1024-thread workgroup per CU, tables in registers): row | {S0,S1} | histogram | scratch
+    bool x16_ok = false;
+    int x16_s01_off = 0, x16_hist_off = 0, x16_scratch_off = 0, x16_lds = 0;
     Layout lay32, lay64;
 };
 
@@ -246,6 +251,12 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         p.sp_scratch_off = p.sp_hist_off + 4096 * 2;
         p.sp_lds = p.sp_scratch_off + kFastScratchBytes;
         p.sp_ok = p.ws_ok && p.sp_lds <= kLdsLimit && p.NB <= kThreads * 4 && p.W <= kThreads * 4;
+        p.x16_s01_off = round_up((p.Gp + 1) * 4, 16);
+        p.x16_hist_off = p.x16_s01_off + 16 * p.NB;
+        p.x16_scratch_off = p.x16_hist_off + 4096 * 2;
+        p.x16_lds = p.x16_scratch_off + kFastScratchBytes;
+        p.x16_ok = p.fast_ok && n_cols_all <= kX16UMax * kX16Threads * 4 && p.x16_lds <= kLdsLimit &&
+                   p.NB <= kX16Threads * 4 && p.W <= kX16Threads * 2 && p.W < 65536;
     }
     return "";
 }

@@ -351,17 +351,18 @@ def test_error_behaviour_matches_reference():
 
 
 def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
-    """k_smooth_ws (wave-specialised), k_smooth_fast (register prefetch, ballot median) and k_smooth
-    (generic) share one float64 evaluation order for windows and median: outputs and medians must
-    agree bit for bit.  The per-cell moments are reduced in kernel-specific (fixed) orders, so they and
-    the thresholds agree to float64 rounding."""
+    """k_smooth_x16 (16 wavefronts per cell, the default for the window 100 / step 10 geometry), k_smooth_ws
+    (two 8-wavefront workgroups per CU, pipelined histogram median) and k_smooth (generic) share one float64
+    evaluation order for windows and median: outputs and medians must agree bit for bit.  The per-cell
+    moments are reduced in kernel-specific (fixed) orders, so they and the thresholds agree to float64
+    rounding."""
     import torch
 
     from infercnvpy_amd import _engine
     from infercnvpy_amd._plan import GenePlan
 
     def run(plan, dm, ref, env):
-        for k in ("ICV_FORCE_GENERIC", "ICV_NO_WS", "ICV_SP"):
+        for k in ("ICV_FORCE_GENERIC", "ICV_NO_X16"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -386,10 +387,9 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm = _engine.DeviceMatrix(dense=X)
         gen = run(plan, dm, ref, ["ICV_FORCE_GENERIC"])
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
-        # default k_smooth_ws, previous generation k_smooth_fast, experimental split kernel k_smooth_sp
-        # (window 100 / step 10 geometry only, otherwise the default runs), prepared-entry CSR, generic CSR
-        for env, mat in (([], dm), (["ICV_NO_WS"], dm), (["ICV_SP"], dm), ([], dm_csr),
-                         (["ICV_FORCE_GENERIC"], dm_csr)):
+        # default (k_smooth_x16 where the geometry admits it, else k_smooth_ws), k_smooth_ws forced,
+        # prepared-entry CSR, generic CSR
+        for env, mat in (([], dm), (["ICV_NO_X16"], dm), ([], dm_csr), (["ICV_FORCE_GENERIC"], dm_csr)):
             fast = run(plan, mat, ref, env)
             for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median)):
                 assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)), env
