@@ -138,7 +138,7 @@ def main():
         ip, ix, dv = synth_csr_on_device(torch, n_local, G, args.density, seed=3 + rank)
         dm = _engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(n_local, G))
         nnz_row = dv.numel() / n_local
-    out = torch.empty((n_local, W), dtype=torch.float32, device="cuda")
+    out = _engine.alloc_out(n_local, W)
     sums = torch.zeros((1, G), dtype=torch.float64, device="cuda")
     fixed_ref = None
     if args.no_refmean:

@@ -125,18 +125,30 @@ def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None):
     return sums
 
 
+def alloc_out(rows, n_windows):
+    """Device float32 ``rows x n_windows`` result buffer whose rows start on 16-byte boundaries (row stride padded
+    to a multiple of 4): the smoothing kernel then writes x_res with 16-byte stores."""
+    torch = _torch()
+    ld = (n_windows + 3) // 4 * 4
+    return torch.empty((rows, ld), dtype=torch.float32, device="cuda")[:, :n_windows]
+
+
 class SmoothResult:
     def __init__(self, out, cell_median, cell_stats, thr, profile):
         self.out = out                  # device float32 C x W (thresholded x_res)
         self.cell_median = cell_median  # device float64 C
-        self.cell_stats = cell_stats    # device float64 C x 2
+        self.cell_stats = cell_stats    # device float64 C x 2 | None (not requested)
         self.thr = thr                  # device float64 n_chunks | None
         self.profile = profile
 
 
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,
-                 chunksize=5000, row_phase=0, flags=0, out=None, profile=False, row0=0, row1=None):
-    """Steps 1-5 of the chunk kernel for rows [row0, row1) of ``dm`` (all device-resident)."""
+                 chunksize=5000, row_phase=0, flags=0, out=None, profile=False, row0=0, row1=None,
+                 cell_stats=False):
+    """Steps 1-5 of the chunk kernel for rows [row0, row1) of ``dm`` (all device-resident).
+
+    ``cell_stats=True`` also returns the per-cell moments (sum, sum of squares of x_res); without them the
+    library forms the noise-threshold moments per chunk inside the smoothing kernel (faster)."""
     torch = _torch()
     lib = _lib.load()
     n = dm.shape[0]
@@ -144,10 +156,10 @@ def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_c
     rows = row1 - row0
     W = plan.n_windows
     if out is None:
-        out = torch.empty((rows, W), dtype=torch.float32, device="cuda")
+        out = alloc_out(rows, W)
     assert out.dtype == torch.float32 and out.shape[0] >= rows and out.shape[1] >= W and out.stride(1) == 1
     med = torch.empty(rows, dtype=torch.float64, device="cuda")
-    stats = torch.empty((rows, 2), dtype=torch.float64, device="cuda")
+    stats = torch.empty((rows, 2), dtype=torch.float64, device="cuda") if cell_stats else None
     dyn = float("nan") if dynamic_threshold is None else float(dynamic_threshold)
     thr = None
     if dynamic_threshold is not None:

@@ -58,8 +58,12 @@ struct icv_plan_s {
     std::vector<hipEvent_t> prof_events;
     double* d_win_scratch = nullptr;  // Layout::win_global: per-workgroup window lines of k_smooth
     int64_t win_scratch_cap = 0;
-    double* d_cell_part = nullptr;  // per-wavefront partial moments of the ws / sp kernels
+    double* d_cell_part = nullptr;  // per-wavefront partial moments of the ws / x16 kernels
     int64_t cell_part_cap = 0;
+    double* d_chunk_part = nullptr;  // k_smooth_x16<CHUNK>: per (chunk, workgroup, wavefront) moments
+    int64_t chunk_part_cap = 0;      // in double2 elements
+    double* d_hb_stats = nullptr;    // per-row moments when the caller passes no cell_stats (rows x 2)
+    int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
@@ -250,11 +254,13 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
         HIP_TRY(hipStreamSynchronize(st));
         unsigned long long h[32];
         HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-        if (block == icv::XT) {  // k_smooth_x16 (-DICV_X_PROFILE): shader cycles per cell of wavefront 1
+        if (block == icv::XT) {  // k_smooth_x16 (-DICV_X_PROFILE): shader cycles per cell of wavefront 15
             (void)hipFree(d);
-            std::fprintf(stderr, "[icv x16 profile] grid=%lld rows=%lld lds=%d cycles per cell: phase A %.0f, barrier 1 "
-                                 "%.0f, phase B %.0f, barrier 2 %.0f\n", (long long)grid, (long long)K.n_rows, lds,
+            std::fprintf(stderr, "[icv x16 profile] grid=%lld rows=%lld lds=%d cycles per cell: A: store %.0f, chains %.0f, S "
+                                 "%.0f, barrier 1 %.0f, B: output+gather+clear %.0f, W %.0f, L %.0f, barrier 2 %.0f\n", (long long)grid,
+                         (long long)K.n_rows, lds, (double)h[6] / (double)K.n_rows, (double)h[7] / (double)K.n_rows,
                          (double)h[0] / (double)K.n_rows, (double)h[1] / (double)K.n_rows,
+                         (double)h[4] / (double)K.n_rows, (double)h[5] / (double)K.n_rows,
                          (double)h[2] / (double)K.n_rows, (double)h[3] / (double)K.n_rows);
             return ICV_OK;
         }
@@ -276,6 +282,14 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(block), lds, st, K);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
+}
+
+// the geometry / input admits k_smooth_x16 (same routing as launch_smooth -> launch_smooth_fast)
+bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay) {
+    const icv::Plan& p = pl->p;
+    return lay.fits && m->dtype == ICV_F32 && m->format == ICV_DENSE && p.ws_ok && K.vec_ok && std::isfinite(K.cap) &&
+           !std::getenv("ICV_FORCE_GENERIC") && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16") && p.B == 10 &&
+           p.window == 100;
 }
 
 // float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
@@ -355,7 +369,8 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     // kernel, one 1024-thread workgroup per CU (ICV_NO_X16=1: developer knob, previous generation)
     void (*xk)(const icv::KParams) = nullptr;
     if (!csr && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16")) {
-        if (p.B == 10 && p.window == 100 && p.NB <= 2 * icv::XT) xk = icv::k_smooth_x16<2, 2, 10, 10>;
+        if (p.B == 10 && p.window == 100)
+            xk = K.chunk_part ? icv::k_smooth_x16<10, 10, true> : icv::k_smooth_x16<10, 10, false>;
     }
     if (xk) {
         icv::KParams X = K;
@@ -367,8 +382,9 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         rc = run_kernel(xk, gx, p.x16_lds, X, st, icv::XT);
         if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
         if (rc) return rc;
-        hipLaunchKernelGGL(icv::k_stats_finish_n, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
-                           K.cell_part, K.n_rows, icv::XWAVE, K.cell_stats);
+        if (!K.chunk_part)
+            hipLaunchKernelGGL(icv::k_stats_finish_n, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
+                               K.cell_part, K.n_rows, icv::XWAVE, K.cell_stats);
     } else {
         rc = run_kernel(kern, grid, p.fast_lds, K, st);
         if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
@@ -598,6 +614,8 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_cell_part);
+        (void)hipFree(pl->d_chunk_part);
+        (void)hipFree(pl->d_hb_stats);
         (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_zrow);
@@ -738,7 +756,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     int rc = check_matrix(pl, m);
     if (rc) return rc;
     const bool do_thr = !std::isnan(dynamic_threshold);
-    if (!cell_median || !cell_stats) return fail(ICV_ERR_INVALID, "cell_median and cell_stats are required");
+    if (!cell_median) return fail(ICV_ERR_INVALID, "cell_median is required");
     if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
         return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");
     if ((rc = ensure_device(pl))) return rc;
@@ -747,6 +765,43 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
         return rc;
+    // cell_stats == NULL: the caller only wants the thresholds.  The per-row moments then live in a plan-owned
+    // buffer, and where k_smooth_x16 runs they are not formed per cell at all: the kernel accumulates them per
+    // chunk (one wavefront reduction per chunk instead of per cell).
+    bool chunk_mode = false;
+    int64_t n_chunks = 1, cs_eff = m->n_rows > 0 ? m->n_rows : 1, ph_eff = 0;
+    if (do_thr) {
+        cs_eff = chunksize;
+        ph_eff = row_phase;
+        n_chunks = (m->n_rows + row_phase + chunksize - 1) / chunksize;
+        if (n_chunks < 1) n_chunks = 1;
+    }
+    if (!cell_stats && m->n_rows > 0) {
+        if (pl->hb_stats_cap < m->n_rows) {
+            (void)hipFree(pl->d_hb_stats);
+            pl->d_hb_stats = nullptr;
+            pl->hb_stats_cap = 0;
+            HIP_TRY(hipMalloc((void**)&pl->d_hb_stats, (size_t)m->n_rows * 2 * sizeof(double)));
+            pl->hb_stats_cap = m->n_rows;
+        }
+        K.cell_stats = pl->d_hb_stats;
+        const int64_t n_part = (int64_t)pl->n_cu * icv::XWAVE;
+        if (x16_applies(pl, m, K, *lay) && n_chunks * n_part <= (int64_t)(64 << 20) / 16) {
+            chunk_mode = true;
+            if (pl->chunk_part_cap < n_chunks * n_part) {
+                (void)hipFree(pl->d_chunk_part);
+                pl->d_chunk_part = nullptr;
+                pl->chunk_part_cap = 0;
+                HIP_TRY(hipMalloc((void**)&pl->d_chunk_part, (size_t)(n_chunks * n_part) * 2 * sizeof(double)));
+                pl->chunk_part_cap = n_chunks * n_part;
+            }
+            HIP_TRY(hipMemsetAsync(pl->d_chunk_part, 0, (size_t)(n_chunks * n_part) * 2 * sizeof(double), st));
+            HIP_TRY(hipMemsetAsync(pl->d_hb_stats, 0, (size_t)m->n_rows * 2 * sizeof(double), st));
+            K.chunk_part = pl->d_chunk_part;
+            K.chunksize = cs_eff;
+            K.row_phase = ph_eff;
+        }
+    }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     const bool deferred = !prof && pl->prof_deferred;
     const bool timed = prof || deferred;
@@ -757,8 +812,16 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     bool ev1_done = false;
     if ((rc = launch_smooth(pl, m, K, *lay, st, timed ? ev[1] : nullptr, &ev1_done))) return rc;
     if (timed && !ev1_done) HIP_TRY(hipEventRecord(ev[1], st));
-    if (do_thr) {
-        rc = icv_chunk_thresholds(cell_stats, m->n_rows, chunksize, row_phase, pl->p.W, dynamic_threshold, thr,
+    if (do_thr && chunk_mode) {
+        // workgroups of the x16 launch: min(CUs, rows); slots of absent workgroups are zero
+        int64_t gx = pl->n_cu;
+        if (gx > m->n_rows) gx = m->n_rows;
+        hipLaunchKernelGGL(icv::k_chunk_thr_part, dim3((unsigned)n_chunks), dim3(256), 0, st, pl->d_chunk_part,
+                           (int)(gx * icv::XWAVE), pl->d_hb_stats, m->n_rows, chunksize, row_phase, pl->p.W,
+                           dynamic_threshold, thr);
+        HIP_TRY(hipGetLastError());
+    } else if (do_thr && m->n_rows > 0) {
+        rc = icv_chunk_thresholds(K.cell_stats, m->n_rows, chunksize, row_phase, pl->p.W, dynamic_threshold, thr,
                                   stream);
         if (rc) return rc;
     }

@@ -1,47 +1,56 @@
 // k_smooth_x16: the dense float32 smoothing kernel as ONE 1024-thread workgroup (16 wavefronts) per CU.
 //
-// Why (round-1 measurements): with two 512-thread workgroups per CU the cell time was the serial
-// chain of one workgroup (S, W, median, output: latency-bound at 8 wavefronts) and the L phase was five L2 round
-// trips for the reference row and the scatter table.  Here
-//   * all 16 wavefronts run the same phase, so every phase is bound by a pipe (float64 VALU, LDS), not by latency;
-//   * the reference row (20 VGPRs), the scatter table (10 VGPRs) and the window descriptors (2 VGPRs) of a thread
-//     are loaded ONCE per kernel: no table traffic per cell, the only VMEM loads of the loop are the row prefetch;
-//   * the row being processed lives in LDS, the next one is in flight in registers (5 x 16 B per lane = 80 KB per
-//     CU, re-requested vector by vector as it is consumed);
-//   * row, {S0,S1}, histogram are separate LDS regions (122 KB of 160 KB): nothing aliases, TWO barriers per cell;
-//   * the median of a cell is resolved in the slack of the next three cells (windows triple buffered in
-//     registers): histogram scan (A of cell+1), bin location (B of cell+1), candidate gather (A of cell+2), exact
-//     float64 ranking by one wavefront (B of cell+2), x_res output (A of cell+3).
+// Round-2 measurements (profiles/r02_microbench_ops.txt): on gfx950 every VALU instruction -- float32 VOP3, SDWA,
+// DPP, float64 alike -- costs ~4.7 cycles of a SIMD's issue (v_add_f32: 2.8), float64 MFMA shares the float64 VALU
+// datapath, and the previous kernel issued ~5 800 VALU wave-instructions per cell: the smoothing kernel is bound by
+// VALU INSTRUCTION COUNT, not by HBM and not by LDS.  This kernel is built around that:
+//   * the reference row (20 VGPRs), the scatter table (10 VGPRs) and the window descriptors of a thread are loaded
+//     ONCE per kernel: no per-cell table loads or address unpacking beyond one SDWA shift per gene;
+//   * all 16 wavefronts run the same phase; row, {S0,S1} and the histograms are separate LDS regions (149 KB of
+//     160 KB), nothing aliases, TWO barriers per cell;
+//   * a thread sums two adjacent blocks per S pass (16-byte LDS reads) and the windows t, t + W/2 (conflict-free
+//     {S0,S1} reads, whole wavefronts idle instead of half-masked ones);
+//   * median: a 4096-bin histogram (32-bit LDS atomics) plus a 64-bin coarse histogram (4 replicas) -- ONE
+//     wavefront resolves the two middle ranks with two 64-lane DPP prefix sums (coarse, then the 64 fine bins of
+//     the located coarse bin), the windows of those bins are gathered, one wavefront ranks them exactly in
+//     float64; all of it runs in the shadow of the next two cells (windows double buffered in registers);
+//   * the row in LDS is being processed while the next one is in flight in registers (5 x 16 B per lane = 80 KB
+//     per CU, re-requested vector by vector as it is consumed).
 //
-//   iteration `it` of a workgroup (cell k = blockIdx.x + it * gridDim.x):
-//     phase A   output(it-3) | gather(it-2) | histogram scan(it-1) | S(it): LDS row -> {S0,S1} per block
+//   iteration `it` of a workgroup (cell = blockIdx.x + it * gridDim.x), p = it & 1:
+//     phase A   S(it): LDS row -> {S0,S1} per block | wavefront 0: histogram scan(it-1) | wavefront 1: rank(it-2)
 //     barrier 1
-//     phase B   rank(it-2) | locate(it-1) | W(it): windows from {S0,S1}, histogram atomics
+//     phase B   output(it-2) | gather(it-1), clear histogram(it-1) | W(it): windows, histogram atomics
 //               | L(it+1): centre, clip, scatter the prefetched row; re-request the row of it+2
 //     barrier 2
 //
 // Arithmetic and evaluation order of windows and median are those of k_smooth (bit-identical x_res and medians);
-// the per-cell moments are reduced over 16 wavefront partials instead of 8 (last-bit differences in the sums).
+// the per-cell moments are reduced over 16 wavefront partials (last-bit differences in the sums).
 // Geometry: float32 dense, one reference row, block form with compile-time block size, G <= 20 480 columns,
-// blocks <= MAXB * 1024, windows <= MAXW * 1024.  Everything else runs k_smooth_ws / k_smooth.
+// blocks <= 2048, windows <= 2048.  Everything else runs k_smooth_ws / k_smooth.
 #pragma once
 #include "icv_kernel_ws.hpp"
+#include "icv_plan.hpp"
 
 namespace icv {
 
 constexpr int XT = 1024;
 constexpr int XWAVE = XT / 64;
-constexpr int XU = 5;  // 16-byte row vectors per thread
+constexpr int XU = 5;        // 16-byte row vectors per thread
+constexpr int XFINE = 4096;  // fine histogram bins (32-bit counters), same binning as k_smooth_ws
+constexpr int XCOARSE = 64;  // coarse bin = fine bin >> 6
+constexpr int XREP = 16;     // replicas of every coarse bin (lane & 15), adjacent in LDS: lanes of one atomic
+                             // instruction that share a coarse bin hit different banks
+static_assert(XREP * XCOARSE == XT && kX16HistBytes == 2 * (XFINE * 4 + XREP * XCOARSE * 4), "plan and kernel agree on the histogram bytes");
 
 struct ScratchX {
-    int wtot[2][XWAVE];  // histogram scan: windows in the 256 bins of each wavefront, by cell parity
-    int sel[2][8];       // located bins of the two middle ranks: b1, b2, below, c1, c2, nan
+    int sel[2][8];  // located bins of the two middle ranks: b1, b2, below, c1, c2, nan
     int ncand[2];
     int nanflag[2];
-    double med[2][2];    // the two middle order statistics
+    double med[2][2];  // the two middle order statistics
     double cand[2][64];
 };
-static_assert(sizeof(ScratchX) <= 1536, "ScratchX must fit the scratch region");
+static_assert(sizeof(ScratchX) <= 1280, "ScratchX must fit the scratch region");
 
 // both moments of a cell reduced over the wavefront at once: the first level moves the sum partials to lanes
 // 0..31 and the sum-of-squares partials to lanes 32..63 (v_permlane32_swap), four DPP levels finish both.
@@ -59,27 +68,56 @@ __device__ __forceinline__ double2 wave_moments(double sum, double sq) {
     return make_double2(readlane_d(v, 0) + readlane_d(v, 16), readlane_d(v, 32) + readlane_d(v, 48));
 }
 
-#ifndef ICV_X_WFIRST
-#define ICV_X_WFIRST 1  // phase B order: 1 = every wavefront W then L; 2 = odd wavefronts L then W (pipes mixed)
-#endif
+// Monotone non-decreasing map window value -> fine bin, the k_smooth_ws binning with the scale folded into one
+// FMA and floor + convert in one instruction (v_cvt_flr_i32_f32): 5 VALU for the central segment.
+__device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_scale, float c_thr) {
+    const float f = (float)v;
+    if (__builtin_expect(fabsf(f) < c_thr, 1)) {  // |u| < 1/8: 3072 bins
+        int b;
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(fmaf(f, c_scale, 2048.0f)));
+        return b < 512 ? 512 : (b > 3583 ? 3583 : b);  // segments stay disjoint under rounding
+    }
+    const float u = f * inv_bound;
+    float g;
+    int lo_b, hi_b;
+    if (u < 0.0f) { g = (u + 1.0f) * (512.0f / 0.875f); lo_b = 0; hi_b = 511; }
+    else { g = fmaf(u - 0.125f, 512.0f / 0.875f, 3584.0f); lo_b = 3584; hi_b = XFINE - 1; }
+    const int b = (int)floorf(g);  // NaN -> 0 after the clamps; the cell is flagged separately
+    return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);
+}
+
 #ifndef ICV_X_WCH
-#define ICV_X_WCH 5  // {S0,S1} pairs of a window read per batch
+#define ICV_X_WCH 2  // {S0,S1} pairs of a window read per batch (register budget: 5 spills next to the resident tables)
+#endif
+#ifndef ICV_X_PRIO
+#define ICV_X_PRIO 0  // wave priority experiments: 1 static by age (youngest first), 2 rotating per iteration
+#endif
+#ifndef ICV_X_LFIRST
+#define ICV_X_LFIRST 0  // 1: odd wavefronts run L before W in phase B (LDS-write-bound next to float64-bound work)
+#endif
+#ifndef ICV_X_ADDR
+#define ICV_X_ADDR 1  // 1: LDS byte addresses of the scatter resident (20 VGPRs) instead of the packed table (10)
 #endif
 
-template <int MAXB, int MAXW, int BT, int NBW>
+// CHUNK: the moments of x_res are accumulated per thread over the consecutive cells of a noise-threshold chunk and
+// reduced once per chunk (P.chunk_part), instead of one 16-wavefront reduction per cell (P.cell_part)
+template <int BT, int NBW, bool CHUNK>
 __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* row = reinterpret_cast<float*>(smem);
     double* S01 = reinterpret_cast<double*>(smem + P.win_off);
-    int* hist = reinterpret_cast<int*>(smem + P.hist_off);
+    unsigned* hist = reinterpret_cast<unsigned*>(smem + P.hist_off);  // [2][XFINE] fine, then [2][XREP][XCOARSE]
+    unsigned* coarse = hist + 2 * XFINE;
     ScratchX* sc = reinterpret_cast<ScratchX*>(smem + P.scratch_off);
-    static_assert(NBIN == 4 * XT, "the histogram scan gives every thread 4 bins");
-    static_assert(BT > 0 && NBW > 0 && NBW % 2 == 0, "compile-time block size and blocks per window");
+    float* stage = reinterpret_cast<float*>(smem + P.scratch_off + kFastScratchBytes);  // x_res of one cell (16-byte stores)
+    static_assert(BT >= 2 && (BT & 1) == 0 && NBW > 0 && NBW % 2 == 0, "even compile-time block size");
+    static_assert((2 * BT * 4) % 16 == 0, "a thread's two blocks are read as 16-byte vectors");
 
     const int t = threadIdx.x;
     const int W = P.W, NB = P.NB;
     const int k1 = (W - 1) / 2, k2 = W / 2;
     const float inv_bound = (float)(1.0 / P.med_bound);
+    const float c_scale = inv_bound * (3072.0f / 0.25f), c_thr = 0.125f * (float)P.med_bound;
     const float cap = (float)P.cap;
     const unsigned row_bytes = (unsigned)P.n_cols * 4u;
     const unsigned voff = (unsigned)t * 16u;
@@ -92,28 +130,49 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 
     // ---- per-thread constants, loaded once -------------------------------------------------------
     u32x4 refv[XU];
+#if ICV_X_ADDR
+    unsigned laddr[XU][4];
+#else
     u32x2 dtab[XU];
+#endif
     {
         const __amdgpu_buffer_rsrc_t lo_rs = make_rsrc(P.ref_lo, row_bytes);
         const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(XU * XT * 8));
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             refv[u] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * XT * 16, 0);
-            dtab[u] = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, (unsigned)t * 8u, u * XT * 8, 0);
+            const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, (unsigned)t * 8u, u * XT * 8, 0);
+#if ICV_X_ADDR
+#ifdef ICV_X_EXP_LINSCAT  // timing experiment (wrong results): conflict-free scatter addresses
+            laddr[u][0] = ((unsigned)(u * 4 + 0) * 1000u + (unsigned)t) * 4u;
+            laddr[u][1] = ((unsigned)(u * 4 + 1) * 1000u + (unsigned)t) * 4u;
+            laddr[u][2] = ((unsigned)(u * 4 + 2) * 1000u + (unsigned)t) * 4u;
+            laddr[u][3] = ((unsigned)(u * 4 + 3) * 1000u + (unsigned)t) * 4u;
+            if (t >= 1000) laddr[u][0] = laddr[u][1] = laddr[u][2] = laddr[u][3] = 80000u;
+            (void)d;
+#else
+            laddr[u][0] = (d.x & 0xffffu) * 4u;
+            laddr[u][1] = (d.x >> 16) * 4u;
+            laddr[u][2] = (d.y & 0xffffu) * 4u;
+            laddr[u][3] = (d.y >> 16) * 4u;
+#endif
+#else
+            dtab[u] = d;
+#endif
         }
     }
-    int wdesc[MAXW];   // (start block) | (len << 16); a thread's missing window repeats its first one
-    bool wfull = true; // every window of this wavefront is a full pyramid window
-#pragma unroll
-    for (int i = 0; i < MAXW; ++i) {
-        const int j = t + i * XT;
-        wdesc[i] = P.w_pack[j < W ? j : (t < W ? t : 0)];
-        wfull &= (wdesc[i] >> 16) == NBW * BT;
-    }
-    wfull = __builtin_amdgcn_ballot_w64(!wfull) == 0;
+    // windows t, t + WH: LDS byte offset of the first {S0,S1} pair, validity, "every valid window of the wavefront
+    // is a full pyramid window" (a missing window repeats window 2t, or window 0)
+    const int WH = (W + 1) / 2;  // thread t owns windows t and t + WH
+    const bool valid0 = t < WH, valid1 = t + WH < W;
+    const int wd0 = P.w_pack[valid0 ? t : 0], wd1 = P.w_pack[valid1 ? t + WH : (valid0 ? t : 0)];
+    const unsigned sp0 = (unsigned)P.win_off + (unsigned)(wd0 & 0xffff) * 16u;
+    const unsigned sp1 = (unsigned)P.win_off + (unsigned)(wd1 & 0xffff) * 16u;
+    const bool wave_w = __builtin_amdgcn_ballot_w64(valid0) != 0;  // the wavefront has windows at all
+    const bool wfull = __builtin_amdgcn_ballot_w64((wd0 >> 16) != NBW * BT || (wd1 >> 16) != NBW * BT) == 0;
     // pad slots and the trash slot are written once: nothing aliases the row
     for (int i = t; i < P.n_pad; i += XT) row[P.pad_idx[i]] = 0.0f;
-    for (int i = t; i < NBIN / 2; i += XT) hist[i] = 0;
+    for (int i = t; i < kX16HistBytes / 4; i += XT) hist[i] = 0u;
     if (t < 2) {
         sc->ncand[t] = 0;
         sc->nanflag[t] = 0;
@@ -121,6 +180,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         sc->med[t][1] = 0.0;
     }
     if (t < 16) sc->sel[t >> 3][t & 7] = 0;
+    // x_res leaves the CU as 16-byte stores (store ISSUE, not bytes, is what a narrow store costs: -10 % kernel time
+    // against two 4-byte stores per thread): needs 16-byte aligned rows
+    const bool st16 = ((P.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0);
+    for (int i = t; i < ((W + 3) & ~3); i += XT) stage[i] = 0.0f;
 
     u32x4 xq[XU];
     {
@@ -131,10 +194,20 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     unsigned two = 2u;
     asm volatile("" : "+v"(two));  // a VGPR operand for the SDWA shifts
 
-    // centre, clip and scatter the row in xq (cell `c_row`), then re-request every vector for cell `c_next`
+    // centre, clip and scatter the row in xq, re-requesting every vector for cell `c_next` as it is consumed
     auto l_phase = [&](int64_t c_next) __attribute__((always_inline)) {
         const bool more = c_next < P.n_rows;
+#ifdef ICV_X_EXP_NOLOAD  // timing experiment (wrong results): no HBM row traffic, the first row is reused
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase, 0u);
+        (void)more;
+        (void)xr;
+#else
+#ifdef ICV_X_EXP_L2ROW  // timing experiment (wrong results): every cell re-reads the workgroup's first row (L2 hits)
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, more ? row_bytes : 0u);
+#else
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (more ? c_next : 0) * P.ld, more ? row_bytes : 0u);
+#endif
+#endif
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const float y0 = __uint_as_float(xq[u].x) - __uint_as_float(refv[u].x);
@@ -143,6 +216,18 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             const float y3 = __uint_as_float(xq[u].w) - __uint_as_float(refv[u].w);
             // v_med3 drops NaNs, np.clip keeps them: unordered pairs take the (never taken on real data) fix-up
             const bool un = __builtin_isunordered(y0, y1) | __builtin_isunordered(y2, y3);
+#if ICV_X_ADDR
+            ICV_LDS_F32_AT(laddr[u][0]) = __builtin_amdgcn_fmed3f(y0, -cap, cap);
+            ICV_LDS_F32_AT(laddr[u][1]) = __builtin_amdgcn_fmed3f(y1, -cap, cap);
+            ICV_LDS_F32_AT(laddr[u][2]) = __builtin_amdgcn_fmed3f(y2, -cap, cap);
+            ICV_LDS_F32_AT(laddr[u][3]) = __builtin_amdgcn_fmed3f(y3, -cap, cap);
+            if (__builtin_expect(un, 0)) {
+                if (y0 != y0) ICV_LDS_F32_AT(laddr[u][0]) = y0;
+                if (y1 != y1) ICV_LDS_F32_AT(laddr[u][1]) = y1;
+                if (y2 != y2) ICV_LDS_F32_AT(laddr[u][2]) = y2;
+                if (y3 != y3) ICV_LDS_F32_AT(laddr[u][3]) = y3;
+            }
+#else
             ICV_LDS_F32_AT(lds_off_lo16(dtab[u].x, two)) = __builtin_amdgcn_fmed3f(y0, -cap, cap);
             ICV_LDS_F32_AT(lds_off_hi16(dtab[u].x, two)) = __builtin_amdgcn_fmed3f(y1, -cap, cap);
             ICV_LDS_F32_AT(lds_off_lo16(dtab[u].y, two)) = __builtin_amdgcn_fmed3f(y2, -cap, cap);
@@ -155,305 +240,409 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 if (y2 != y2) row[dy & 0xffffu] = y2;
                 if (y3 != y3) row[dy >> 16] = y3;
             }
+#endif
+#ifndef ICV_X_EXP_NOLOAD
             xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, 0);  // out of range: zeros, no traffic
+#else
+            asm volatile("" : "+v"(xq[u]));
+#endif
         }
     };
 
+#if ICV_X_PRIO == 1  // static: the younger wavefronts of a SIMD (arbitration losers at equal priority) go first
+    if ((t >> 8) == 0) __builtin_amdgcn_s_setprio(0);
+    else if ((t >> 8) == 1) __builtin_amdgcn_s_setprio(1);
+    else if ((t >> 8) == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#endif
     // the first row is scattered before the loop; its successor is requested right away
     l_phase((int64_t)blockIdx.x + gridDim.x);
 
-    double wv0[MAXW], wv1[MAXW], wv2[MAXW];  // windows of cells it, it-1, it-2 (after the rotation in phase B)
-    unsigned wb0 = 0, wb1 = 0;               // their histogram bins, 16 bits each (MAXW == 2)
-    static_assert(MAXW == 2, "two windows per thread: bins packed in one register");
-#pragma unroll
-    for (int i = 0; i < MAXW; ++i) wv0[i] = wv1[i] = wv2[i] = 0.0;
+    // windows 2t, 2t+1 of cells of even / odd iteration (double buffered), and their fine bins (-1: no window)
+    double wvE0 = 0.0, wvE1 = 0.0, wvO0 = 0.0, wvO1 = 0.0;
+    int wbE0 = -1, wbE1 = -1, wbO0 = -1, wbO1 = -1;
     __syncthreads();
 
 #ifdef ICV_X_PROFILE
-    unsigned long long tlast = 0, tacc[4] = {0, 0, 0, 0};
+#ifndef ICV_X_PROFILE_T
+#define ICV_X_PROFILE_T 320
+#endif
+    // phase timers of one wavefront, accumulated in LDS (no registers held across the loop)
+    unsigned long long* tacc = reinterpret_cast<unsigned long long*>(smem + P.scratch_off + 1280);
+    if (t == ICV_X_PROFILE_T)
+        for (int i = 0; i < 9; ++i) tacc[i] = 0;
 #define ICV_XPH(i)                                              \
-    if (P.dbg && t == 64) {                                     \
+    if (P.dbg && t == ICV_X_PROFILE_T) {                        \
         unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tacc[i] += now_ - tlast;                                \
-        tlast = now_;                                           \
+        tacc[i] += now_ - tacc[8];                              \
+        tacc[8] = now_;                                         \
     }
-    if (P.dbg && t == 64) tlast = __builtin_amdgcn_s_memtime();
+    if (P.dbg && t == ICV_X_PROFILE_T) tacc[8] = __builtin_amdgcn_s_memtime();
 #else
 #define ICV_XPH(i)
 #endif
 
-    for (int64_t it = 0; it < n_mine + 3; ++it) {
+    // CHUNK: running moments of this thread's windows over the cells of the current chunk
+    double accS = 0.0, accQ = 0.0;
+    int64_t chunk_cur = -1, chunk_end = INT64_MIN;
+    (void)accS;
+    (void)accQ;
+    (void)chunk_cur;
+    (void)chunk_end;
+    // one iteration; wvA/wbA: registers of cells with the parity of `it`, wvB/wbB: the other parity
+    auto iteration = [&](int64_t it, int p0, double& wvA0, double& wvA1, int& wbA0, int& wbA1, double& wvB0, double& wvB1,
+                         int& wbB0, int& wbB1) __attribute__((always_inline)) {
+        const int p1 = p0 ^ 1;
         const int64_t cell = (int64_t)blockIdx.x + it * gridDim.x;
-        const bool have0 = it < n_mine;                      // cell it: S and W
-        const bool have1 = it >= 1 && it - 1 < n_mine;       // cell it-1: scan, locate
-        const bool have2 = it >= 2 && it - 2 < n_mine;       // cell it-2: gather, rank
-        const bool have3 = it >= 3;                          // cell it-3: output
-        const int p0 = (int)(it & 1), p1 = p0 ^ 1;           // parity of cells it / it-2, and it-1 / it-3
+        const bool have0 = it < n_mine;                 // cell it: S, W
+        const bool have1 = it >= 1 && it - 1 < n_mine;  // cell it-1: scan, gather
+        const bool have2 = it >= 2 && it - 2 < n_mine;  // cell it-2: rank, output
         int tl = t;
         asm volatile("" : "+v"(tl));  // keep thread-derived addresses and predicates out of LICM (register budget)
 
         // =============================== phase A ================================================
-        if (have3) {
-            // ---- x_res of cell it-3 from its windows (wv2), moments, median --------------------
-            const int64_t pcell = cell - 3 * (int64_t)gridDim.x;
-            const double2 mm = *reinterpret_cast<const double2*>(sc->med[p1]);
-            const double med = (k1 == k2) ? mm.x : (mm.x + mm.y) / 2.0;
-            double sum = 0.0, sq = 0.0;
-            float* orow = P.out + pcell * P.ldo;
-#pragma unroll
-            for (int i = 0; i < MAXW; ++i) {
-                const int j = tl + i * XT;
-                if (j < W) {
-                    const double y = wv2[i] - med;
-                    orow[j] = (float)y;
-                    sum = sum + y;
-                    sq = fma(y, y, sq);
-                }
-            }
-            const double2 mo = wave_moments(sum, sq);
-            if ((tl & 63) == 0) reinterpret_cast<double2*>(P.cell_part)[pcell * XWAVE + (tl >> 6)] = mo;
-            if (tl == 0) P.cell_median[pcell] = med;
-        }
-        if (have2) {
-            // ---- windows of cell it-2 (wv1) in the bins of its two middle ranks -> cand[] ------
-            const int4 s = *reinterpret_cast<const int4*>(sc->sel[p0]);  // b1, b2, below, c1
-            const int2 s2 = *reinterpret_cast<const int2*>(sc->sel[p0] + 4);  // c2, nan
-            const int nin = s.w + (s.y != s.x ? s2.x : 0);
-            if (!s2.y) {
-                if (nin <= 64) {
-                    const unsigned bA = wb1 & 0xffffu, bB = wb1 >> 16;
-                    const bool hA = (tl < W) & ((int)bA == s.x | (int)bA == s.y);
-                    const bool hB = (tl + XT < W) & ((int)bB == s.x | (int)bB == s.y);
-                    if (__builtin_amdgcn_ballot_w64(hA | hB)) {
-                        if (hA) {
-                            const int idx = atomicAdd(&sc->ncand[p0], 1);
-                            if (idx < 64) sc->cand[p0][idx] = wv1[0];
-                        }
-                        if (hB) {
-                            const int idx = atomicAdd(&sc->ncand[p0], 1);
-                            if (idx < 64) sc->cand[p0][idx] = wv1[1];
-                        }
-                    }
-                } else if (tl == 0) {
-                    // too many windows share the median bins: the generic kernel recomputes the cell
-                    const int slot = atomicAdd(P.row_count, 1);
-                    P.row_list[slot] = cell - 2 * (int64_t)gridDim.x;
-                }
+        const int ts = tl - XT / 2;  // wavefronts 8..15 (wavefronts 0, 1 carry the median chains of this phase)
+#ifdef ICV_X_EXP_NOSTORE
+        if (st16 && it >= 3 && ts >= 0 && 4 * ts < W && P.dbg) {
+#else
+        if (st16 && it >= 3 && ts >= 0 && 4 * ts < W) {
+#endif
+            // ---- x_res of cell it-3, staged in LDS by phase B of the previous iteration: one 16-byte store ----
+            float* orow = P.out + (cell - 3 * (int64_t)gridDim.x) * P.ldo;
+            const float4 q = *reinterpret_cast<const float4*>(stage + 4 * ts);
+            if (4 * ts + 4 <= W) {
+                *reinterpret_cast<float4*>(orow + 4 * ts) = q;
+            } else {
+                orow[4 * ts] = q.x;
+                if (4 * ts + 1 < W) orow[4 * ts + 1] = q.y;
+                if (4 * ts + 2 < W) orow[4 * ts + 2] = q.z;
             }
         }
-        int2 hv = make_int2(0, 0);
-        int htot = 0, hincl = 0, nanf = 0;
-        if (have1) {
-            // ---- histogram of cell it-1: 4 bins per thread, wavefront prefix sums, clear -------
-            nanf = sc->nanflag[p1];
-            hv = reinterpret_cast<const int2*>(hist)[tl];
-            reinterpret_cast<int2*>(hist)[tl] = make_int2(0, 0);
-            const int s = hv.x + hv.y;  // no carry between halves: counts <= W < 65536
-            htot = (s & 0xffff) + ((unsigned)s >> 16);
-            hincl = wave_scan_dpp(htot);
-            if ((tl & 63) == 63) sc->wtot[p1][tl >> 6] = hincl;
-        }
-        if (have0) {
-            // ---- S: block partial sums of cell it, straight into their own LDS region ----------
-#pragma unroll
-            for (int i = 0; i < MAXB; ++i) {
-                const int b = tl + i * XT;
-                if (b < NB) {
-                    double s0 = 0.0, s1 = 0.0;
-                    const float* rp = row + b * BT;
-                    if constexpr ((BT & 1) == 0) {
-                        const float2* rp2 = reinterpret_cast<const float2*>(rp);
-                        float2 v2[BT / 2];
-#pragma unroll
-                        for (int r = 0; r < BT / 2; ++r) v2[r] = rp2[r];
-#pragma unroll
-                        for (int r = 0; r < BT / 2; ++r) {
-                            block_accumulate((double)v2[r].x, 2 * r, s0, s1);
-                            block_accumulate((double)v2[r].y, 2 * r + 1, s0, s1);
-                        }
-                    } else {
-                        float v1[BT];
-#pragma unroll
-                        for (int r = 0; r < BT; ++r) v1[r] = rp[r];
-#pragma unroll
-                        for (int r = 0; r < BT; ++r) block_accumulate((double)v1[r], r, s0, s1);
-                    }
-                    *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0, s1);
-                }
-            }
-        }
-        ICV_XPH(0)
-        __syncthreads();  // barrier 1: {S0,S1} of cell it complete, row dead; scan totals / candidates published
-        ICV_XPH(1)
-        asm volatile("" : "+v"(tl));
-
-        // =============================== phase B ================================================
-        if (have2 && tl < 64) {
-            // ---- exact float64 ranks of the <= 64 candidates of cell it-2: one wavefront --------
-            const int4 s = *reinterpret_cast<const int4*>(sc->sel[p0]);
-            const int2 s2 = *reinterpret_cast<const int2*>(sc->sel[p0] + 4);
-            const int nin = s.w + (s.y != s.x ? s2.x : 0);
-            double ma = 0.0, mb = 0.0;  // handed-back cell: placeholder, rewritten by k_smooth
-            if (s2.y) {
-                ma = mb = __builtin_nan("");
-            } else if (nin <= 64) {
-                const int n = sc->ncand[p0] < 64 ? sc->ncand[p0] : 64;
-                const double mine = (tl < n) ? sc->cand[p0][tl] : __builtin_inf();
-                int r = 0;
-                for (int q = 0; q < n; ++q) {  // n is wavefront-uniform (typically 2..4)
-                    const double o = readlane_d(mine, q);
-                    r += (int)(o < mine) | ((int)(o == mine) & (int)(q < tl));
-                }
-                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(tl < n && r == k1 - s.z);
-                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(tl < n && r == k2 - s.z);
-                ma = readlane_d(mine, m1 ? (int)__builtin_ctzll(m1) : 0);
-                mb = readlane_d(mine, m2 ? (int)__builtin_ctzll(m2) : 0);
-            }
-            if (tl == 0) {
-                *reinterpret_cast<double2*>(sc->med[p0]) = make_double2(ma, mb);
-                sc->ncand[p0] = 0;
-            }
-        }
-        if (have1) {
-            // ---- locate the bins of ranks k1, k2 of cell it-1 (the wavefront(s) that hold them) --
+        ICV_XPH(6)
+        // the two single-wavefront chains (LDS round trips, DPP scans, lane reads: ~1000 cycles of latency each) run
+        // on wavefronts 0 and 1, which take no part in the S phase; their SIMDs' share of the block sums goes to
+        // wavefronts 4 and 5 (two passes), so every SIMD issues four S passes
+        if (have1 && tl < 64) {
+            // ---- wavefront 0: the bins of the two middle ranks of cell it-1 -----------------------
+            // (all LDS reads of a step are issued together: one round trip, not one per use)
+            const unsigned* cz = coarse + p1 * (XREP * XCOARSE);
+            const unsigned* fz = hist + p1 * XFINE;
+            const uint4* c4 = reinterpret_cast<const uint4*>(cz + tl * XREP);
+            const int nanf = sc->nanflag[p1];
+            const uint4 ca = c4[0], cb = c4[1], cc = c4[2], cd = c4[3];
             if (nanf) {
                 if (tl == 0) {
                     sc->nanflag[p1] = 0;
                     sc->sel[p1][5] = 1;
                 }
             } else {
-                const int lane = tl & 63;
-                const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
-                int pre = sc->wtot[p1][lane & 15];
-                pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, false);
-                pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, false);
-                pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, false);
-                pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, false);
-                const int mine = __builtin_amdgcn_readlane(hincl, 63);
-                const int base = __builtin_amdgcn_readlane(pre, wv_id) - mine;  // windows in lower wavefronts' bins
-                if (tl == 0) sc->sel[p1][5] = 0;
+                const int c = (int)((((ca.x + ca.y) + (ca.z + ca.w)) + ((cb.x + cb.y) + (cb.z + cb.w))) +
+                                    (((cc.x + cc.y) + (cc.z + cc.w)) + ((cd.x + cd.y) + (cd.z + cd.w))));
+                const int cincl = wave_scan_dpp(c);
+                int Cprev = -1, f = 0, fincl = 0;
+                int res[2][3];
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
                     const int k = which == 0 ? k1 : k2;
-                    if (k >= base && k < base + mine) {  // wavefront-uniform
-                        const unsigned long long m = __builtin_amdgcn_ballot_w64(hincl + base > k);
-                        const int L = (int)__builtin_ctzll(m);
-                        const int ex = __builtin_amdgcn_readlane(hincl - htot, L) + base;
-                        const int w0 = __builtin_amdgcn_readlane(hv.x, L), w1 = __builtin_amdgcn_readlane(hv.y, L);
-                        // lanes 0..3: count of bin i of the located group of four, prefix over the 4 lanes
-                        const int word = (lane & 2) == 0 ? w0 : w1;
-                        const int cnt = lane < 4 ? ((word >> ((lane & 1) * 16)) & 0xffff) : 0;
-                        int inc = cnt;
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);
-                        inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);
-                        const unsigned long long mj = __builtin_amdgcn_ballot_w64(lane < 4 && inc + ex > k);
-                        const int j = (int)__builtin_ctzll(mj);
-                        const int bin = ((wv_id << 6) + L) * 4 + j;
-                        const int below = __builtin_amdgcn_readlane(inc - cnt, j) + ex;
-                        const int cj = __builtin_amdgcn_readlane(cnt, j);
-                        if (lane == 0) {
-                            if (which == 0) {
-                                sc->sel[p1][0] = bin;
-                                sc->sel[p1][2] = below;
-                                sc->sel[p1][3] = cj;
-                            } else {
-                                sc->sel[p1][1] = bin;
-                                sc->sel[p1][4] = cj;
-                            }
-                        }
+                    const int C = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(cincl > k));
+                    const int belowC = __builtin_amdgcn_readlane(cincl - c, C);
+                    if (C != Cprev) {  // wavefront-uniform
+                        f = (int)fz[C * 64 + tl];
+                        fincl = wave_scan_dpp(f);
+                        Cprev = C;
                     }
+                    const int j = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(fincl + belowC > k));
+                    res[which][0] = C * 64 + j;
+                    res[which][1] = __builtin_amdgcn_readlane(fincl - f, j) + belowC;
+                    res[which][2] = __builtin_amdgcn_readlane(f, j);
+                }
+                if (tl == 0) {
+                    *reinterpret_cast<int4*>(sc->sel[p1]) = make_int4(res[0][0], res[1][0], res[0][1], res[0][2]);
+                    *reinterpret_cast<int2*>(sc->sel[p1] + 4) = make_int2(res[1][2], 0);
                 }
             }
         }
-        // rotate the window registers: cell it-1 -> wv1, cell it-2 -> wv2
-#pragma unroll
-        for (int i = 0; i < MAXW; ++i) {
-            wv2[i] = wv1[i];
-            wv1[i] = wv0[i];
+        if (have2 && (tl >> 6) == 1) {
+            // ---- wavefront 1: exact float64 ranks of the <= 64 candidates of cell it-2 -------------
+            const int lane = tl & 63;
+            const int4 s = *reinterpret_cast<const int4*>(sc->sel[p0]);       // b1, b2, below, c1
+            const int2 s2 = *reinterpret_cast<const int2*>(sc->sel[p0] + 4);  // c2, nan
+            const int ncr = sc->ncand[p0];
+            const double mine_raw = sc->cand[p0][lane];  // unconditional: one LDS round trip for all four reads
+            const int nin = s.w + (s.y != s.x ? s2.x : 0);
+            double ma = 0.0, mb = 0.0;  // handed-back cell: placeholder, rewritten by k_smooth
+            if (s2.y) {
+                ma = mb = __builtin_nan("");
+            } else if (nin <= 64) {
+                const int n = ncr < 64 ? ncr : 64;
+                const double mine = (lane < n) ? mine_raw : __builtin_inf();
+                int r = 0;
+                for (int q = 0; q < n; ++q) {  // n is wavefront-uniform (typically 2..4)
+                    const double o = readlane_d(mine, q);
+                    r += (int)(o < mine) | ((int)(o == mine) & (int)(q < lane));
+                }
+                const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane < n && r == k1 - s.z);
+                const unsigned long long m2 = __builtin_amdgcn_ballot_w64(lane < n && r == k2 - s.z);
+                ma = readlane_d(mine, m1 ? (int)__builtin_ctzll(m1) : 0);
+                mb = readlane_d(mine, m2 ? (int)__builtin_ctzll(m2) : 0);
+            }
+            if (lane == 0) {
+                *reinterpret_cast<double2*>(sc->med[p0]) = make_double2(ma, mb);
+                sc->ncand[p0] = 0;
+            }
         }
-        wb1 = wb0;
+        ICV_XPH(7)
+        if (have0 && tl >= 128) {
+            // ---- S: block partial sums, straight into their own LDS region.  Pass 0: wavefront w = 2..15 takes the
+            // block pairs 64 (w - 2) + lane; pass 1: wavefronts 4, 5 take the pairs 64 (w + 10) + lane
+            const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
+            const int n_pass = (wv_id == 4 || wv_id == 5) ? 2 : 1;
+            for (int pass = 0; pass < n_pass; ++pass) {
+                const int b = 2 * ((pass == 0 ? tl - 128 : tl + 640));
+                if (b < NB) {
+                    const float4* rp = reinterpret_cast<const float4*>(row + b * BT);
+                    float v[2 * BT];
+#pragma unroll
+                    for (int r = 0; r < 2 * BT / 4; ++r) {
+                        const float4 q = rp[r];
+                        v[4 * r] = q.x;
+                        v[4 * r + 1] = q.y;
+                        v[4 * r + 2] = q.z;
+                        v[4 * r + 3] = q.w;
+                    }
+                    // canonical order of block_accumulate without its two no-ops (0 + v0, fma(0, v0, 0) and
+                    // fma(1, v1, 0)): same values, only the sign of an all-zero sum can differ
+                    double s0a = (double)v[0], s0b = (double)v[BT];
+                    double s1a, s1b;
+                    {
+                        const double a1 = (double)v[1], b1 = (double)v[BT + 1];
+                        s0a = s0a + a1;
+                        s0b = s0b + b1;
+                        s1a = a1;
+                        s1b = b1;
+                    }
+#pragma unroll
+                    for (int r = 2; r < BT; ++r) {
+                        block_accumulate((double)v[r], r, s0a, s1a);
+                        block_accumulate((double)v[BT + r], r, s0b, s1b);
+                    }
+                    double2* sp = reinterpret_cast<double2*>(S01 + 2 * b);
+                    sp[0] = make_double2(s0a, s1a);
+                    if (b + 1 < NB) sp[1] = make_double2(s0b, s1b);
+                }
+            }
+        }
+        ICV_XPH(0)
+        __syncthreads();  // barrier 1: {S0,S1} of cell it complete, row dead; bins / median published
+        ICV_XPH(1)
+        asm volatile("" : "+v"(tl));
+#if ICV_X_PRIO == 2  // rotating: each wavefront of a SIMD is the preferred one in one of four consecutive phases
+        {
+            const int q = (__builtin_amdgcn_readfirstlane(tl >> 8) + (int)(it & 3)) & 3;
+            if (q == 0) __builtin_amdgcn_s_setprio(0);
+            else if (q == 1) __builtin_amdgcn_s_setprio(1);
+            else if (q == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+#endif
 
-        auto w_phase = [&]() __attribute__((always_inline)) {
-            int lnan = 0;
+        // =============================== phase B ================================================
+        // ---- x_res of cell it-2 from its windows (still in wvA): staged in LDS (stored as 16-byte vectors by phase
+        // A of the next iteration) and its moments
+        float yf0 = 0.0f, yf1 = 0.0f;
+        double2 mo = make_double2(0.0, 0.0);
+        double med_out = 0.0;
+        if (have2) {
+            const int64_t pcell = cell - 2 * (int64_t)gridDim.x;
+            const double2 mm = *reinterpret_cast<const double2*>(sc->med[p0]);
+            med_out = (k1 == k2) ? mm.x : (mm.x + mm.y) / 2.0;
+            if constexpr (CHUNK) {
+                if (pcell >= chunk_end) {  // uniform: first cell of this workgroup in a new chunk
+                    if (wave_w && chunk_cur >= 0) {
+                        const double2 m2 = wave_moments(accS, accQ);
+                        if ((tl & 63) == 0)
+                            reinterpret_cast<double2*>(P.chunk_part)[(chunk_cur * gridDim.x + blockIdx.x) * XWAVE + (tl >> 6)] = m2;
+                    }
+                    chunk_cur = (pcell + P.row_phase) / P.chunksize;
+                    chunk_end = (chunk_cur + 1) * P.chunksize - P.row_phase;
+                    accS = 0.0;
+                    accQ = 0.0;
+                }
+            }
+            if (wave_w) {
+                const double y0 = wvA0 - med_out, y1 = wvA1 - med_out;
+                const bool v0 = tl < WH, v1 = tl + WH < W;
+                yf0 = (float)y0;
+                yf1 = (float)y1;
+                if constexpr (CHUNK) {
+                    // a cell handed back to k_smooth (more than 64 windows in the median bins) is accounted there
+                    const int4 s = *reinterpret_cast<const int4*>(sc->sel[p0]);
+                    const int2 s2 = *reinterpret_cast<const int2*>(sc->sel[p0] + 4);
+                    const bool handed = !s2.y && s.w + (s.y != s.x ? s2.x : 0) > 64;
+                    if (!handed) {
+                        if (v0) {
+                            accS = accS + y0;
+                            accQ = fma(y0, y0, accQ);
+                        }
+                        if (v1) {
+                            accS = accS + y1;
+                            accQ = fma(y1, y1, accQ);
+                        }
+                    }
+                } else {
+                    double sum = y0, sq = y0 * y0;
+                    if (v1) {
+                        sum = sum + y1;
+                        sq = fma(y1, y1, sq);
+                    }
+                    if (!v0) sum = sq = 0.0;
+                    mo = wave_moments(sum, sq);
+                }
+                if (st16) {
+                    if (v0) stage[tl] = yf0;
+                    if (v1) stage[tl + WH] = yf1;
+                }
+            }
+        }
+        if (have1) {
+            // ---- windows of cell it-1 (wvB) in the bins of its two middle ranks -> cand[]; no window lies in a
+            // bin strictly between the bins of two adjacent ranks, so "b1 <= bin <= b2" selects exactly those bins
+            const int4 s = *reinterpret_cast<const int4*>(sc->sel[p1]);
+            const int2 s2 = *reinterpret_cast<const int2*>(sc->sel[p1] + 4);
+            const int nin = s.w + (s.y != s.x ? s2.x : 0);
+            if (!s2.y) {
+                if (nin <= 64) {
+                    const unsigned span = (unsigned)(s.y - s.x);
+                    const bool hA = (unsigned)(wbB0 - s.x) <= span, hB = (unsigned)(wbB1 - s.x) <= span;
+                    if (__builtin_amdgcn_ballot_w64(hA | hB)) {
+                        if (hA) {
+                            const int idx = atomicAdd(&sc->ncand[p1], 1);
+                            if (idx < 64) sc->cand[p1][idx] = wvB0;
+                        }
+                        if (hB) {
+                            const int idx = atomicAdd(&sc->ncand[p1], 1);
+                            if (idx < 64) sc->cand[p1][idx] = wvB1;
+                        }
+                    }
+                } else if (tl == 0) {
+                    // too many windows share the median bins: the generic kernel recomputes the cell
+                    const int slot = atomicAdd(P.row_count, 1);
+                    P.row_list[slot] = cell - (int64_t)gridDim.x;
+                }
+            }
+            // clear the histograms of cell it-1 (scanned before barrier 1; next used by W of cell it+1)
+            reinterpret_cast<uint4*>(hist + p1 * XFINE)[tl] = make_uint4(0u, 0u, 0u, 0u);
+            coarse[p1 * (XREP * XCOARSE) + tl] = 0u;
+        }
+        ICV_XPH(4)
+#if ICV_X_LFIRST
+        const bool l_first = (__builtin_amdgcn_readfirstlane(tl >> 6) & 1) != 0;
+        if (l_first && cell + gridDim.x < P.n_rows) l_phase(cell + 2 * (int64_t)gridDim.x);
+#endif
+        if (have0 && wave_w) {
+            // ---- W: windows 2t, 2t+1 of cell it from {S0,S1}, histogram atomics --------------------
+            double v0, v1;
             if (wfull) {
                 // every window of the wavefront is a full pyramid window: no per-window branches, both windows of
                 // the thread advance together (interleaved float64 chains), canonical order inside a window
                 constexpr int HB = NBW / 2;
-                const double2* sp[MAXW];
-                double v[MAXW];
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i) {
-                    sp[i] = reinterpret_cast<const double2*>(S01) + (wdesc[i] & 0xffff);
-                    v[i] = 0.0;
-                }
+                const double2* q0 = reinterpret_cast<const double2*>(smem + sp0);
+                const double2* q1 = reinterpret_cast<const double2*>(smem + sp1);
+                v0 = 0.0;
+                v1 = 0.0;
 #pragma unroll
                 for (int m = 0; m < NBW; ++m) {
-                    double2 sv[MAXW];
-#pragma unroll
-                    for (int i = 0; i < MAXW; ++i) sv[i] = sp[i][m];
-#pragma unroll
-                    for (int i = 0; i < MAXW; ++i)
-                        v[i] = fma((double)(m < HB ? m * BT + 1 : NBW * BT - m * BT), sv[i].x, v[i]);
-#pragma unroll
-                    for (int i = 0; i < MAXW; ++i) v[i] = m < HB ? v[i] + sv[i].y : v[i] - sv[i].y;
+                    const double2 a = q0[m], b = q1[m];
+                    const double wgt = (double)(m < HB ? m * BT + 1 : NBW * BT - m * BT);
+                    v0 = fma(wgt, a.x, v0);
+                    v1 = fma(wgt, b.x, v1);
+                    v0 = m < HB ? v0 + a.y : v0 - a.y;
+                    v1 = m < HB ? v1 + b.y : v1 - b.y;
                     if (m % ICV_X_WCH == ICV_X_WCH - 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
                 }
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i) {
-                    v[i] = finish_window(v[i], NBW * BT, pyr_den, pyr_rcp, 1.0);
-                    const bool valid = tl + i * XT < W;
-                    wv0[i] = valid ? v[i] : 0.0;
-                    lnan |= valid & (v[i] != v[i]);
-                    const int hb = hist_bin(v[i], inv_bound);
-                    wb0 = i ? (wb0 | ((unsigned)hb << 16)) : (unsigned)hb;
-                    if (valid) atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));
-                }
+                v0 = finish_window(v0, NBW * BT, pyr_den, pyr_rcp, 1.0);
+                v1 = finish_window(v1, NBW * BT, pyr_den, pyr_rcp, 1.0);
             } else {
+                double vv[2];
 #pragma unroll
-                for (int i = 0; i < MAXW; ++i) {
-                    const int j = tl + i * XT;
-                    wv0[i] = 0.0;
-                    if (i == 0) wb0 = 0;
-                    if (j < W) {
-                        int wp = wdesc[i];
-                        asm volatile("" : "+v"(wp));  // decode inside the loop (register budget)
-                        const int ln = wp >> 16;
-                        const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
-                        double v = window_from_blocks(ln, BT, [&](int m, double& a, double& b2) {
-                            const double2 s = sp[m];
-                            a = s.x;
-                            b2 = s.y;
-                        });
-                        // flat windows (one per chromosome with <= window genes) read their gene count
-                        v = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
-                        wv0[i] = v;
-                        lnan |= (v != v);
-                        const int hb = hist_bin(v, inv_bound);
-                        wb0 = i ? (wb0 | ((unsigned)hb << 16)) : (unsigned)hb;
-                        atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    int wp = i ? wd1 : wd0;
+                    asm volatile("" : "+v"(wp));  // decode inside the loop (register budget)
+                    const int ln = wp >> 16;
+                    const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
+                    double v = window_from_blocks(ln, BT, [&](int m, double& a, double& b2) {
+                        const double2 s = sp[m];
+                        a = s.x;
+                        b2 = s.y;
+                    });
+                    // flat windows (one per chromosome with <= window genes) read their gene count
+                    const int j = tl + i * WH < W ? tl + i * WH : 0;
+                    vv[i] = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
                 }
+                v0 = vv[0];
+                v1 = vv[1];
             }
-            if (lnan) sc->nanflag[p0] = 1;  // benign race: every writer stores 1
-        };
-
+            wvA0 = v0;
+            wvA1 = v1;
+            const int h0 = hist_bin_x(v0, inv_bound, c_scale, c_thr), h1 = hist_bin_x(v1, inv_bound, c_scale, c_thr);
+            const bool w0 = tl < WH, w1 = tl + WH < W;
+            wbA0 = w0 ? h0 : -1;
+            wbA1 = w1 ? h1 : -1;
+            unsigned* fz = hist + p0 * XFINE;
+            unsigned* cz = coarse + p0 * (XREP * XCOARSE) + (tl & (XREP - 1));
+#ifndef ICV_X_EXP_NOATOM  // timing experiment (wrong medians): 1 = no coarse atomics, 2 = no atomics at all
+#define ICV_X_EXP_NOATOM 0
+#endif
+            if (w0) {
+                if (ICV_X_EXP_NOATOM < 2) atomicAdd(fz + h0, 1u);
+                if (ICV_X_EXP_NOATOM < 1) atomicAdd(cz + (h0 >> 6) * XREP, 1u);
+            }
+            if (w1) {
+                if (ICV_X_EXP_NOATOM < 2) atomicAdd(fz + h1, 1u);
+                if (ICV_X_EXP_NOATOM < 1) atomicAdd(cz + (h1 >> 6) * XREP, 1u);
+            }
+            const double vs = w1 ? v0 + v1 : v0;  // NaN in either window (|window| is bounded: no inf - inf)
+            if (w0 && vs != vs) sc->nanflag[p0] = 1;  // benign race: every writer stores 1
+        }
+        ICV_XPH(5)
+#if ICV_X_LFIRST  // odd wavefronts ran the L phase before W (below)
         const int64_t nxt = cell + gridDim.x;
-#if ICV_X_WFIRST == 2
-        const bool l_first = (__builtin_amdgcn_readfirstlane(tl >> 6) & 1) != 0;
-        if (l_first && nxt < P.n_rows) l_phase(nxt + gridDim.x);
-        if (have0) w_phase();
         if (!l_first && nxt < P.n_rows) l_phase(nxt + gridDim.x);
 #else
-        if (have0) w_phase();
+        const int64_t nxt = cell + gridDim.x;
         if (nxt < P.n_rows) l_phase(nxt + gridDim.x);
 #endif
+        if (have2) {
+            const int64_t pcell = cell - 2 * (int64_t)gridDim.x;
+            if (!st16) {  // unaligned result rows: 4-byte stores, after the row loads of the L phase
+                float* orow = P.out + pcell * P.ldo;
+                if (tl < WH) orow[tl] = yf0;
+                if (tl + WH < W) orow[tl + WH] = yf1;
+            }
+            if constexpr (!CHUNK)
+                if ((tl & 63) == 0) reinterpret_cast<double2*>(P.cell_part)[pcell * XWAVE + (tl >> 6)] = mo;
+            if (tl == 0) P.cell_median[pcell] = med_out;
+        }
         ICV_XPH(2)
-        __syncthreads();  // barrier 2: row of cell it+1 scattered, histogram of cell it complete, {S0,S1} dead
+        __syncthreads();  // barrier 2: row of cell it+1 scattered, histograms of cell it complete, {S0,S1} dead
         ICV_XPH(3)
+    };
+
+    const int64_t n_it = n_mine + 3;  // two iterations of median pipeline + one for the staged x_res store
+    for (int64_t it = 0; it < n_it; it += 2) {
+        iteration(it, 0, wvE0, wvE1, wbE0, wbE1, wvO0, wvO1, wbO0, wbO1);
+        if (it + 1 < n_it) iteration(it + 1, 1, wvO0, wvO1, wbO0, wbO1, wvE0, wvE1, wbE0, wbE1);
+    }
+    if constexpr (CHUNK) {
+        if (wave_w && chunk_cur >= 0) {
+            const double2 m2 = wave_moments(accS, accQ);
+            if ((t & 63) == 0)
+                reinterpret_cast<double2*>(P.chunk_part)[(chunk_cur * gridDim.x + blockIdx.x) * XWAVE + (t >> 6)] = m2;
+        }
     }
 #ifdef ICV_X_PROFILE
-    if (P.dbg && t == 64)
-        for (int i = 0; i < 4; ++i) atomicAdd(P.dbg + i, tacc[i]);
+    if (P.dbg && t == ICV_X_PROFILE_T)
+        for (int i = 0; i < 8; ++i) atomicAdd(P.dbg + i, tacc[i]);
 #endif
 #undef ICV_XPH
 }

@@ -79,6 +79,11 @@ struct KParams {
     // win_only != 0: write the float64 windows to win_out[cell * win_ld + j] and stop there (no median, no x_res)
     int64_t win_ld;
     int32_t win_only, _pad3;
+    // k_smooth_x16<CHUNK>: moments per noise-threshold chunk instead of per cell.  Chunk k holds the rows r with
+    // (r + row_phase) / chunksize == k; chunk_part[(k * gridDim.x + workgroup) * 16 + wavefront] = {sum, sum of
+    // squares} of that wavefront's windows over the workgroup's cells of the chunk (zero-filled by the host)
+    int64_t chunksize, row_phase;
+    double* chunk_part;
 };
 
 struct Scratch {
@@ -641,6 +646,46 @@ __global__ void __launch_bounds__(256) k_chunk_thr(const double* stats, int64_t 
     for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
         s += stats[2 * r];
         q += stats[2 * r + 1];
+    }
+    ss[threadIdx.x] = s;
+    sq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            ss[threadIdx.x] += ss[threadIdx.x + o];
+            sq[threadIdx.x] += sq[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)(r1 - r0) * (double)n_windows;
+        const double mean = ss[0] / n;
+        double var = (sq[0] - ss[0] * mean) / n;
+        if (var < 0.0) var = 0.0;
+        thr[k] = dyn * sqrt(var);
+    }
+}
+
+// the same from the per-(workgroup, wavefront) chunk partials of k_smooth_x16<CHUNK>; hb_stats: per-row moments,
+// zero except for the rows the generic kernel recomputed (cells handed back by k_smooth_x16).  Fixed order.
+__global__ void __launch_bounds__(256) k_chunk_thr_part(const double* chunk_part, int n_part, const double* hb_stats,
+                                                        int64_t n_rows, int64_t chunksize, int64_t row_phase,
+                                                        int n_windows, double dyn, double* thr) {
+    __shared__ double ss[256], sq[256];
+    const int64_t k = blockIdx.x;
+    int64_t r0 = k * chunksize - row_phase, r1 = r0 + chunksize;
+    if (r0 < 0) r0 = 0;
+    if (r1 > n_rows) r1 = n_rows;
+    double s = 0.0, q = 0.0;
+    const double2* part = reinterpret_cast<const double2*>(chunk_part) + k * n_part;
+    for (int i = threadIdx.x; i < n_part; i += 256) {
+        const double2 v = part[i];
+        s += v.x;
+        q += v.y;
+    }
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        s += hb_stats[2 * r];
+        q += hb_stats[2 * r + 1];
     }
     ss[threadIdx.x] = s;
     sq[threadIdx.x] = q;

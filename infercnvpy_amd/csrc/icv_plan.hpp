@@ -23,6 +23,7 @@ constexpr int kWsUMax = 12;            // same for the 448 worker threads of k_s
 constexpr int kWsMaxB = 5, kWsMaxW = 5, kWsMaxK = 30;
 constexpr int kX16Threads = 1024;      // k_smooth_x16: 16 wavefronts, one workgroup per CU
 constexpr int kX16UMax = 5;            // 16-byte row vectors per lane in flight
+constexpr int kX16HistBytes = 2 * (4096 * 4 + 16 * 64 * 4);  // fine + 16 coarse replicas, both cell parities
 
 struct Layout {
     int elem_bytes = 4;
@@ -253,10 +254,10 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         p.sp_ok = p.ws_ok && p.sp_lds <= kLdsLimit && p.NB <= kThreads * 4 && p.W <= kThreads * 4;
         p.x16_s01_off = round_up((p.Gp + 1) * 4, 16);
         p.x16_hist_off = p.x16_s01_off + 16 * p.NB;
-        p.x16_scratch_off = p.x16_hist_off + 4096 * 2;
-        p.x16_lds = p.x16_scratch_off + kFastScratchBytes;
+        p.x16_scratch_off = p.x16_hist_off + kX16HistBytes;
+        p.x16_lds = p.x16_scratch_off + kFastScratchBytes + round_up(4 * p.W, 16);  // + x_res staging row
         p.x16_ok = p.fast_ok && n_cols_all <= kX16UMax * kX16Threads * 4 && p.x16_lds <= kLdsLimit &&
-                   p.NB <= kX16Threads * 4 && p.W <= kX16Threads * 2 && p.W < 65536;
+                   p.NB <= kX16Threads * 2 && p.W <= kX16Threads * 2;
     }
     return "";
 }

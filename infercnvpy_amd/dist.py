@@ -137,12 +137,33 @@ def global_thresholds(cell_stats, global_row0, n_obs_global, chunksize, n_window
     return thresholds_from_moments(m, n_windows, dynamic_threshold)
 
 
+def shards_aligned(bounds, n_obs_global: int, chunksize: int) -> bool:
+    """True if no ``chunksize``-row chunk of the global matrix is split between two shards."""
+    return all(r0 == r1 or (r0 % chunksize == 0 and (r1 % chunksize == 0 or r1 == n_obs_global)) for r0, r1 in bounds)
+
+
+def agree_aligned(local_aligned: bool, device="cpu", group=None) -> bool:
+    """Every rank learns whether ALL ranks hold chunk-aligned shards (one-element all-reduce)."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(local_aligned)
+    import torch
+
+    flag = torch.tensor([0.0 if local_aligned else 1.0], dtype=torch.float64, device=device)
+    all_reduce_sum_(flag, group)
+    return float(flag.item()) == 0.0
+
+
 def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_global=None, lfc_clip=3.0,
-              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None):
+              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None, all_bounds=None):
     """Hot path for this rank's rows of a row-sharded matrix (device resident).
 
-    Chunk-aligned shards (``global_row0 % chunksize == 0``) need no communication here; otherwise
-    the smoothing kernel runs first, the chunk moments are all-reduced and the thresholds applied.
+    Whether the noise threshold needs communication is a property of the WHOLE partition, and every rank must
+    take the same branch (the unaligned path is a collective): with ``all_bounds`` (the row ranges of all
+    ranks, e.g. from :func:`shard_bounds`) the decision is computed locally and identically everywhere;
+    without it the ranks agree through a one-element all-reduce.  Chunk-aligned partitions need no further
+    communication; otherwise the smoothing kernel runs first, the chunk moments of ALL ranks (aligned ones
+    included) are all-reduced and the thresholds applied.
     Returns the local :class:`infercnvpy_amd._engine.SmoothResult`.
     """
     import ctypes as C
@@ -151,17 +172,24 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
 
     rows = dm_local.shape[0]
     n_obs_global = rows if n_obs_global is None else n_obs_global
-    aligned = (global_row0 % chunksize == 0) and ((global_row0 + rows) % chunksize == 0
-                                                  or global_row0 + rows == n_obs_global)
+    if all_bounds is not None:
+        aligned = shards_aligned(all_bounds, n_obs_global, chunksize)
+    else:
+        aligned = shards_aligned([(global_row0, global_row0 + rows)], n_obs_global, chunksize)
+        if dynamic_threshold is not None:
+            aligned = agree_aligned(aligned, ref_lo.device if hasattr(ref_lo, "device") else "cpu", group)
     if dynamic_threshold is None or aligned:
         return _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                     dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags)
     torch = _engine._torch()
     lib = _lib.load()
     res = _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip, dynamic_threshold=None,
-                               chunksize=chunksize, flags=flags)
+                               chunksize=chunksize, flags=flags, cell_stats=True)
     thr_all = global_thresholds(res.cell_stats, global_row0, n_obs_global, chunksize, plan.n_windows,
                                 float(dynamic_threshold), group)
+    if rows == 0:
+        res.thr = thr_all[:0]
+        return res
     k0 = global_row0 // chunksize
     k1 = (global_row0 + rows - 1) // chunksize
     thr = thr_all[k0:k1 + 1].contiguous()

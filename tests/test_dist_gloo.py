@@ -105,6 +105,53 @@ def test_shard_bounds_properties():
     assert icd.shard_bounds(10, 3, 5, align=False) == [(0, 4), (4, 7), (7, 10)]
 
 
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # shard_bounds(12500, 5, 5000, align=False)-style partitions mix aligned and unaligned
+        # shards; every rank must take the same (collective) branch.  Scaled down: 3 ranks, chunksize 50.
+        n_obs, cs = 150, 50
+        bounds = [(0, 100), (100, 130), (130, 150)]
+        r0, r1 = bounds[rank]
+        local = icd.shards_aligned([(r0, r1)], n_obs, cs)
+        assert local == (rank == 0)
+        assert icd.agree_aligned(local) is False
+        assert icd.shards_aligned(bounds, n_obs, cs) is False
+        ok_bounds = icd.shard_bounds(n_obs, world, cs)
+        assert icd.agree_aligned(icd.shards_aligned([ok_bounds[rank]], n_obs, cs)) is True
+        q.put((rank, "ok", None))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_agree_on_the_threshold_branch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"
+
+
+def test_shards_aligned():
+    assert icd.shards_aligned(icd.shard_bounds(1_000_000, 8, 5000), 1_000_000, 5000)
+    assert icd.shards_aligned(icd.shard_bounds(12_345, 4, 5000), 12_345, 5000)
+    assert icd.shards_aligned([(0, 10), (10, 10), (10, 17)], 17, 5)
+    assert not icd.shards_aligned(icd.shard_bounds(12_500, 5, 5000, align=False), 12_500, 5000)
+    assert not icd.shards_aligned([(0, 7), (7, 10)], 10, 5)
+
+
 def test_chunk_moments_segments():
     rng = np.random.RandomState(0)
     stats = torch.from_numpy(rng.rand(137, 2))

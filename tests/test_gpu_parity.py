@@ -361,12 +361,12 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
     from infercnvpy_amd import _engine
     from infercnvpy_amd._plan import GenePlan
 
-    def run(plan, dm, ref, env):
+    def run(plan, dm, ref, env, stats=True):
         for k in ("ICV_FORCE_GENERIC", "ICV_NO_X16"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
-        res = _engine.run_hot_path(plan, dm, ref, chunksize=300)
+        res = _engine.run_hot_path(plan, dm, ref, chunksize=300, cell_stats=stats)
         torch.cuda.synchronize()
         for k in env:
             monkeypatch.delenv(k)
@@ -397,6 +397,12 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
                 torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
             assert torch.isnan(fast.out[6]).all() and not torch.isnan(fast.out[:6]).any()
             assert (fast.out[5] == 0).all()
+            # without per-cell moments the thresholds come from per-chunk partial sums (formed inside
+            # k_smooth_x16 where it runs): same thresholds to rounding, same output
+            lean = run(plan, mat, ref, env, stats=False)
+            assert lean.cell_stats is None
+            torch.testing.assert_close(lean.thr, gen.thr, rtol=1e-12, atol=1e-12, equal_nan=True)
+            assert torch.equal(torch.nan_to_num(lean.out, nan=123.0), torch.nan_to_num(gen.out, nan=123.0)), env
 
 
 @pytest.mark.parametrize("fmt", ["dense", "csr"])
@@ -465,7 +471,7 @@ def test_unaligned_shards_match_single_run():
     parts, moments = [], []
     for r0, r1 in ((0, cut), (cut, 1100)):
         dm = _engine.DeviceMatrix(dense=X[r0:r1].contiguous())
-        res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=None)
+        res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=None, cell_stats=True)
         parts.append((r0, r1, dm, res))
         moments.append(icd.chunk_moments(res.cell_stats, r0, cs, 3))
     thr_all = icd.thresholds_from_moments(moments[0] + moments[1], plan.n_windows, 1.5)
