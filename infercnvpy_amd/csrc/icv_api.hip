@@ -65,6 +65,7 @@ struct icv_plan_s {
     double* d_hb_stats = nullptr;    // per-row moments when the caller passes no cell_stats (rows x 2)
     int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
+    uint32_t* d_x16_wdesc = nullptr;
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
     // Gene sets whose padded row does not fit LDS (float32: > ~40 000 genes, float64: > ~20 000): the
@@ -103,6 +104,7 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.cov_j0.data(), p.cov_j0.size() * 4, (void**)&pl->d_cov_j0));
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
+    HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;  // >= Gp + 1: the trash slot reads 0
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
     pl->device = dev;
@@ -220,6 +222,7 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.dst16 = pl->d_dst16;
     K.pad_idx = pl->d_pad;
     K.w_pack = pl->d_wpack;
+    K.x16_wdesc = pl->d_x16_wdesc;
     K.n_pad = (int32_t)p.pad_idx.size();
     K.pyr_den = p.pyr_den;
     K.pyr_rcp = p.pyr_rcp;
@@ -618,6 +621,7 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_hb_stats);
         (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
+        (void)hipFree(pl->d_x16_wdesc);
         (void)hipFree(pl->d_zrow);
     }
     delete pl;

@@ -8,8 +8,8 @@
 //     ONCE per kernel: no per-cell table loads or address unpacking beyond one SDWA shift per gene;
 //   * all 16 wavefronts run the same phase; row, {S0,S1} and the histograms are separate LDS regions (149 KB of
 //     160 KB), nothing aliases, TWO barriers per cell;
-//   * a thread sums two adjacent blocks per S pass (16-byte LDS reads) and the windows t, t + W/2 (conflict-free
-//     {S0,S1} reads, whole wavefronts idle instead of half-masked ones);
+//   * a thread sums two adjacent blocks per S pass (16-byte LDS reads) and the windows t, t + W/2 and two ADJACENT windows of one chromosome:
+//     11 conflict-free {S0,S1} reads serve both windows;
 //   * median: a 4096-bin histogram (32-bit LDS atomics) plus a 64-bin coarse histogram (4 replicas) -- ONE
 //     wavefront resolves the two middle ranks with two 64-lane DPP prefix sums (coarse, then the 64 fine bins of
 //     the located coarse bin), the windows of those bins are gathered, one wavefront ranks them exactly in
@@ -161,15 +161,17 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 #endif
         }
     }
-    // windows t, t + WH: LDS byte offset of the first {S0,S1} pair, validity, "every valid window of the wavefront
-    // is a full pyramid window" (a missing window repeats window 2t, or window 0)
-    const int WH = (W + 1) / 2;  // thread t owns windows t and t + WH
-    const bool valid0 = t < WH, valid1 = t + WH < W;
-    const int wd0 = P.w_pack[valid0 ? t : 0], wd1 = P.w_pack[valid1 ? t + WH : (valid0 ? t : 0)];
-    const unsigned sp0 = (unsigned)P.win_off + (unsigned)(wd0 & 0xffff) * 16u;
-    const unsigned sp1 = (unsigned)P.win_off + (unsigned)(wd1 & 0xffff) * 16u;
+    // windows: thread t owns the adjacent windows j0, j0 + 1 of ONE chromosome (plan table x16_wdesc: first block,
+    // first window, validity, "full pyramid window"), so the two windows share 9 of their 10 {S0,S1} pairs: 11 LDS
+    // reads for both instead of 20.  {S0,S1} of block b lives at slot (b >> 1) + 1024 (b & 1): the reads of a
+    // wavefront (block stride 2 between lanes) and the writes of the S phase are 16-byte strided, conflict-free.
+    const unsigned wdx = P.x16_wdesc[t];
+    const int wb0 = (int)(wdx & 0xfffu), wj0 = (int)((wdx >> 12) & 0xfffu);
+    const bool valid0 = (wdx >> 24) & 1u, valid1 = (wdx >> 25) & 1u;
+    const unsigned spA = (unsigned)P.win_off + (unsigned)((wb0 >> 1) + 1024 * (wb0 & 1)) * 16u;              // block b0
+    const unsigned spB = (unsigned)P.win_off + (unsigned)(((wb0 + 1) >> 1) + 1024 * ((wb0 + 1) & 1)) * 16u;  // block b0+1
     const bool wave_w = __builtin_amdgcn_ballot_w64(valid0) != 0;  // the wavefront has windows at all
-    const bool wfull = __builtin_amdgcn_ballot_w64((wd0 >> 16) != NBW * BT || (wd1 >> 16) != NBW * BT) == 0;
+    const bool wfull = __builtin_amdgcn_ballot_w64((valid0 && !((wdx >> 26) & 1u)) || (valid1 && !((wdx >> 27) & 1u))) == 0;
     // pad slots and the trash slot are written once: nothing aliases the row
     for (int i = t; i < P.n_pad; i += XT) row[P.pad_idx[i]] = 0.0f;
     for (int i = t; i < kX16HistBytes / 4; i += XT) hist[i] = 0u;
@@ -184,6 +186,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     // against two 4-byte stores per thread): needs 16-byte aligned rows
     const bool st16 = ((P.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0);
     for (int i = t; i < ((W + 3) & ~3); i += XT) stage[i] = 0.0f;
+    for (int i = t; i < 2 * 2048; i += XT) S01[i] = 0.0;  // slots past the last block are read (and discarded)
 
     u32x4 xq[XU];
     {
@@ -426,9 +429,9 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                         block_accumulate((double)v[r], r, s0a, s1a);
                         block_accumulate((double)v[BT + r], r, s0b, s1b);
                     }
-                    double2* sp = reinterpret_cast<double2*>(S01 + 2 * b);
+                    double2* sp = reinterpret_cast<double2*>(S01) + (b >> 1);  // even blocks | 1024 | odd blocks
                     sp[0] = make_double2(s0a, s1a);
-                    if (b + 1 < NB) sp[1] = make_double2(s0b, s1b);
+                    if (b + 1 < NB) sp[1024] = make_double2(s0b, s1b);
                 }
             }
         }
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             }
             if (wave_w) {
                 const double y0 = wvA0 - med_out, y1 = wvA1 - med_out;
-                const bool v0 = tl < WH, v1 = tl + WH < W;
+                const bool v0 = valid0, v1 = valid1;
                 yf0 = (float)y0;
                 yf1 = (float)y1;
                 if constexpr (CHUNK) {
@@ -499,8 +502,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                     mo = wave_moments(sum, sq);
                 }
                 if (st16) {
-                    if (v0) stage[tl] = yf0;
-                    if (v1) stage[tl + WH] = yf1;
+                    if (v0) stage[wj0] = yf0;
+                    if (v1) stage[wj0 + 1] = yf1;
                 }
             }
         }
@@ -543,21 +546,24 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             // ---- W: windows 2t, 2t+1 of cell it from {S0,S1}, histogram atomics --------------------
             double v0, v1;
             if (wfull) {
-                // every window of the wavefront is a full pyramid window: no per-window branches, both windows of
-                // the thread advance together (interleaved float64 chains), canonical order inside a window
+                // every window of the wavefront is a full pyramid window: no per-window branches; window j0 uses
+                // the pairs of blocks b0 .. b0+9, window j0+1 those of b0+1 .. b0+10 (canonical order inside a
+                // window, the two float64 chains interleaved)
                 constexpr int HB = NBW / 2;
-                const double2* q0 = reinterpret_cast<const double2*>(smem + sp0);
-                const double2* q1 = reinterpret_cast<const double2*>(smem + sp1);
+                const double2* qA = reinterpret_cast<const double2*>(smem + spA);  // blocks b0, b0+2, ...
+                const double2* qB = reinterpret_cast<const double2*>(smem + spB);  // blocks b0+1, b0+3, ...
                 v0 = 0.0;
                 v1 = 0.0;
+                double2 cur = qA[0];
 #pragma unroll
                 for (int m = 0; m < NBW; ++m) {
-                    const double2 a = q0[m], b = q1[m];
+                    const double2 nxt = ((m + 1) & 1) ? qB[(m + 1) >> 1] : qA[(m + 1) >> 1];  // block b0 + m + 1
                     const double wgt = (double)(m < HB ? m * BT + 1 : NBW * BT - m * BT);
-                    v0 = fma(wgt, a.x, v0);
-                    v1 = fma(wgt, b.x, v1);
-                    v0 = m < HB ? v0 + a.y : v0 - a.y;
-                    v1 = m < HB ? v1 + b.y : v1 - b.y;
+                    v0 = fma(wgt, cur.x, v0);   // window j0, its block m     = block b0 + m
+                    v1 = fma(wgt, nxt.x, v1);   // window j0 + 1, its block m = block b0 + m + 1
+                    v0 = m < HB ? v0 + cur.y : v0 - cur.y;
+                    v1 = m < HB ? v1 + nxt.y : v1 - nxt.y;
+                    cur = nxt;
                     if (m % ICV_X_WCH == ICV_X_WCH - 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
                 }
                 v0 = finish_window(v0, NBW * BT, pyr_den, pyr_rcp, 1.0);
@@ -566,17 +572,19 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 double vv[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    int wp = i ? wd1 : wd0;
-                    asm volatile("" : "+v"(wp));  // decode inside the loop (register budget)
-                    const int ln = wp >> 16;
-                    const double2* sp = reinterpret_cast<const double2*>(S01) + (wp & 0xffff);
+                    int bs = wb0 + i, jr = wj0 + i;
+                    asm volatile("" : "+v"(bs), "+v"(jr));  // addresses formed here, not hoisted (register budget)
+                    const int j = jr < W ? jr : 0;
+                    const bool ok = i ? valid1 : valid0;
+                    const int ln = ok ? P.w_len[j] : NBW * BT;
+                    const double2* sb = reinterpret_cast<const double2*>(S01);
                     double v = window_from_blocks(ln, BT, [&](int m, double& a, double& b2) {
-                        const double2 s = sp[m];
-                        a = s.x;
-                        b2 = s.y;
+                        const int bb = bs + m;
+                        const double2 q = sb[(bb >> 1) + 1024 * (bb & 1)];
+                        a = q.x;
+                        b2 = q.y;
                     });
                     // flat windows (one per chromosome with <= window genes) read their gene count
-                    const int j = tl + i * WH < W ? tl + i * WH : 0;
                     vv[i] = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
                 }
                 v0 = vv[0];
@@ -585,7 +593,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             wvA0 = v0;
             wvA1 = v1;
             const int h0 = hist_bin_x(v0, inv_bound, c_scale, c_thr), h1 = hist_bin_x(v1, inv_bound, c_scale, c_thr);
-            const bool w0 = tl < WH, w1 = tl + WH < W;
+            const bool w0 = valid0, w1 = valid1;
             wbA0 = w0 ? h0 : -1;
             wbA1 = w1 ? h1 : -1;
             unsigned* fz = hist + p0 * XFINE;
@@ -616,8 +624,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             const int64_t pcell = cell - 2 * (int64_t)gridDim.x;
             if (!st16) {  // unaligned result rows: 4-byte stores, after the row loads of the L phase
                 float* orow = P.out + pcell * P.ldo;
-                if (tl < WH) orow[tl] = yf0;
-                if (tl + WH < W) orow[tl + WH] = yf1;
+                if (valid0) orow[wj0] = yf0;
+                if (valid1) orow[wj0 + 1] = yf1;
             }
             if constexpr (!CHUNK)
                 if ((tl & 63) == 0) reinterpret_cast<double2*>(P.cell_part)[pcell * XWAVE + (tl >> 6)] = mo;

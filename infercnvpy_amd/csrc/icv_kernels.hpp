@@ -84,6 +84,9 @@ struct KParams {
     // squares} of that wavefront's windows over the workgroup's cells of the chunk (zero-filled by the host)
     int64_t chunksize, row_phase;
     double* chunk_part;
+    // k_smooth_x16: per thread, first block (bits 0-11) and first window (12-23) of its two adjacent windows,
+    // window valid (24, 25), full pyramid window (26, 27)
+    const uint32_t* x16_wdesc;
 };
 
 struct Scratch {

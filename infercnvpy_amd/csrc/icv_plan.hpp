@@ -68,6 +68,7 @@ struct Plan {
     // k_smooth_x16 (one 1024-thread workgroup per CU, tables in registers): row | {S0,S1} | histogram | scratch
     bool x16_ok = false;
     int x16_s01_off = 0, x16_hist_off = 0, x16_scratch_off = 0, x16_lds = 0;
+    std::vector<uint32_t> x16_wdesc;  // per thread: the pair of adjacent windows it owns (icv_kernels.hpp KParams)
     Layout lay32, lay64;
 };
 
@@ -253,11 +254,31 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         p.sp_lds = p.sp_scratch_off + kFastScratchBytes;
         p.sp_ok = p.ws_ok && p.sp_lds <= kLdsLimit && p.NB <= kThreads * 4 && p.W <= kThreads * 4;
         p.x16_s01_off = round_up((p.Gp + 1) * 4, 16);
-        p.x16_hist_off = p.x16_s01_off + 16 * p.NB;
+        p.x16_hist_off = p.x16_s01_off + 16 * 2048;  // even blocks | odd blocks, 1024 slots each
         p.x16_scratch_off = p.x16_hist_off + kX16HistBytes;
         p.x16_lds = p.x16_scratch_off + kFastScratchBytes + round_up(4 * p.W, 16);  // + x_res staging row
         p.x16_ok = p.fast_ok && n_cols_all <= kX16UMax * kX16Threads * 4 && p.x16_lds <= kLdsLimit &&
-                   p.NB <= kX16Threads * 2 && p.W <= kX16Threads * 2;
+                   p.NB <= kX16Threads * 2 - 16 && p.W <= 4095;
+        // windows dealt to threads in pairs of adjacent windows of one chromosome
+        p.x16_wdesc.assign(kX16Threads, 0u);
+        {
+            int idx = 0;
+            for (int c = 0; c < n_chr && p.x16_ok; ++c) {
+                const int w0 = p.chr_pos[c], wc = (c + 1 < n_chr ? p.chr_pos[c + 1] : p.W) - w0;
+                for (int q = 0; q < wc; q += 2) {
+                    if (idx >= kX16Threads) {
+                        p.x16_ok = false;
+                        break;
+                    }
+                    const int j0 = w0 + q;
+                    const bool v1 = q + 1 < wc;
+                    const uint32_t full0 = p.w_len[j0] == window ? 1u : 0u;
+                    const uint32_t full1 = (v1 && p.w_len[j0 + 1] == window) ? 1u : 0u;
+                    p.x16_wdesc[idx++] = (uint32_t)(p.w_start[j0] / B) | ((uint32_t)j0 << 12) | (1u << 24) |
+                                         ((v1 ? 1u : 0u) << 25) | (full0 << 26) | (full1 << 27);
+                }
+            }
+        }
     }
     return "";
 }

@@ -2,9 +2,9 @@
 # quick A/B of build variants (timing only for the *_exp builds): every build twice, interleaved
 set -u
 O=gpurun_out/${1:-r02x}; mkdir -p $O
-B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline"
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline"
 one() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4))"; }
-for rep in 1 2; do
+for rep in 1 2 3 4 5; do
   timeout 120 $B 2>&1 | tail -1 | one default | tee -a $O/bench.txt
   for lib in variants/libicv_*.so; do
     case $lib in *prof*) continue;; esac
