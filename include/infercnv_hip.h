@@ -47,8 +47,9 @@ enum { ICV_DENSE = 0, ICV_CSR = 1 };
 enum {
     ICV_FLAG_TRUNC_TO_INT = 1, /* bounded centring of an integer matrix keeps the matrix dtype
                                   (reference :428): centred values are truncated toward zero */
-    ICV_FLAG_ROUND_F32 = 2     /* bounded centring of a float32 matrix against a float64 reference:
+    ICV_FLAG_ROUND_F32 = 2,    /* bounded centring of a float32 matrix against a float64 reference:
                                   differences are rounded to float32 (same line)              */
+    ICV_FLAG_NO_APPLY = 4      /* icv_infercnv_run: compute the thresholds, leave `out` un-thresholded */
 };
 
 /* A cells x genes expression matrix resident in HBM. */
@@ -92,6 +93,11 @@ typedef struct {
  * The library derives the window table: per chromosome with G_c genes,
  *   window < G_c : W_c = ceil((G_c - window + 1) / step) pyramid windows  (:205-218)
  *   otherwise    : one flat window over all G_c genes                     (:227-236)
+ * Concurrency: the tables of a plan are immutable after creation, but the plan also owns the per-call device
+ * workspace of the compute entry points (moment partials, hand-back lists, CSR staging): ONE compute call at a
+ * time per plan.  A second call entering while one is in its launch sequence fails with ICV_ERR_INVALID ("plan
+ * busy") instead of racing; calls on different plans, and successive calls on one plan enqueued on the same
+ * stream, are fine.
  */
 int icv_plan_create(int32_t n_cols_all, const int32_t *h_col_pos, int32_t n_chr,
                     const int32_t *h_chrom_offsets, int32_t window, int32_t step, icv_plan_t *out);
@@ -117,7 +123,8 @@ int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, 
  *   clip to +-lfc_clip in the matrix dtype, pyramid/flat windowed mean per chromosome in
  *   float64, subtract the per-cell median over all W windows.
  * Outputs (device):
- *   out         n_rows x ldo float32, un-thresholded x_res
+ *   out         n_rows x ldo float32, un-thresholded x_res (rows on 16-byte boundaries -- ldo % 4 == 0 and a
+ *               16-byte aligned base -- let the dense fast kernel store 16 bytes per lane)
  *   cell_median n_rows float64
  *   cell_stats  n_rows x 2 float64: sum(x_res), sum(x_res^2) of the row (for the chunk std)
  * `ref_lo`/`ref_hi`: n_cols values of the matrix dtype, in input column order.
@@ -150,6 +157,10 @@ typedef struct {
 
 /* Convenience: smooth -> chunk thresholds -> apply, on one stream.  `dynamic_threshold` NaN
  * disables step 5 (reference: None).  `thr` may be NULL only when step 5 is disabled.
+ * `cell_stats` may be NULL: the per-cell moments are then not returned, and where the dense fast kernel runs
+ * they are not formed at all (the kernel accumulates the noise-threshold moments per chunk).
+ * flags | ICV_FLAG_NO_APPLY: compute `thr` but leave `out` un-thresholded (for icv_threshold_mask).
+ * One call at a time per plan: the plan owns the per-call workspace (see icv_plan_create).
  * If `h_profile` is non-NULL the call records HIP events around each stage, synchronises the
  * stream before returning and fills the struct. */
 int icv_infercnv_run(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
@@ -182,6 +193,20 @@ int icv_gene_values(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, co
 int icv_csr_count(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, int64_t *row_nnz, void *stream);
 int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const int64_t *indptr,
                  int32_t *indices, double *data, void *stream);
+
+/* Step 5b fused with the packing (the public tl.infercnv path: X_cnv leaves the GPU as CSR and the dense thresholded
+ * matrix is never needed): same decision as icv_apply_threshold, but `out` (the UN-thresholded x_res of
+ * icv_infercnv_smooth / icv_infercnv_run with ICV_FLAG_NO_APPLY) is left untouched; the kept entries
+ * (|x| >= thr in float64, x != 0; NaN kept) are recorded as bits, `mask` = n_rows x n_words uint64 with
+ * n_words = ceil(n_windows / 64), and counted into `row_nnz`.  `thr` NULL = no threshold (dynamic_threshold=None).
+ * icv_csr_fill_masked then packs indices / values at indptr[row] (caller-side prefix sum of row_nnz).
+ * x_res is read twice in total and never rewritten. */
+int icv_threshold_mask(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                       double lfc_clip, int32_t flags, const float *out, int64_t ldo, const double *cell_median,
+                       const double *thr, int64_t chunksize, int64_t row_phase, uint64_t *mask,
+                       int64_t *row_nnz, void *stream);
+int icv_csr_fill_masked(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const uint64_t *mask,
+                        const int64_t *indptr, int32_t *indices, double *data, void *stream);
 
 /* ---- ithcna / ithgex (tl/_scores.py:77-221) -------------------------------------------------
  * Interquartile range of all n x n entries of np.corrcoef(x) for one group of cells: x is a dense

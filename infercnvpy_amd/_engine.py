@@ -111,8 +111,9 @@ def to_device_matrix(X, dtype=None, device="cuda"):
     return DeviceMatrix(dense=torch.from_numpy(X).to(device))
 
 
-def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None):
-    """float64 per-group column sums, accumulated into ``sums`` (device n_groups x n_cols)."""
+def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None, row0=0, row1=None):
+    """float64 per-group column sums of rows [row0, row1), accumulated into ``sums`` (device n_groups x n_cols);
+    ``row_group``: group of every one of those rows (-1 = none)."""
     torch = _torch()
     lib = _lib.load()
     if sums is None:
@@ -120,7 +121,7 @@ def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None):
     rg = None
     if row_group is not None:
         rg = torch.as_tensor(np.asarray(row_group, dtype=np.int32)).to("cuda")
-    m = dm.c_struct()
+    m = dm.c_struct(row0, row1)
     _lib.check(lib.icv_colsum(C.byref(m), _ptr(rg), n_groups, _ptr(sums), _stream_ptr(torch)))
     return sums
 
@@ -142,13 +143,158 @@ class SmoothResult:
         self.profile = profile
 
 
+class SlabStream:
+    """Upload the rows of a host matrix piece by piece on a side stream while the caller computes.
+
+    A helper thread issues the host -> HBM copies (pageable source: the copy call blocks its thread, not the
+    caller; measured 56 GB/s on PCIe Gen5 x16, the same as from pinned memory) and records an event per piece;
+    ``pieces()`` yields ``(r0, r1)`` in order once the current stream has been made to wait for that piece.
+    ``dm`` is the DeviceMatrix of the whole slab (valid row ranges: the pieces yielded so far).
+    """
+
+    def __init__(self, X, tdtype, piece_rows):
+        import queue
+        import threading
+
+        torch = _torch()
+        np_dtype = np.float32 if tdtype == torch.float32 else np.float64
+        self.n_rows = X.shape[0]
+        self.bounds = [(r, min(self.n_rows, r + piece_rows)) for r in range(0, self.n_rows, piece_rows)]
+        self._q = queue.Queue()
+        self._landed = 0
+        self._stream = torch.cuda.Stream()
+        device = torch.cuda.current_device()  # the helper thread starts on device 0 otherwise
+        self._err = None
+        if sp.issparse(X):
+            indptr64 = np.ascontiguousarray(X.indptr.astype(np.int64, copy=False))
+            nnz = int(indptr64[-1])
+            d_indices = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
+            d_data = torch.empty(max(nnz, 1), dtype=tdtype, device="cuda")
+            d_indptr = torch.from_numpy(indptr64).cuda()
+            self.dm = DeviceMatrix(indptr=d_indptr, indices=d_indices, data=d_data, shape=X.shape,
+                                   indptr_host=indptr64)
+            idx_h, dat_h = X.indices, X.data
+
+            def copy_piece(r0, r1):
+                k0, k1 = int(indptr64[r0]), int(indptr64[r1])
+                if k1 > k0:
+                    d_indices[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(idx_h[k0:k1].astype(np.int32, copy=False))))
+                    d_data[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(dat_h[k0:k1].astype(np_dtype, copy=False))))
+        else:
+            dense = torch.empty(X.shape, dtype=tdtype, device="cuda")
+            self.dm = DeviceMatrix(dense=dense)
+
+            def copy_piece(r0, r1):
+                dense[r0:r1].copy_(torch.from_numpy(np.ascontiguousarray(X[r0:r1].astype(np_dtype, copy=False))))
+
+        def work():
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(self._stream):
+                    for r0, r1 in self.bounds:
+                        copy_piece(r0, r1)
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                        self._q.put((r0, r1, ev))
+            except BaseException as e:  # surfaced in the consumer
+                self._err = e
+                self._q.put(None)
+
+        self.h2d_seconds = 0.0
+        inner = work
+
+        def timed():
+            import time
+
+            t0 = time.perf_counter()
+            inner()
+            self._stream.synchronize()
+            self.h2d_seconds = time.perf_counter() - t0
+
+        self._thread = threading.Thread(target=timed, daemon=True)
+        self._thread.start()
+
+    def pieces(self):
+        """Row ranges in order; blocks (stream-wise) only for pieces that have not landed yet.  Re-iterable."""
+        torch = _torch()
+        for k in range(len(self.bounds)):
+            if k >= self._landed:
+                item = self._q.get()
+                if item is None:
+                    raise self._err
+                torch.cuda.current_stream().wait_event(item[2])
+                self._landed += 1
+            yield self.bounds[k]
+        if self._thread.is_alive():
+            self._thread.join()
+
+
+class PackedRows:
+    """x_res of a row range with its keep-mask and per-row counts (device), awaiting the CSR fill."""
+
+    def __init__(self, out, mask, counts, thr):
+        self.out, self.mask, self.counts, self.thr = out, mask, counts, thr
+
+
+def threshold_mask(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_clip, chunksize, row_phase=0,
+                   flags=0, row0=0, row1=None):
+    """Step 5b without rewriting x_res: keep-bits (|x| >= thr decided in float64, x != 0) + per-row counts."""
+    torch = _torch()
+    lib = _lib.load()
+    rows = res.out.shape[0]
+    n_words = (plan.n_windows + 63) // 64
+    mask = torch.empty((rows, n_words), dtype=torch.int64, device="cuda")
+    counts = torch.empty(rows, dtype=torch.int64, device="cuda")
+    m = dm.c_struct(row0, row1)
+    _lib.check(lib.icv_threshold_mask(
+        plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(res.out),
+        res.out.stride(0), _ptr(res.cell_median), _ptr(res.thr), int(chunksize), int(row_phase), _ptr(mask),
+        _ptr(counts), _stream_ptr(torch)))
+    return PackedRows(res.out, mask, counts, res.thr)
+
+
+def packed_to_host_csr(parts, n_cols):
+    """Pieces of :class:`PackedRows` (consecutive row ranges) -> one scipy CSR float64 on the host.
+
+    One prefix sum per piece on the device, one synchronisation for the sizes, then the indices / values of
+    every piece are packed on the device straight into its slice of the final host arrays."""
+    torch = _torch()
+    lib = _lib.load()
+    indptrs = []
+    for p in parts:
+        ip = torch.zeros(p.counts.shape[0] + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(p.counts, 0, out=ip[1:])
+        indptrs.append(ip)
+    nnzs = [int(ip[-1].item()) for ip in indptrs]
+    total, rows = sum(nnzs), sum(p.counts.shape[0] for p in parts)
+    indptr_h = np.zeros(rows + 1, dtype=np.int64)
+    indices_h = np.empty(total, dtype=np.int32)
+    data_h = np.empty(total, dtype=np.float64)
+    cap = max(nnzs + [1])
+    idx_d = torch.empty(cap, dtype=torch.int32, device="cuda")
+    dat_d = torch.empty(cap, dtype=torch.float64, device="cuda")
+    r, o = 0, 0
+    for p, ip, nnz in zip(parts, indptrs, nnzs):
+        n = p.counts.shape[0]
+        if nnz:
+            _lib.check(lib.icv_csr_fill_masked(_ptr(p.out), n, n_cols, p.out.stride(0), _ptr(p.mask), _ptr(ip),
+                                               _ptr(idx_d), _ptr(dat_d), _stream_ptr(torch)))
+            torch.from_numpy(indices_h[o:o + nnz]).copy_(idx_d[:nnz])
+            torch.from_numpy(data_h[o:o + nnz]).copy_(dat_d[:nnz])
+        indptr_h[r + 1:r + n + 1] = ip[1:].cpu().numpy() + o
+        r += n
+        o += nnz
+    return sp.csr_matrix((data_h, indices_h, indptr_h), shape=(rows, n_cols))
+
+
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,
                  chunksize=5000, row_phase=0, flags=0, out=None, profile=False, row0=0, row1=None,
-                 cell_stats=False):
+                 cell_stats=False, apply=True):
     """Steps 1-5 of the chunk kernel for rows [row0, row1) of ``dm`` (all device-resident).
 
     ``cell_stats=True`` also returns the per-cell moments (sum, sum of squares of x_res); without them the
-    library forms the noise-threshold moments per chunk inside the smoothing kernel (faster)."""
+    library forms the noise-threshold moments per chunk inside the smoothing kernel (faster).
+    ``apply=False`` computes the thresholds but leaves ``out`` un-thresholded (for :func:`threshold_mask`)."""
     torch = _torch()
     lib = _lib.load()
     n = dm.shape[0]
@@ -172,7 +318,8 @@ def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_c
     prof = _lib.Profile() if profile else None
     _lib.check(lib.icv_infercnv_run(
         plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), dyn, int(chunksize), int(row_phase),
-        int(flags), _ptr(out), out.stride(0), _ptr(med), _ptr(stats), _ptr(thr),
+        int(flags) | (0 if apply else _lib.ICV_FLAG_NO_APPLY), _ptr(out), out.stride(0), _ptr(med), _ptr(stats),
+        _ptr(thr),
         C.byref(prof) if prof is not None else None, _stream_ptr(torch)))
     return SmoothResult(out, med, stats, thr, prof)
 

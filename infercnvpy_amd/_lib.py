@@ -19,13 +19,14 @@ ICV_F32, ICV_F64 = 0, 1
 ICV_DENSE, ICV_CSR = 0, 1
 ICV_FLAG_TRUNC_TO_INT = 1
 ICV_FLAG_ROUND_F32 = 2
+ICV_FLAG_NO_APPLY = 4
 
 # every symbol include/infercnv_hip.h declares
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
-    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_corr_iqr",
+    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_row_abs_sum", "icv_last_error", "icv_version",
     "icv_device_count",
 )
@@ -93,6 +94,8 @@ def load():
     lib.icv_gene_values.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, i64, vp, i64, vp]
     lib.icv_csr_count.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_csr_fill.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp]
+    lib.icv_threshold_mask.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp, vp, vp]
+    lib.icv_csr_fill_masked.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, vp]
     lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]
     lib.icv_ward_linkage.argtypes = [vp, i64, i64, vp, P(i32), vp]

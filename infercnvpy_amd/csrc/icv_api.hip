@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,7 @@ int fail(int code, const std::string& msg) {
 struct icv_plan_s {
     icv::Plan p;
     std::mutex mu;
+    std::atomic<bool> busy{false};  // a compute entry point is in its launch sequence (workspace in use)
     int device = -1;
     int n_cu = 0;
     int32_t *d_dst = nullptr, *d_src = nullptr, *d_wstart = nullptr, *d_wlen = nullptr;
@@ -77,6 +79,23 @@ struct icv_plan_s {
 };
 
 namespace {
+
+// one compute call at a time per plan (the plan owns the per-call workspace); released on scope exit
+struct PlanBusy {
+    icv_plan_t pl;
+    bool ok;
+    explicit PlanBusy(icv_plan_t p) : pl(p), ok(false) {
+        bool expected = false;
+        ok = p && p->busy.compare_exchange_strong(expected, true);
+    }
+    ~PlanBusy() {
+        if (ok) pl->busy.store(false);
+    }
+};
+#define PLAN_BUSY_GUARD(pl)                                                                          \
+    PlanBusy busy_guard_(pl);                                                                        \
+    if (!busy_guard_.ok)                                                                             \
+        return fail(ICV_ERR_INVALID, "plan busy: one compute call at a time per plan (see icv_plan_create)")
 
 int ensure_device(icv_plan_t pl) {
     std::lock_guard<std::mutex> lk(pl->mu);
@@ -717,6 +736,7 @@ int icv_infercnv_smooth(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, 
                         double* cell_stats, void* stream) {
     int rc = check_matrix(pl, m);
     if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
     if (!cell_median || !cell_stats) return fail(ICV_ERR_INVALID, "cell_median and cell_stats are required");
     if ((rc = ensure_device(pl))) return rc;
     icv::KParams K;
@@ -743,6 +763,7 @@ int icv_apply_threshold(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, 
                         const double* thr, int64_t chunksize, int64_t row_phase, void* stream) {
     int rc = check_matrix(pl, m);
     if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
     if (!cell_median || !thr || chunksize < 1) return fail(ICV_ERR_INVALID, "bad apply_threshold arguments");
     if ((rc = ensure_device(pl))) return rc;
     icv::KParams K;
@@ -759,6 +780,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
                      void* stream) {
     int rc = check_matrix(pl, m);
     if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
     const bool do_thr = !std::isnan(dynamic_threshold);
     if (!cell_median) return fail(ICV_ERR_INVALID, "cell_median is required");
     if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
@@ -830,7 +852,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         if (rc) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(ev[2], st));
-    if (do_thr && (rc = launch_apply(m, K, thr, chunksize, row_phase, st))) return rc;
+    if (do_thr && !(flags & ICV_FLAG_NO_APPLY) && (rc = launch_apply(m, K, thr, chunksize, row_phase, st))) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev[3], st));
     if (deferred) {  // no synchronisation here: the times are read by icv_profile_collect
         for (auto& e : ev) pl->prof_events.push_back(e);
@@ -880,6 +902,7 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
                     int64_t ldg, void* stream) {
     int rc = check_matrix(pl, m);
     if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
     if (!gene_out || ldg < m->n_cols) return fail(ICV_ERR_INVALID, "gene_out is null or ldg < n_cols");
     if (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
         return fail(ICV_ERR_INVALID, "chunksize / row_phase invalid");
@@ -938,6 +961,53 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     HIP_TRY(hipFreeAsync(med, st));
     HIP_TRY(hipFreeAsync(cmed, st));
     HIP_TRY(hipFreeAsync(cstat, st));
+    return ICV_OK;
+}
+
+int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                       int32_t flags, const float* out, int64_t ldo, const double* cell_median, const double* thr,
+                       int64_t chunksize, int64_t row_phase, uint64_t* mask, int64_t* row_nnz, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
+    if (!cell_median || !mask || !row_nnz || (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize)))
+        return fail(ICV_ERR_INVALID, "bad threshold_mask arguments");
+    if ((rc = ensure_device(pl))) return rc;
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, const_cast<float*>(out), ldo,
+                          const_cast<double*>(cell_median), nullptr, K, lay)))
+        return rc;
+    if (K.n_rows < 1) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int n_words = (pl->p.W + 63) / 64;
+    const int64_t cs = thr ? chunksize : 1;
+    auto* mk = reinterpret_cast<unsigned long long*>(mask);
+    dim3 grid((unsigned)K.n_rows), block(256);
+    if (m->dtype == ICV_F32) {
+        if (m->format == ICV_DENSE)
+            hipLaunchKernelGGL((icv::k_thr_mask<float, false>), grid, block, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz);
+        else
+            hipLaunchKernelGGL((icv::k_thr_mask<float, true>), grid, block, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz);
+    } else {
+        if (m->format == ICV_DENSE)
+            hipLaunchKernelGGL((icv::k_thr_mask<double, false>), grid, block, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz);
+        else
+            hipLaunchKernelGGL((icv::k_thr_mask<double, true>), grid, block, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz);
+    }
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_csr_fill_masked(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, const uint64_t* mask,
+                        const int64_t* indptr, int32_t* indices, double* data, void* stream) {
+    if (!x || !mask || !indptr || !indices || !data || n_cols < 0 || ld < n_cols)
+        return fail(ICV_ERR_INVALID, "bad csr_fill_masked arguments");
+    if (n_rows < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_csr_fill_masked, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld,
+                       reinterpret_cast<const unsigned long long*>(mask), (n_cols + 63) / 64, indptr, indices, data);
+    HIP_TRY(hipGetLastError());
     return ICV_OK;
 }
 

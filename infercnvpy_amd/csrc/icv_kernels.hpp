@@ -837,6 +837,80 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
     }
 }
 
+// step 5b fused with the CSR count (public path: X_cnv leaves the GPU as CSR, reference :455): the same decision
+// as k_apply_thr, but x_res is left untouched -- the kept entries (|x| >= thr decided in float64, x != 0; NaN is
+// kept) are recorded as one bit per window and counted per row; k_csr_fill_masked then packs them.  x_res is read
+// twice in total and never rewritten.
+template <typename T, bool CSR>
+__global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double* thr, int64_t chunksize,
+                                                  int64_t row_phase, unsigned long long* mask, int n_words,
+                                                  int64_t* row_nnz) {
+    __shared__ int tie_n, cnt[4];
+    __shared__ int tie_j[32];
+    __shared__ double vals[kTieBuf];
+    const int64_t cell = blockIdx.x;
+    const bool has_thr = thr != nullptr;
+    const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
+    const float thf = (float)th;
+    const float* orow = P.out + cell * P.ldo;
+    unsigned long long* mrow = mask + cell * (int64_t)n_words;
+    if (threadIdx.x == 0) tie_n = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int j0 = 0; j0 < P.W; j0 += 256) {
+        const int j = j0 + (int)threadIdx.x;
+        bool keep = false;
+        if (j < P.W) {
+            const float y = orow[j];
+            const float a = fabsf(y);
+            keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
+            if (has_thr) {
+                if (a < thf) keep = false;
+                else if (a == thf) {  // float32 cannot decide: exact float64 recomputation below
+                    const int idx = atomicAdd(&tie_n, 1);
+                    if (idx < 32) {
+                        tie_j[idx] = j;
+                    } else {  // > 32 ties in one row: resolve serially
+                        const int st = P.w_start[j];
+                        const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                                          P.cell_median[cell];
+                        if (fabs(yd) < th) keep = false;
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if ((threadIdx.x & 63) == 0 && j < P.W) mrow[j >> 6] = m;
+        kept += (threadIdx.x & 63) == 0 ? __popcll(m) : 0;
+    }
+    __syncthreads();  // mask words and the tie list are complete (workgroup scope)
+    const int nt = tie_n < 32 ? tie_n : 32;
+    int dropped = 0;
+    for (int i = 0; i < nt; ++i) {  // rare (about one window in 1e7): the block recomputes it together
+        const int j = tie_j[i];
+        const int st = P.w_start[j], ln = P.w_len[j];
+        const int len = ln > 0 ? ln : -ln;
+        bool drop = false;
+        if (len <= kTieBuf) {
+            for (int k = threadIdx.x; k < len; k += 256) vals[k] = value_at<T, CSR>(P, cell, st + k);
+            __syncthreads();
+            if (threadIdx.x == 0)
+                drop = fabs(window_canonical(P, j, [&](int k) { return vals[k]; }) - P.cell_median[cell]) < th;
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            drop = fabs(window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                        P.cell_median[cell]) < th;
+        }
+        if (threadIdx.x == 0 && drop) {
+            mrow[j >> 6] &= ~(1ull << (j & 63));
+            ++dropped;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) row_nnz[cell] = (int64_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3] - dropped);
+}
+
 // x_res = window - median (float32), per-cell moments and median, from float64 windows resident in HBM (the
 // last step of the chromosome-group fallback; same DPP reduction tree as the smoothing kernels)
 __global__ void __launch_bounds__(256) k_win_finish(const double* win, int64_t n_rows, int W, const double* med,
@@ -1165,6 +1239,29 @@ __global__ void __launch_bounds__(256) k_csr_fill(const float* x, int64_t n_rows
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
             indices[base + pos] = j;
             data[base + pos] = (double)v;
+        }
+        base += __popcll(m);
+    }
+}
+
+// pack the kept entries (bit mask of k_thr_mask) of the dense float32 result: one wavefront per row
+__global__ void __launch_bounds__(256) k_csr_fill_masked(const float* x, int64_t n_rows, int n_cols, int64_t ld,
+                                                         const unsigned long long* mask, int n_words,
+                                                         const int64_t* indptr, int32_t* indices, double* data) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + row * ld;
+    const unsigned long long* mrow = mask + row * (int64_t)n_words;
+    int64_t base = indptr[row];
+    for (int w = 0; w < n_words; ++w) {
+        const unsigned long long m = mrow[w];
+        if (m == 0ull) continue;  // wavefront-uniform
+        const int j = w * 64 + lane;
+        if ((m >> lane) & 1ull) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            indices[base + pos] = j;
+            data[base + pos] = (double)xr[j];
         }
         base += __popcll(m);
     }

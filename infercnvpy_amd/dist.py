@@ -69,11 +69,14 @@ def all_reduce_sum_(tensor, group=None):
     return tensor
 
 
-def reference_means(local_sums, local_counts, out_dtype, group=None):
-    """All-reduce per-group float64 column sums and counts; return the R x G means (numpy).
+def reference_means(local_sums, local_counts, out_dtype, group=None, device_out=False):
+    """All-reduce per-group float64 column sums and counts; return the R x G means.
 
     ``local_sums``: torch float64 ``[R, G]`` on this rank's device (what ``icv_colsum`` produced for
     this rank's rows); ``local_counts``: length-R integer counts of this rank's rows per group.
+    Returns a numpy array of ``out_dtype``, or with ``device_out=True`` a torch tensor on the device of
+    ``local_sums`` (no host round trip: nothing synchronises with the host; an empty category then gives
+    NaN means instead of raising).
     """
     import torch
 
@@ -84,6 +87,9 @@ def reference_means(local_sums, local_counts, out_dtype, group=None):
     r = local_sums.shape[0]
     sums = packed[:-r].reshape(local_sums.shape)
     cnt = packed[-r:]
+    if device_out:
+        tdtype = {"float32": torch.float32, "float64": torch.float64}[np.dtype(out_dtype).name]
+        return (sums / cnt[:, None]).to(tdtype)
     if bool((cnt == 0).any()):
         raise ValueError("a reference category has no cells on any rank")
     return (sums / cnt[:, None]).cpu().numpy().astype(out_dtype)
@@ -155,7 +161,7 @@ def agree_aligned(local_aligned: bool, device="cpu", group=None) -> bool:
 
 
 def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_global=None, lfc_clip=3.0,
-              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None, all_bounds=None):
+              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None, all_bounds=None, out=None):
     """Hot path for this rank's rows of a row-sharded matrix (device resident).
 
     Whether the noise threshold needs communication is a property of the WHOLE partition, and every rank must
@@ -180,11 +186,11 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
             aligned = agree_aligned(aligned, ref_lo.device if hasattr(ref_lo, "device") else "cpu", group)
     if dynamic_threshold is None or aligned:
         return _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip,
-                                    dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags)
+                                    dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags, out=out)
     torch = _engine._torch()
     lib = _lib.load()
     res = _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip, dynamic_threshold=None,
-                               chunksize=chunksize, flags=flags, cell_stats=True)
+                               chunksize=chunksize, flags=flags, cell_stats=True, out=out)
     thr_all = global_thresholds(res.cell_stats, global_row0, n_obs_global, chunksize, plan.n_windows,
                                 float(dynamic_threshold), group)
     if rows == 0:

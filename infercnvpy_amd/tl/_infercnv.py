@@ -24,11 +24,12 @@ def _as_float_kind(dtype) -> str:
     return np.dtype(dtype).kind
 
 
-def _reference_rows(X, obs, reference_key, reference_cat, reference, n_vars, dm_slabs):
+def _reference_rows(X, obs, reference_key, reference_cat, reference, n_vars, dm_pieces):
     """R x G reference profile as a host float array (reference ``_get_reference``, :359-408).
 
     Means are computed on the GPU (float64 column sums / count) and rounded to the dtype numpy
     would have produced (float32 matrix -> float32 mean, everything else -> float64).
+    ``dm_pieces()`` yields ``(device matrix, row0, row1, global_row0)``: row ranges resident in HBM, in order.
     """
     if reference is not None:
         ref = np.asarray(reference)
@@ -40,9 +41,9 @@ def _reference_rows(X, obs, reference_key, reference_cat, reference, n_vars, dm_
             log.warning("Using mean of all cells as reference. For better results, provide either "
                         "`reference`, or both `reference_key` and `reference_cat`. ")
             sums, n = None, 0
-            for dm in dm_slabs():
-                sums = _engine.column_sums(dm, None, 1, sums)
-                n += dm.shape[0]
+            for dm, r0, r1, _ in dm_pieces():
+                sums = _engine.column_sums(dm, None, 1, sums, r0, r1)
+                n += r1 - r0
             ref = (sums / n).cpu().numpy().astype(mean_dtype)
         else:
             obs_col = obs[reference_key]
@@ -62,10 +63,9 @@ def _reference_rows(X, obs, reference_key, reference_cat, reference, n_vars, dm_
                 counts[gi] = int(sel.sum())
                 groups[sel & (groups < 0)] = gi
             dup = len(set(cats.tolist())) != len(cats)
-            sums, row = None, 0
-            for dm in dm_slabs():
-                sums = _engine.column_sums(dm, groups[row: row + dm.shape[0]], len(cats), sums)
-                row += dm.shape[0]
+            sums = None
+            for dm, r0, r1, g0 in dm_pieces():
+                sums = _engine.column_sums(dm, groups[g0: g0 + (r1 - r0)], len(cats), sums, r0, r1)
             sums = sums.cpu().numpy()
             if dup:  # same label listed twice: rows repeat
                 first = {c: i for i, c in reversed(list(enumerate(cats.tolist())))}
@@ -95,14 +95,25 @@ def infercnv(
     layer: str | None = None,
     key_added: str = "cnv",
     calculate_gene_values: bool = False,
+    _timings: dict | None = None,
 ):
     """Infer copy number variation by averaging gene expression over genomic regions (GPU).
 
     Parameters and return value as the reference function (``tl/_infercnv.py:18-96``).  ``n_jobs`` is
     accepted for compatibility and ignored (cells are processed by one workgroup each on the GPU;
     ``chunksize`` keeps its numerical meaning: the noise threshold is the standard deviation of
-    each ``chunksize``-cell chunk, reference :449-451).
+    each ``chunksize``-cell chunk, reference :449-451).  ``_timings`` (not part of the reference API): a dict
+    that receives the wall-clock seconds of the stages (plan, host -> HBM copy, kernels, CSR pack + copy back).
+
+    Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
+    while the pieces that have landed are smoothed (reference means: summed); X_cnv is packed to CSR on the
+    GPU from the un-thresholded result and a keep-mask (x_res is never rewritten) and only the packed arrays
+    cross PCIe on the way back.
     """
+    import time as _time
+
+    tm = _timings if _timings is not None else {}
+    t_start = _time.perf_counter()
     if not adata.var_names.is_unique:
         raise ValueError("Ensure your var_names are unique!")
     if {"chromosome", "start", "end"} - set(adata.var.columns) != set():
@@ -120,6 +131,9 @@ def infercnv(
         X = np.asarray(X)
     if sp.issparse(X):
         X = X.tocsr()
+        if not X.has_canonical_format:  # the kernels expect unique, sorted column indices per row
+            X = X.copy()
+            X.sum_duplicates()
     n_obs, n_vars = X.shape
     chunksize = int(chunksize)
     if chunksize < 1:
@@ -157,22 +171,33 @@ def infercnv(
     slab_rows = max(chunksize, slab_rows // chunksize * chunksize)
     bounds = [(r, min(n_obs, r + slab_rows)) for r in range(0, max(n_obs, 1), slab_rows)] if n_obs else []
 
-    cache = {}
+    # pieces of a slab: a few chunks each (~2 GB of input), copied by a helper thread while earlier ones compute
+    piece_rows = max(chunksize, int(2e9 // max(per_row, 1)) // chunksize * chunksize)
+    tm["plan"] = _time.perf_counter() - t_start
+    t_h2d = [0.0]
+    streams = {}
 
-    def slab(i):
-        if i not in cache:
-            if len(bounds) > 1:
-                cache.clear()
+    def slab_stream(i):
+        """Start (or return) the upload of slab i; only one slab is resident at a time."""
+        if i not in streams:
+            for k in list(streams):
+                t_h2d[0] += streams.pop(k).h2d_seconds
             r0, r1 = bounds[i]
             rows = X if (r0 == 0 and r1 == n_obs) else X[r0:r1]  # slicing a CSR matrix copies it
-            cache[i] = _engine.to_device_matrix(rows, dtype=tdtype)
-        return cache[i]
+            streams[i] = _engine.SlabStream(rows, tdtype, piece_rows)
+        return streams[i]
 
-    def dm_slabs():
-        for i in range(len(bounds)):
-            yield slab(i)
+    def dm_pieces():
+        for i, (g0, _) in enumerate(bounds):
+            ss = slab_stream(i)
+            for r0, r1 in ss.pieces():
+                yield ss.dm, r0, r1, g0 + r0
 
-    ref = _reference_rows(X, adata.obs, reference_key, reference_cat, reference, n_vars, dm_slabs)
+    need_means = reference is None
+    t0 = _time.perf_counter()
+    ref = _reference_rows(X, adata.obs, reference_key, reference_cat, reference, n_vars, dm_pieces)
+    if need_means:
+        tm["reference_pass"] = _time.perf_counter() - t0
     n_ref = ref.shape[0]
     flags = 0
     if n_ref == 1:
@@ -187,15 +212,33 @@ def infercnv(
             flags |= _lib.ICV_FLAG_ROUND_F32
 
     pieces, gene_pieces = [], []
-    for i, (r0, r1) in enumerate(bounds):
-        res = _engine.run_hot_path(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip,
-                                   dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags)
-        pieces.append(_engine.dense_to_host_csr(res.out, plan.n_windows))
+    t_pack = 0.0
+    t0 = _time.perf_counter()
+    for i in range(len(bounds)):
+        ss = slab_stream(i)  # a single slab that a reference pass has already brought in is not uploaded again
+        parts, thrs = [], []
+        for r0, r1 in ss.pieces():
+            res = _engine.run_hot_path(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
+                                       dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
+                                       row0=r0, row1=r1, apply=False)
+            parts.append(_engine.threshold_mask(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
+                                                chunksize=chunksize, flags=flags, row0=r0, row1=r1))
+            if res.thr is not None:
+                thrs.append(res.thr)
+        tp = _time.perf_counter()
+        pieces.append(_engine.packed_to_host_csr(parts, plan.n_windows))
+        t_pack += _time.perf_counter() - tp
         if calculate_gene_values:
-            gv = _engine.gene_values(plan, slab(i), ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr,
+            thr_all = torch.cat(thrs) if thrs else None
+            gv = _engine.gene_values(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=thr_all,
                                      chunksize=chunksize, flags=flags)
             gene_pieces.append(gv.cpu().numpy())
-    cache.clear()
+        del parts
+    for k in list(streams):
+        t_h2d[0] += streams.pop(k).h2d_seconds
+    tm["stream_and_kernels"] = _time.perf_counter() - t0 - t_pack
+    tm["h2d"] = t_h2d[0]
+    tm["csr_pack_d2h"] = t_pack
     if pieces:
         res_mat = sp.vstack(pieces).tocsr() if len(pieces) > 1 else pieces[0]
     else:
@@ -206,6 +249,7 @@ def infercnv(
     if calculate_gene_values:
         per_gene_mtx = np.vstack(gene_pieces) if gene_pieces else np.zeros((0, n_vars))
     plan.close()
+    tm["total"] = _time.perf_counter() - t_start
 
     if inplace:
         adata.obsm[f"X_{key_added}"] = res_mat
