@@ -706,8 +706,17 @@ def test_cell_linkage_and_heatmap_dendrogram():
     cnv.tl.cell_linkage(ad)
     Z = ad.uns["cnv_linkage"]["linkage"]
     np.testing.assert_array_equal(ad.uns["cnv_linkage"]["leaves"], leaves_list(Z))
+    # the cell-level Ward order is its own option; dendrogram=True keeps the reference's meaning (categories)
+    axes = cnv.pl.chromosome_heatmap(ad, groupby="g", cell_order="ward", show=False)
+    assert "heatmap_ax" in axes and "dendrogram_ax" not in axes
+    img = np.asarray(axes["heatmap_ax"].images[0].get_array())
+    rank = np.empty(300, dtype=np.int64)
+    rank[leaves_list(Z)] = np.arange(300)
+    order = np.concatenate([g[np.argsort(rank[g], kind="stable")] for g in (np.arange(0, 100), np.arange(100, 200),
+                                                                          np.arange(200, 300))])
+    np.testing.assert_allclose(img, X[order].astype(np.float64))
     axes = cnv.pl.chromosome_heatmap(ad, groupby="g", dendrogram=True, show=False)
-    assert "heatmap_ax" in axes
+    assert "dendrogram_ax" in axes
 
 
 def test_distance_row_blocks_and_single_process_sharded_driver():

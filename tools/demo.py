@@ -44,7 +44,7 @@ def main():
     print("linkage", Z.shape, "top merge height %.3f" % Z[-1, 2])
     out = os.path.join(ROOT, "gpurun_out", "demo_heatmap.png")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    axes = cnv.pl.chromosome_heatmap(adata, groupby="cell_type", dendrogram=True, show=False, save=out)
+    axes = cnv.pl.chromosome_heatmap(adata, groupby="cell_type", cell_order="ward", dendrogram=True, show=False, save=out)
     print("heatmap axes", sorted(axes), "->", out)
     score = cnv.tl.cnv_score(adata, "cell_type", inplace=False)
     assert score["tumorA"] > 1.5 * score["normal"] and score["tumorB"] > 1.3 * score["normal"]
