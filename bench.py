@@ -105,7 +105,7 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(window=100, step=10, cells_per_worker=100, reps=2):
+def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=3):
     from concurrent.futures import ProcessPoolExecutor
 
     cores = os.cpu_count() or 1

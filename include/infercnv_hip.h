@@ -112,7 +112,8 @@ int icv_plan_window_table(icv_plan_t plan, int32_t *h_start /* W */, int32_t *h_
  * Per-group column sums in float64.  h/d: `row_group` (device, n_rows int32; -1 = row not in
  * any group; NULL = every row in group 0).  `sums` (device, n_groups x n_cols float64) is
  * ACCUMULATED into, so shards / ranks can add up before the caller divides by the counts.
- * Dense sums are deterministic (fixed reduction tree); CSR sums use float64 atomics.
+ * Dense and CSR sums are deterministic (fixed reduction order; CSR: one wavefront per row slab adds into LDS
+ * accumulators in row order).
  */
 int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, double *sums,
                void *stream);
@@ -237,6 +238,11 @@ int icv_ward_linkage(float *dist_sq, int64_t n, int64_t ld, double *h_linkage, i
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);
+
+/* the same on a CSR X_cnv (values float32 or float64, `indptr` n_rows + 1 int64 offsets into `data`): only the
+ * stored entries are read, nothing is densified */
+int icv_csr_row_abs_sum(const void *data, int32_t dtype, const int64_t *indptr, int64_t n_rows, double *row_sum,
+                        void *stream);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 const char *icv_last_error(void);

@@ -335,6 +335,20 @@ def row_abs_sum(x_cnv):
     return res
 
 
+def csr_row_abs_sum(x_csr):
+    """per-row sum |x| of a host scipy CSR matrix: only indptr and the stored values go to the GPU."""
+    torch = _torch()
+    lib = _lib.load()
+    x_csr = x_csr.tocsr()
+    data = x_csr.data if x_csr.data.dtype in (np.float32, np.float64) else x_csr.data.astype(np.float64)
+    d = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    ip = torch.from_numpy(np.ascontiguousarray(x_csr.indptr.astype(np.int64, copy=False))).cuda()
+    res = torch.empty(x_csr.shape[0], dtype=torch.float64, device="cuda")
+    _lib.check(lib.icv_csr_row_abs_sum(_ptr(d), _lib.ICV_F32 if data.dtype == np.float32 else _lib.ICV_F64, _ptr(ip),
+                                       x_csr.shape[0], _ptr(res), _stream_ptr(torch)))
+    return res
+
+
 def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, thr=None, chunksize=5000,
                 row_phase=0, flags=0):
     """calculate_gene_values: float64 ``rows x n_vars`` device tensor, NaN where a gene has no value."""

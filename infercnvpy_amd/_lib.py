@@ -27,7 +27,7 @@ EXPORTS = (
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_corr_iqr",
-    "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_row_abs_sum", "icv_last_error", "icv_version",
+    "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_last_error", "icv_version",
     "icv_device_count",
 )
 
@@ -100,6 +100,7 @@ def load():
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]
     lib.icv_ward_linkage.argtypes = [vp, i64, i64, vp, P(i32), vp]
     lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]
+    lib.icv_csr_row_abs_sum.argtypes = [vp, i32, vp, i64, vp, vp]
     lib.icv_last_error.restype = C.c_char_p
     lib.icv_last_error.argtypes = []
     for name in EXPORTS:

@@ -97,6 +97,31 @@ struct PlanBusy {
     if (!busy_guard_.ok)                                                                             \
         return fail(ICV_ERR_INVALID, "plan busy: one compute call at a time per plan (see icv_plan_create)")
 
+// stream-ordered temporary: freed on every exit path (error paths leaked their buffers)
+struct AsyncBuf {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    ~AsyncBuf() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+    hipError_t alloc(size_t bytes, hipStream_t s) {
+        st = s;
+        return hipMallocAsync(&p, bytes ? bytes : 16, s);
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+// events of a timed run: destroyed on exit unless handed over to the plan (deferred profiling)
+struct EventSet {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool keep = false;
+    ~EventSet() {
+        if (!keep)
+            for (auto& e : ev)
+                if (e) (void)hipEventDestroy(e);
+    }
+};
+
 int ensure_device(icv_plan_t pl) {
     std::lock_guard<std::mutex> lk(pl->mu);
     int dev = 0;
@@ -324,6 +349,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     void (*kern)(const icv::KParams) = nullptr;
     constexpr int U = icv::kFastUMax;
     K.scratch_off = p.fast_scratch_off;
+    AsyncBuf ws_guard;  // prepared CSR entries: released on every exit path
     void* ws_buf = nullptr;
     if (!p.ws_ok) return -1;  // caller falls back to the generic kernel
     {
@@ -341,7 +367,8 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
                                static_cast<float*>(pl->d_zrow), nz);
             const int64_t n = csr_end - csr_begin;
-            HIP_TRY(hipMallocAsync(&ws_buf, (size_t)(n > 0 ? n : 1) * 6, st));
+            HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));
+            ws_buf = ws_guard.p;
             float* cv = static_cast<float*>(ws_buf);
             uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
             K.cvals = cv - csr_begin;  // indexed by the absolute entry number
@@ -410,7 +437,6 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     } else {
         rc = run_kernel(kern, grid, p.fast_lds, K, st);
         if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
-        if (ws_buf) HIP_TRY(hipFreeAsync(ws_buf, st));
         if (rc) return rc;
         // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)
         hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
@@ -684,13 +710,22 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nc = m->n_cols;
     if (m->format == ICV_CSR) {
-        const int rows_per_slab = 512;
+        // one wavefront per (slab, column tile): slabs sized so that every CU gets a few of them
+        int n_cu = 256;
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                n_cu = prop.multiProcessorCount;
+        }
+        int rows_per_slab = (int)((m->n_rows + (int64_t)n_cu * 4 - 1) / ((int64_t)n_cu * 4));
+        if (rows_per_slab < 64) rows_per_slab = 64;
         const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
         const int n_tiles = (nc + icv::kCsrTileCols - 1) / icv::kCsrTileCols;
-        const int lds = icv::kCsrTileCols * (int)sizeof(double);
+        const int lds = (nc < icv::kCsrTileCols ? nc : icv::kCsrTileCols) * (int)sizeof(double);
         double* partial = nullptr;
         HIP_TRY(hipMallocAsync((void**)&partial, (size_t)n_slabs * nc * sizeof(double), st));
-        dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(512);
+        dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(64);
         void (*kf)(const float*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
             icv::k_colsum_csr<float>;
         void (*kd)(const double*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
@@ -828,11 +863,12 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
             K.row_phase = ph_eff;
         }
     }
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    EventSet evs;
+    hipEvent_t* ev = evs.ev;
     const bool deferred = !prof && pl->prof_deferred;
     const bool timed = prof || deferred;
     if (timed) {
-        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipEventCreate(&ev[i]));
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     bool ev1_done = false;
@@ -855,14 +891,14 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     if (do_thr && !(flags & ICV_FLAG_NO_APPLY) && (rc = launch_apply(m, K, thr, chunksize, row_phase, st))) return rc;
     if (timed) HIP_TRY(hipEventRecord(ev[3], st));
     if (deferred) {  // no synchronisation here: the times are read by icv_profile_collect
-        for (auto& e : ev) pl->prof_events.push_back(e);
+        for (int i = 0; i < 4; ++i) pl->prof_events.push_back(ev[i]);
+        evs.keep = true;
     } else if (prof) {
         HIP_TRY(hipEventSynchronize(ev[3]));
         HIP_TRY(hipEventElapsedTime(&prof->smooth_ms, ev[0], ev[1]));
         HIP_TRY(hipEventElapsedTime(&prof->thresholds_ms, ev[1], ev[2]));
         HIP_TRY(hipEventElapsedTime(&prof->apply_ms, ev[2], ev[3]));
         HIP_TRY(hipEventElapsedTime(&prof->total_ms, ev[0], ev[3]));
-        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return ICV_OK;
 }
@@ -912,14 +948,16 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     if (n < 1) return ICV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int W = p.W, n_cov = (int)p.cov_col.size();
-    float* out32 = nullptr;
-    double *win = nullptr, *gv = nullptr, *med = nullptr, *cmed = nullptr, *cstat = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&out32, (size_t)n * W * sizeof(float), st));
-    HIP_TRY(hipMallocAsync((void**)&win, (size_t)n * W * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&gv, (size_t)n * (n_cov > 0 ? n_cov : 1) * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&med, (size_t)n * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&cmed, (size_t)n * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&cstat, (size_t)n * 2 * sizeof(double), st));
+    AsyncBuf b_out32, b_win, b_gv, b_med, b_cmed, b_cstat;
+    HIP_TRY(b_out32.alloc((size_t)n * W * sizeof(float), st));
+    HIP_TRY(b_win.alloc((size_t)n * W * sizeof(double), st));
+    HIP_TRY(b_gv.alloc((size_t)n * (n_cov > 0 ? n_cov : 1) * sizeof(double), st));
+    HIP_TRY(b_med.alloc((size_t)n * sizeof(double), st));
+    HIP_TRY(b_cmed.alloc((size_t)n * sizeof(double), st));
+    HIP_TRY(b_cstat.alloc((size_t)n * 2 * sizeof(double), st));
+    float* out32 = b_out32.as<float>();
+    double *win = b_win.as<double>(), *gv = b_gv.as<double>(), *med = b_med.as<double>(), *cmed = b_cmed.as<double>(),
+           *cstat = b_cstat.as<double>();
     icv::KParams K;
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out32, W, cmed, cstat, K, lay))) return rc;
@@ -955,13 +993,7 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(out32, st));
-    HIP_TRY(hipFreeAsync(win, st));
-    HIP_TRY(hipFreeAsync(gv, st));
-    HIP_TRY(hipFreeAsync(med, st));
-    HIP_TRY(hipFreeAsync(cmed, st));
-    HIP_TRY(hipFreeAsync(cstat, st));
-    return ICV_OK;
+    return ICV_OK;  // the stream-ordered temporaries are released by their guards
 }
 
 int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
@@ -1235,6 +1267,23 @@ int icv_row_abs_sum(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, 
     if (n_rows < 1) return ICV_OK;
     hipLaunchKernelGGL(icv::k_row_abs_sum, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld, row_sum);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_csr_row_abs_sum(const void* data, int32_t dtype, const int64_t* indptr, int64_t n_rows, double* row_sum,
+                        void* stream) {
+    if (!indptr || !row_sum || (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad csr_row_abs_sum arguments");
+    if (n_rows < 1) return ICV_OK;
+    dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(icv::k_csr_row_abs_sum<float>, grid, block, 0, st, static_cast<const float*>(data), indptr,
+                           n_rows, row_sum);
+    else
+        hipLaunchKernelGGL(icv::k_csr_row_abs_sum<double>, grid, block, 0, st, static_cast<const double*>(data), indptr,
+                           n_rows, row_sum);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

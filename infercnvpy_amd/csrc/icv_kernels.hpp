@@ -1008,36 +1008,53 @@ __global__ void __launch_bounds__(1024) k_colsum_finish(const double* partial, i
     }
 }
 
-// CSR: a workgroup owns (row slab) x (tile of 8192 columns): float64 accumulators in LDS (ds_add_f64),
-// one pass over the slab's entries per column tile, then the tile goes to partial[slab][...] and
-// k_colsum_finish adds the slabs.  (Global float64 atomics on 20 000 addresses serialise badly.)
-constexpr int kCsrTileCols = 8192;
+// CSR: ONE wavefront owns (row slab) x (tile of up to 20 000 columns = 160 000 B of float64 accumulators in LDS,
+// the whole LDS of a CU).  The rows of the slab are walked in order and every batch of 64 stored entries of a row
+// is added with one ds_add_f64: the columns of a row are distinct, the LDS executes the instructions of a
+// wavefront in order, so every column receives its addends in row order -- deterministic, unlike several
+// wavefronts adding into one tile.  The tile then goes to partial[slab][...] and k_colsum_finish adds the slabs
+// in a fixed order.  Loads of the next batches are issued before the adds of the current one.
+constexpr int kCsrTileCols = 20000;
 template <typename T>
-__global__ void __launch_bounds__(512) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
-                                                    int64_t n_rows, int n_cols, const int32_t* row_group, int group,
-                                                    int rows_per_slab, double* partial /* n_slabs x n_cols */) {
+__global__ void __launch_bounds__(64) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
+                                                   int64_t n_rows, int n_cols, const int32_t* row_group, int group,
+                                                   int rows_per_slab, double* partial /* n_slabs x n_cols */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);
     const int c0 = blockIdx.x * kCsrTileCols;
     const int nc = (n_cols - c0) < kCsrTileCols ? (n_cols - c0) : kCsrTileCols;
-    for (int i = threadIdx.x; i < nc; i += 512) tile[i] = 0.0;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nc; i += 64) tile[i] = 0.0;
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
     int64_t r1 = r0 + rows_per_slab;
     if (r1 > n_rows) r1 = n_rows;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t row = r0 + wave; row < r1; row += 8) {
+    constexpr int U = 4;
+    for (int64_t row = r0; row < r1; ++row) {
         if (row_group && row_group[row] != group) continue;
         const int64_t e = indptr[row + 1];
-        for (int64_t k = indptr[row] + lane; k < e; k += 64) {
-            const int c = indices[k] - c0;
-            if (c >= 0 && c < nc)
-                __hip_atomic_fetch_add(tile + c, (double)vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int64_t k0 = indptr[row]; k0 < e; k0 += 64 * U) {
+            int c[U];
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t k = k0 + u * 64 + lane;
+                c[u] = -1;
+                v[u] = 0.0;
+                if (k < e) {
+                    c[u] = indices[k] - c0;
+                    v[u] = (double)vals[k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (c[u] >= 0 && c[u] < nc)
+                    __hip_atomic_fetch_add(tile + c[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
     double* dst = partial + (int64_t)blockIdx.y * n_cols + c0;
-    for (int i = threadIdx.x; i < nc; i += 512) dst[i] = tile[i];
+    for (int i = lane; i < nc; i += 64) dst[i] = tile[i];
 }
 
 // cnv_score: per-row sum |x| (tl/_scores.py:66), one wavefront per row, float64
@@ -1242,6 +1259,20 @@ __global__ void __launch_bounds__(256) k_csr_fill(const float* x, int64_t n_rows
         }
         base += __popcll(m);
     }
+}
+
+// cnv_score on a CSR X_cnv: per-row sum |data| over the stored entries (implicit zeros add nothing), float64,
+// one wavefront per row, fixed reduction order
+template <typename T>
+__global__ void __launch_bounds__(256) k_csr_row_abs_sum(const T* data, const int64_t* indptr, int64_t n_rows,
+                                                         double* row_sum) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    double acc = 0.0;
+    const int64_t e = indptr[row + 1];
+    for (int64_t k = indptr[row] + (threadIdx.x & 63); k < e; k += 64) acc += fabs((double)data[k]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
 }
 
 // pack the kept entries (bit mask of k_thr_mask) of the dense float32 result: one wavefront per row

@@ -28,11 +28,12 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
 
     torch = _engine._torch()
     x = adata.obsm[f"X_{use_rep}"]
-    if sp.issparse(x):
-        x = x.toarray()
-    x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
-    row_abs = _engine.row_abs_sum(torch.from_numpy(x).cuda()).cpu().numpy()
     n_win = x.shape[1]
+    if sp.issparse(x):  # what tl.infercnv writes: CSR float64 -- only the stored values travel, in float64
+        row_abs = _engine.csr_row_abs_sum(x).cpu().numpy()
+    else:
+        x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+        row_abs = _engine.row_abs_sum(torch.from_numpy(x).cuda()).cpu().numpy()
 
     labels = adata.obs[groupby]
     values = np.asarray(labels.values if hasattr(labels, "values") else labels)

@@ -214,6 +214,10 @@ def test_column_sums_and_reference_means():
         s_grp = _engine.column_sums(dm, groups, 3).cpu().numpy()
         for gi in range(3):
             np.testing.assert_allclose(s_grp[gi], X[groups == gi].sum(axis=0, dtype=np.float64), rtol=1e-13)
+        # bitwise reproducible run to run, dense and CSR alike (no floating-point atomics whose order can vary)
+        for _ in range(3):
+            assert np.array_equal(_engine.column_sums(dm).cpu().numpy()[0], s_all)
+            assert np.array_equal(_engine.column_sums(dm, groups, 3).cpu().numpy(), s_grp)
     torch.cuda.synchronize()
 
 
