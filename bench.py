@@ -354,6 +354,7 @@ def main():
             "traffic": traffic,
             "bytes_per_cell": bytes_per_cell,
             "kernel_ms": avg_smooth_ms,
+            "kernel_ms_min_max": [min(smooth_ms), max(smooth_ms)],
             "cells_per_launch": n_local,
         },
     }

@@ -267,6 +267,7 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.pad_idx = pl->d_pad;
     K.w_pack = pl->d_wpack;
     K.x16_wdesc = pl->d_x16_wdesc;
+    K.x16_half = p.x16_half;
     K.n_pad = (int32_t)p.pad_idx.size();
     K.pyr_den = p.pyr_den;
     K.pyr_rcp = p.pyr_rcp;
@@ -335,8 +336,9 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
 bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay) {
     const icv::Plan& p = pl->p;
     return lay.fits && m->dtype == ICV_F32 && m->format == ICV_DENSE && p.ws_ok && K.vec_ok && std::isfinite(K.cap) &&
-           !std::getenv("ICV_FORCE_GENERIC") && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16") && p.B == 10 &&
-           p.window == 100;
+           !std::getenv("ICV_FORCE_GENERIC") && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16") &&
+           p.step == 10 &&
+           ((p.B == 10 && p.window == 100 && p.x16_fine == 4096) || (p.B == 5 && p.window == 250 && p.x16_fine == 1024));
 }
 
 // float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
@@ -418,8 +420,12 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     // kernel, one 1024-thread workgroup per CU (ICV_NO_X16=1: developer knob, previous generation)
     void (*xk)(const icv::KParams) = nullptr;
     if (!csr && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16")) {
-        if (p.B == 10 && p.window == 100)
-            xk = K.chunk_part ? icv::k_smooth_x16<10, 10, true> : icv::k_smooth_x16<10, 10, false>;
+        if (p.step != 10)
+            xk = nullptr;  // the instantiations below assume step 10 (blocks between adjacent windows)
+        else if (p.B == 10 && p.window == 100 && p.x16_fine == 4096)
+            xk = K.chunk_part ? icv::k_smooth_x16<10, 10, 1, true, 4096, true> : icv::k_smooth_x16<10, 10, 1, false, 4096, true>;
+        else if (p.B == 5 && p.window == 250 && p.x16_fine == 1024)
+            xk = K.chunk_part ? icv::k_smooth_x16<5, 50, 2, true, 1024, false> : icv::k_smooth_x16<5, 50, 2, false, 1024, false>;
     }
     if (xk) {
         icv::KParams X = K;

@@ -9,7 +9,7 @@
 //   * all 16 wavefronts run the same phase; row, {S0,S1} and the histograms are separate LDS regions (149 KB of
 //     160 KB), nothing aliases, TWO barriers per cell;
 //   * a thread sums two adjacent blocks per S pass (16-byte LDS reads) and the windows t, t + W/2 and two ADJACENT windows of one chromosome:
-//     11 conflict-free {S0,S1} reads serve both windows;
+//     NBW + step / BT conflict-free {S0,S1} reads serve both windows;
 //   * median: a 4096-bin histogram (32-bit LDS atomics) plus a 64-bin coarse histogram (4 replicas) -- ONE
 //     wavefront resolves the two middle ranks with two 64-lane DPP prefix sums (coarse, then the 64 fine bins of
 //     the located coarse bin), the windows of those bins are gathered, one wavefront ranks them exactly in
@@ -37,11 +37,11 @@ namespace icv {
 constexpr int XT = 1024;
 constexpr int XWAVE = XT / 64;
 constexpr int XU = 5;        // 16-byte row vectors per thread
-constexpr int XFINE = 4096;  // fine histogram bins (32-bit counters), same binning as k_smooth_ws
-constexpr int XCOARSE = 64;  // coarse bin = fine bin >> 6
-constexpr int XREP = 16;     // replicas of every coarse bin (lane & 15), adjacent in LDS: lanes of one atomic
-                             // instruction that share a coarse bin hit different banks
-static_assert(XREP * XCOARSE == XT && kX16HistBytes == 2 * (XFINE * 4 + XREP * XCOARSE * 4), "plan and kernel agree on the histogram bytes");
+// histogram: FINE bins (32-bit counters; 4096 for the window-100 geometry = the k_smooth_ws binning, 1024 where LDS
+// is short) + FINE / 64 coarse bins (coarse = fine >> 6), each coarse bin in XREP replicas (lane & 15) adjacent in
+// LDS: lanes of one atomic instruction that share a coarse bin hit different banks.  Both cell parities.
+constexpr int XREP = 16;
+constexpr int x16_hist_bytes(int fine) { return 2 * (fine * 4 + XREP * (fine / 64) * 4); }
 
 struct ScratchX {
     int sel[2][8];  // located bins of the two middle ranks: b1, b2, below, c1, c2, nan
@@ -68,20 +68,26 @@ __device__ __forceinline__ double2 wave_moments(double sum, double sq) {
     return make_double2(readlane_d(v, 0) + readlane_d(v, 16), readlane_d(v, 32) + readlane_d(v, 48));
 }
 
-// Monotone non-decreasing map window value -> fine bin, the k_smooth_ws binning with the scale folded into one
-// FMA and floor + convert in one instruction (v_cvt_flr_i32_f32): 5 VALU for the central segment.
+// Monotone non-decreasing map window value -> fine bin (the k_smooth_ws binning scaled to FINE bins: the central
+// quarter of [-bound, bound] gets 3/4 of the bins, each tail 1/8), scale folded into one FMA, floor + convert in one
+// instruction (v_cvt_flr_i32_f32): 5 VALU for the central segment.
+template <int FINE>
 __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_scale, float c_thr) {
+    constexpr int T = FINE / 8;  // bins per tail
     const float f = (float)v;
-    if (__builtin_expect(fabsf(f) < c_thr, 1)) {  // |u| < 1/8: 3072 bins
+    if (__builtin_expect(fabsf(f) < c_thr, 1)) {  // |u| < 1/8: 3 FINE / 4 bins
         int b;
-        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(fmaf(f, c_scale, 2048.0f)));
-        return b < 512 ? 512 : (b > 3583 ? 3583 : b);  // segments stay disjoint under rounding
+        asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(fmaf(f, c_scale, (float)(FINE / 2))));
+        return b < T ? T : (b > FINE - T - 1 ? FINE - T - 1 : b);  // segments stay disjoint under rounding
     }
-    const float u = f * inv_bound;
+    float ct = c_thr;
+    asm volatile("" : "+v"(ct));  // formed here, not hoisted: the (rare) tail path keeps no register alive
+    const float u = f * (0.125f / ct);  // = f / bound
+    (void)inv_bound;
     float g;
     int lo_b, hi_b;
-    if (u < 0.0f) { g = (u + 1.0f) * (512.0f / 0.875f); lo_b = 0; hi_b = 511; }
-    else { g = fmaf(u - 0.125f, 512.0f / 0.875f, 3584.0f); lo_b = 3584; hi_b = XFINE - 1; }
+    if (u < 0.0f) { g = (u + 1.0f) * ((float)T / 0.875f); lo_b = 0; hi_b = T - 1; }
+    else { g = fmaf(u - 0.125f, (float)T / 0.875f, (float)(FINE - T)); lo_b = FINE - T; hi_b = FINE - 1; }
     const int b = (int)floorf(g);  // NaN -> 0 after the clamps; the cell is flagged separately
     return b < lo_b ? lo_b : (b > hi_b ? hi_b : b);
 }
@@ -101,8 +107,12 @@ __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_sca
 
 // CHUNK: the moments of x_res are accumulated per thread over the consecutive cells of a noise-threshold chunk and
 // reduced once per chunk (P.chunk_part), instead of one 16-wavefront reduction per cell (P.cell_part)
-template <int BT, int NBW, bool CHUNK>
+// REFRES: the reference row lives in registers for the whole kernel (20 VGPRs); false: re-read from L2 at the start
+// of every L phase (long windows need the registers for larger batches of {S0,S1} reads)
+template <int BT, int NBW, int SB /* blocks between adjacent windows = step / BT */, bool CHUNK, int FINE, bool REFRES>
 __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
+    constexpr int XFINE = FINE, XCOARSE = FINE / 64;
+    static_assert(FINE % 1024 == 0 && XCOARSE * XREP <= XT && FINE / 4 <= XT, "histogram cleared by one store per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* row = reinterpret_cast<float*>(smem);
     double* S01 = reinterpret_cast<double*>(smem + P.win_off);
@@ -110,15 +120,18 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     unsigned* coarse = hist + 2 * XFINE;
     ScratchX* sc = reinterpret_cast<ScratchX*>(smem + P.scratch_off);
     float* stage = reinterpret_cast<float*>(smem + P.scratch_off + kFastScratchBytes);  // x_res of one cell (16-byte stores)
-    static_assert(BT >= 2 && (BT & 1) == 0 && NBW > 0 && NBW % 2 == 0, "even compile-time block size");
-    static_assert((2 * BT * 4) % 16 == 0, "a thread's two blocks are read as 16-byte vectors");
+    static_assert(BT >= 2 && NBW > 0 && NBW % 2 == 0, "compile-time block size, even number of blocks per window");
+
 
     const int t = threadIdx.x;
     const int W = P.W, NB = P.NB;
     const int k1 = (W - 1) / 2, k2 = W / 2;
-    const float inv_bound = (float)(1.0 / P.med_bound);
-    const float c_scale = inv_bound * (3072.0f / 0.25f), c_thr = 0.125f * (float)P.med_bound;
-    const float cap = (float)P.cap;
+    // wavefront-uniform float constants, forced into SGPRs (they come out of float64 -> float32 conversions, which
+    // would otherwise park them in VGPRs for the whole kernel)
+    auto uniform = [](float x) { return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+    const float inv_bound = uniform((float)(1.0 / P.med_bound));
+    const float c_scale = uniform(inv_bound * ((float)(3 * FINE / 4) / 0.25f)), c_thr = uniform(0.125f * (float)P.med_bound);
+    const float cap = uniform((float)P.cap);
     const unsigned row_bytes = (unsigned)P.n_cols * 4u;
     const unsigned voff = (unsigned)t * 16u;
     const double pyr_den = P.pyr_den, pyr_rcp = P.pyr_rcp;
@@ -129,18 +142,18 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         __builtin_trap();  // the L phase addresses the row by absolute LDS offsets
 
     // ---- per-thread constants, loaded once -------------------------------------------------------
-    u32x4 refv[XU];
+    u32x4 refv[REFRES ? XU : 1];
+    const __amdgpu_buffer_rsrc_t ref_rs = make_rsrc(P.ref_lo, row_bytes);
 #if ICV_X_ADDR
     unsigned laddr[XU][4];
 #else
     u32x2 dtab[XU];
 #endif
     {
-        const __amdgpu_buffer_rsrc_t lo_rs = make_rsrc(P.ref_lo, row_bytes);
         const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(XU * XT * 8));
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            refv[u] = __builtin_amdgcn_raw_buffer_load_b128(lo_rs, voff, u * XT * 16, 0);
+            if constexpr (REFRES) refv[u] = __builtin_amdgcn_raw_buffer_load_b128(ref_rs, voff, u * XT * 16, 0);
             const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, (unsigned)t * 8u, u * XT * 8, 0);
 #if ICV_X_ADDR
 #ifdef ICV_X_EXP_LINSCAT  // timing experiment (wrong results): conflict-free scatter addresses
@@ -163,18 +176,22 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     }
     // windows: thread t owns the adjacent windows j0, j0 + 1 of ONE chromosome (plan table x16_wdesc: first block,
     // first window, validity, "full pyramid window"), so the two windows share 9 of their 10 {S0,S1} pairs: 11 LDS
-    // reads for both instead of 20.  {S0,S1} of block b lives at slot (b >> 1) + 1024 (b & 1): the reads of a
+    // reads for both instead of 20.  {S0,S1} of block b lives at slot (b >> 1) + half (b & 1): the reads of a
     // wavefront (block stride 2 between lanes) and the writes of the S phase are 16-byte strided, conflict-free.
     const unsigned wdx = P.x16_wdesc[t];
     const int wb0 = (int)(wdx & 0xfffu), wj0 = (int)((wdx >> 12) & 0xfffu);
     const bool valid0 = (wdx >> 24) & 1u, valid1 = (wdx >> 25) & 1u;
-    const unsigned spA = (unsigned)P.win_off + (unsigned)((wb0 >> 1) + 1024 * (wb0 & 1)) * 16u;              // block b0
-    const unsigned spB = (unsigned)P.win_off + (unsigned)(((wb0 + 1) >> 1) + 1024 * ((wb0 + 1) & 1)) * 16u;  // block b0+1
+    constexpr int INTER = 2 * SB;  // {S0,S1} of block b lives in array b % INTER at slot b / INTER
+    const int half = P.x16_half;   // slots per array
+    unsigned spK[INTER];           // LDS byte address of blocks b0, b0 + 1, ..., b0 + INTER - 1
+#pragma unroll
+    for (int k = 0; k < INTER; ++k)
+        spK[k] = (unsigned)P.win_off + (unsigned)((wb0 + k) / INTER + half * ((wb0 + k) % INTER)) * 16u;
     const bool wave_w = __builtin_amdgcn_ballot_w64(valid0) != 0;  // the wavefront has windows at all
     const bool wfull = __builtin_amdgcn_ballot_w64((valid0 && !((wdx >> 26) & 1u)) || (valid1 && !((wdx >> 27) & 1u))) == 0;
     // pad slots and the trash slot are written once: nothing aliases the row
     for (int i = t; i < P.n_pad; i += XT) row[P.pad_idx[i]] = 0.0f;
-    for (int i = t; i < kX16HistBytes / 4; i += XT) hist[i] = 0u;
+    for (int i = t; i < x16_hist_bytes(FINE) / 4; i += XT) hist[i] = 0u;
     if (t < 2) {
         sc->ncand[t] = 0;
         sc->nanflag[t] = 0;
@@ -186,7 +203,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     // against two 4-byte stores per thread): needs 16-byte aligned rows
     const bool st16 = ((P.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0);
     for (int i = t; i < ((W + 3) & ~3); i += XT) stage[i] = 0.0f;
-    for (int i = t; i < 2 * 2048; i += XT) S01[i] = 0.0;  // slots past the last block are read (and discarded)
+    for (int i = t; i < 2 * INTER * half; i += XT) S01[i] = 0.0;  // slots past the last block are read (and discarded)
 
     u32x4 xq[XU];
     {
@@ -211,12 +228,18 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (more ? c_next : 0) * P.ld, more ? row_bytes : 0u);
 #endif
 #endif
+        u32x4 rloc[REFRES ? 1 : XU];
+        if constexpr (!REFRES) {
+#pragma unroll
+            for (int u = 0; u < XU; ++u) rloc[u] = __builtin_amdgcn_raw_buffer_load_b128(ref_rs, voff, u * XT * 16, 0);
+        }
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            const float y0 = __uint_as_float(xq[u].x) - __uint_as_float(refv[u].x);
-            const float y1 = __uint_as_float(xq[u].y) - __uint_as_float(refv[u].y);
-            const float y2 = __uint_as_float(xq[u].z) - __uint_as_float(refv[u].z);
-            const float y3 = __uint_as_float(xq[u].w) - __uint_as_float(refv[u].w);
+            const u32x4 rv = REFRES ? refv[REFRES ? u : 0] : rloc[REFRES ? 0 : u];
+            const float y0 = __uint_as_float(xq[u].x) - __uint_as_float(rv.x);
+            const float y1 = __uint_as_float(xq[u].y) - __uint_as_float(rv.y);
+            const float y2 = __uint_as_float(xq[u].z) - __uint_as_float(rv.z);
+            const float y3 = __uint_as_float(xq[u].w) - __uint_as_float(rv.w);
             // v_med3 drops NaNs, np.clip keeps them: unordered pairs take the (never taken on real data) fix-up
             const bool un = __builtin_isunordered(y0, y1) | __builtin_isunordered(y2, y3);
 #if ICV_X_ADDR
@@ -263,7 +286,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 
     // windows 2t, 2t+1 of cells of even / odd iteration (double buffered), and their fine bins (-1: no window)
     double wvE0 = 0.0, wvE1 = 0.0, wvO0 = 0.0, wvO1 = 0.0;
-    int wbE0 = -1, wbE1 = -1, wbO0 = -1, wbO1 = -1;
+    unsigned wbE = 0xffffffffu, wbO = 0xffffffffu;  // two 16-bit bins per register (0xffff: no window)
     __syncthreads();
 
 #ifdef ICV_X_PROFILE
@@ -285,6 +308,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 #define ICV_XPH(i)
 #endif
 
+    const int s_q = ((NB + 1) / 2 + XT - 1) / XT;  // S passes per wavefront on average (1: window 100, 2: window 250)
     // CHUNK: running moments of this thread's windows over the cells of the current chunk
     double accS = 0.0, accQ = 0.0;
     int64_t chunk_cur = -1, chunk_end = INT64_MIN;
@@ -293,8 +317,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     (void)chunk_cur;
     (void)chunk_end;
     // one iteration; wvA/wbA: registers of cells with the parity of `it`, wvB/wbB: the other parity
-    auto iteration = [&](int64_t it, int p0, double& wvA0, double& wvA1, int& wbA0, int& wbA1, double& wvB0, double& wvB1,
-                         int& wbB0, int& wbB1) __attribute__((always_inline)) {
+    auto iteration = [&](int64_t it, int p0, double& wvA0, double& wvA1, unsigned& wbA, double& wvB0, double& wvB1,
+                         unsigned& wbB) __attribute__((always_inline)) {
         const int p1 = p0 ^ 1;
         const int64_t cell = (int64_t)blockIdx.x + it * gridDim.x;
         const bool have0 = it < n_mine;                 // cell it: S, W
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             // (all LDS reads of a step are issued together: one round trip, not one per use)
             const unsigned* cz = coarse + p1 * (XREP * XCOARSE);
             const unsigned* fz = hist + p1 * XFINE;
-            const uint4* c4 = reinterpret_cast<const uint4*>(cz + tl * XREP);
+            const uint4* c4 = reinterpret_cast<const uint4*>(cz + (tl < XCOARSE ? tl : 0) * XREP);
             const int nanf = sc->nanflag[p1];
             const uint4 ca = c4[0], cb = c4[1], cc = c4[2], cd = c4[3];
             if (nanf) {
@@ -339,8 +363,9 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                     sc->sel[p1][5] = 1;
                 }
             } else {
-                const int c = (int)((((ca.x + ca.y) + (ca.z + ca.w)) + ((cb.x + cb.y) + (cb.z + cb.w))) +
-                                    (((cc.x + cc.y) + (cc.z + cc.w)) + ((cd.x + cd.y) + (cd.z + cd.w))));
+                const int csum = (int)((((ca.x + ca.y) + (ca.z + ca.w)) + ((cb.x + cb.y) + (cb.z + cb.w))) +
+                                       (((cc.x + cc.y) + (cc.z + cc.w)) + ((cd.x + cd.y) + (cd.z + cd.w))));
+                const int c = tl < XCOARSE ? csum : 0;
                 const int cincl = wave_scan_dpp(c);
                 int Cprev = -1, f = 0, fincl = 0;
                 int res[2][3];
@@ -395,23 +420,38 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             }
         }
         ICV_XPH(7)
-        if (have0 && tl >= 128) {
-            // ---- S: block partial sums, straight into their own LDS region.  Pass 0: wavefront w = 2..15 takes the
-            // block pairs 64 (w - 2) + lane; pass 1: wavefronts 4, 5 take the pairs 64 (w + 10) + lane
+        if (have0) {
+            // ---- S: block partial sums, straight into their own LDS region.  A pass of a wavefront covers 64
+            // pairs of adjacent blocks.  With q = ceil(pairs / 1024) passes per wavefront on average, the chain
+            // wavefronts 0, 1 take q - 1 passes, wavefronts 4, 5 (same SIMDs) q + 1, the others q: every SIMD
+            // issues 4 q passes.  Pass k of wavefront w covers slot base(w) + k (slots dealt in wavefront order).
             const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
-            const int n_pass = (wv_id == 4 || wv_id == 5) ? 2 : 1;
+            const int q = s_q;
+            const int n_pass = wv_id < 2 ? q - 1 : ((wv_id == 4 || wv_id == 5) ? q + 1 : q);
+            // slots before wavefront w: w * q - min(w, 2) + (w > 4) + (w > 5)
+            const int slot0 = wv_id * q - (wv_id < 2 ? wv_id : 2) + (wv_id > 4 ? 1 : 0) + (wv_id > 5 ? 1 : 0);
             for (int pass = 0; pass < n_pass; ++pass) {
-                const int b = 2 * ((pass == 0 ? tl - 128 : tl + 640));
+                const int b = 2 * ((slot0 + pass) * 64 + (tl & 63));
                 if (b < NB) {
-                    const float4* rp = reinterpret_cast<const float4*>(row + b * BT);
                     float v[2 * BT];
+                    if constexpr ((2 * BT * 4) % 16 == 0) {  // 16-byte aligned pairs of blocks
+                        const float4* rp = reinterpret_cast<const float4*>(row + b * BT);
 #pragma unroll
-                    for (int r = 0; r < 2 * BT / 4; ++r) {
-                        const float4 q = rp[r];
-                        v[4 * r] = q.x;
-                        v[4 * r + 1] = q.y;
-                        v[4 * r + 2] = q.z;
-                        v[4 * r + 3] = q.w;
+                        for (int r = 0; r < 2 * BT / 4; ++r) {
+                            const float4 qv = rp[r];
+                            v[4 * r] = qv.x;
+                            v[4 * r + 1] = qv.y;
+                            v[4 * r + 2] = qv.z;
+                            v[4 * r + 3] = qv.w;
+                        }
+                    } else {  // 8-byte aligned (BT = 5: 40 bytes per pair)
+                        const float2* rp = reinterpret_cast<const float2*>(row + b * BT);
+#pragma unroll
+                        for (int r = 0; r < BT; ++r) {
+                            const float2 qv = rp[r];
+                            v[2 * r] = qv.x;
+                            v[2 * r + 1] = qv.y;
+                        }
                     }
                     // canonical order of block_accumulate without its two no-ops (0 + v0, fma(0, v0, 0) and
                     // fma(1, v1, 0)): same values, only the sign of an all-zero sum can differ
@@ -429,9 +469,9 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                         block_accumulate((double)v[r], r, s0a, s1a);
                         block_accumulate((double)v[BT + r], r, s0b, s1b);
                     }
-                    double2* sp = reinterpret_cast<double2*>(S01) + (b >> 1);  // even blocks | 1024 | odd blocks
-                    sp[0] = make_double2(s0a, s1a);
-                    if (b + 1 < NB) sp[1024] = make_double2(s0b, s1b);
+                    double2* sp = reinterpret_cast<double2*>(S01);  // INTER arrays of `half` slots
+                    sp[b / INTER + half * (b % INTER)] = make_double2(s0a, s1a);
+                    if (b + 1 < NB) sp[(b + 1) / INTER + half * ((b + 1) % INTER)] = make_double2(s0b, s1b);
                 }
             }
         }
@@ -502,8 +542,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                     mo = wave_moments(sum, sq);
                 }
                 if (st16) {
-                    if (v0) stage[wj0] = yf0;
-                    if (v1) stage[wj0 + 1] = yf1;
+                    int js = wj0;
+                    asm volatile("" : "+v"(js));  // address formed here, not held in a register across the loop
+                    if (v0) stage[js] = yf0;
+                    if (v1) stage[js + 1] = yf1;
                 }
             }
         }
@@ -516,7 +558,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             if (!s2.y) {
                 if (nin <= 64) {
                     const unsigned span = (unsigned)(s.y - s.x);
-                    const bool hA = (unsigned)(wbB0 - s.x) <= span, hB = (unsigned)(wbB1 - s.x) <= span;
+                    const bool hA = (wbB & 0xffffu) - (unsigned)s.x <= span, hB = (wbB >> 16) - (unsigned)s.x <= span;
                     if (__builtin_amdgcn_ballot_w64(hA | hB)) {
                         if (hA) {
                             const int idx = atomicAdd(&sc->ncand[p1], 1);
@@ -534,8 +576,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 }
             }
             // clear the histograms of cell it-1 (scanned before barrier 1; next used by W of cell it+1)
-            reinterpret_cast<uint4*>(hist + p1 * XFINE)[tl] = make_uint4(0u, 0u, 0u, 0u);
-            coarse[p1 * (XREP * XCOARSE) + tl] = 0u;
+            unsigned zero = 0u;
+            asm volatile("" : "+v"(zero));  // materialised here (one v_mov), not four registers held across the loop
+            if (tl < XFINE / 4) reinterpret_cast<uint4*>(hist + p1 * XFINE)[tl] = make_uint4(zero, zero, zero, zero);
+            if (tl < XREP * XCOARSE) coarse[p1 * (XREP * XCOARSE) + tl] = zero;
         }
         ICV_XPH(4)
 #if ICV_X_LFIRST
@@ -545,57 +589,81 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         if (have0 && wave_w) {
             // ---- W: windows 2t, 2t+1 of cell it from {S0,S1}, histogram atomics --------------------
             double v0, v1;
-            if (wfull) {
-                // every window of the wavefront is a full pyramid window: no per-window branches; window j0 uses
+            auto fast_windows = [&]() __attribute__((always_inline))
+            {
+                // full pyramid windows, no per-window branches (the few flat windows -- one per chromosome with at
+                // most `window` genes -- are overwritten below): window j0 uses
                 // the pairs of blocks b0 .. b0+9, window j0+1 those of b0+1 .. b0+10 (canonical order inside a
                 // window, the two float64 chains interleaved)
                 constexpr int HB = NBW / 2;
-                const double2* qA = reinterpret_cast<const double2*>(smem + spA);  // blocks b0, b0+2, ...
-                const double2* qB = reinterpret_cast<const double2*>(smem + spB);  // blocks b0+1, b0+3, ...
+#ifdef ICV_X_WCH_LONG
+                constexpr int WCH = NBW > 10 ? ICV_X_WCH_LONG : ICV_X_WCH;
+#else
+                constexpr int WCH = NBW > 10 ? 5 : ICV_X_WCH;  // long windows: fewer, larger batches of LDS reads
+#endif
+                auto blk = [&](int i) __attribute__((always_inline)) {  // {S0,S1} of block b0 + i
+                    return reinterpret_cast<const double2*>(smem + spK[i % INTER])[i / INTER];
+                };
                 v0 = 0.0;
                 v1 = 0.0;
-                double2 cur = qA[0];
+                double2 ring[SB + 1];  // blocks b0 + m .. b0 + m + SB
+#pragma unroll
+                for (int k = 0; k <= SB; ++k) ring[k] = blk(k);
 #pragma unroll
                 for (int m = 0; m < NBW; ++m) {
-                    const double2 nxt = ((m + 1) & 1) ? qB[(m + 1) >> 1] : qA[(m + 1) >> 1];  // block b0 + m + 1
+                    const double2 a = ring[m % (SB + 1)], b = ring[(m + SB) % (SB + 1)];
+                    if (m + 1 < NBW) ring[m % (SB + 1)] = blk(m + SB + 1);  // consumed slot <- the block after the ring
                     const double wgt = (double)(m < HB ? m * BT + 1 : NBW * BT - m * BT);
-                    v0 = fma(wgt, cur.x, v0);   // window j0, its block m     = block b0 + m
-                    v1 = fma(wgt, nxt.x, v1);   // window j0 + 1, its block m = block b0 + m + 1
-                    v0 = m < HB ? v0 + cur.y : v0 - cur.y;
-                    v1 = m < HB ? v1 + nxt.y : v1 - nxt.y;
-                    cur = nxt;
-                    if (m % ICV_X_WCH == ICV_X_WCH - 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
+                    v0 = fma(wgt, a.x, v0);  // window j0, its block m     = block b0 + m
+                    v1 = fma(wgt, b.x, v1);  // window j0 + 1, its block m = block b0 + SB + m
+                    v0 = m < HB ? v0 + a.y : v0 - a.y;
+                    v1 = m < HB ? v1 + b.y : v1 - b.y;
+                    if (m % WCH == WCH - 1) __builtin_amdgcn_sched_barrier(0);  // bound the reads in flight
                 }
                 v0 = finish_window(v0, NBW * BT, pyr_den, pyr_rcp, 1.0);
                 v1 = finish_window(v1, NBW * BT, pyr_den, pyr_rcp, 1.0);
-            } else {
-                double vv[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    int bs = wb0 + i, jr = wj0 + i;
-                    asm volatile("" : "+v"(bs), "+v"(jr));  // addresses formed here, not hoisted (register budget)
-                    const int j = jr < W ? jr : 0;
-                    const bool ok = i ? valid1 : valid0;
-                    const int ln = ok ? P.w_len[j] : NBW * BT;
+            };
+            // (two call sites on purpose: with the fast path behind the wavefront-uniform test the register
+            // allocator keeps the row prefetch in registers; as one unconditional block it spilled it)
+            if (wfull) fast_windows();
+            else fast_windows();
+            if (!wfull) {
+                // flat windows in this wavefront (one per chromosome with at most `window` genes; always the first
+                // window of its thread's pair): plain mean of the chromosome's genes = sum of the S0 of its blocks in
+                // block order (canonical), over the gene count.  Handled one at a time with wavefront-uniform
+                // values: block count and gene count come through the SCALAR cache (a vector load here would drain
+                // the row prefetch), the LDS reads are broadcasts, the owning lane keeps the result.
+                unsigned long long fm = __builtin_amdgcn_ballot_w64(valid0 && !((wdx >> 26) & 1u));
+                const int wbase = __builtin_amdgcn_readfirstlane(tl & ~63);
+#pragma unroll 1
+                while (fm) {
+                    const int L = (int)__builtin_ctzll(fm);
+                    fm &= fm - 1;
+                    const unsigned fi = P.x16_wdesc[XT + wbase + L];  // uniform address: s_load
+                    const int nb = (int)(fi & 0xffffu);
+                    const int bs = __builtin_amdgcn_readlane(wb0, L);
                     const double2* sb = reinterpret_cast<const double2*>(S01);
-                    double v = window_from_blocks(ln, BT, [&](int m, double& a, double& b2) {
-                        const int bb = bs + m;
-                        const double2 q = sb[(bb >> 1) + 1024 * (bb & 1)];
-                        a = q.x;
-                        b2 = q.y;
-                    });
-                    // flat windows (one per chromosome with <= window genes) read their gene count
-                    vv[i] = finish_window(v, ln, pyr_den, pyr_rcp, ln > 0 ? 1.0 : P.w_denom[j]);
+                    // one LDS read per block, all in flight at once (lane m: block m), then the canonical
+                    // left-to-right sum through lane reads
+                    double acc = 0.0;
+#pragma unroll 1
+                    for (int base = 0; base < nb; base += 64) {
+                        const int mm = base + (tl & 63);
+                        const int bb = bs + (mm < nb ? mm : 0);
+                        const double s0l = sb[bb / INTER + half * (bb % INTER)].x;
+                        const int cnt = nb - base < 64 ? nb - base : 64;
+#pragma unroll 1
+                        for (int q = 0; q < cnt; ++q) acc = acc + readlane_d(s0l, q);
+                    }
+                    const double vf = acc / (double)(int)(fi >> 16);
+                    if ((tl & 63) == L) v0 = vf;
                 }
-                v0 = vv[0];
-                v1 = vv[1];
             }
             wvA0 = v0;
             wvA1 = v1;
-            const int h0 = hist_bin_x(v0, inv_bound, c_scale, c_thr), h1 = hist_bin_x(v1, inv_bound, c_scale, c_thr);
+            const int h0 = hist_bin_x<FINE>(v0, inv_bound, c_scale, c_thr), h1 = hist_bin_x<FINE>(v1, inv_bound, c_scale, c_thr);
             const bool w0 = valid0, w1 = valid1;
-            wbA0 = w0 ? h0 : -1;
-            wbA1 = w1 ? h1 : -1;
+            wbA = (unsigned)(w0 ? h0 : 0xffff) | ((unsigned)(w1 ? h1 : 0xffff) << 16);
             unsigned* fz = hist + p0 * XFINE;
             unsigned* cz = coarse + p0 * (XREP * XCOARSE) + (tl & (XREP - 1));
 #ifndef ICV_X_EXP_NOATOM  // timing experiment (wrong medians): 1 = no coarse atomics, 2 = no atomics at all
@@ -638,8 +706,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 
     const int64_t n_it = n_mine + 3;  // two iterations of median pipeline + one for the staged x_res store
     for (int64_t it = 0; it < n_it; it += 2) {
-        iteration(it, 0, wvE0, wvE1, wbE0, wbE1, wvO0, wvO1, wbO0, wbO1);
-        if (it + 1 < n_it) iteration(it + 1, 1, wvO0, wvO1, wbO0, wbO1, wvE0, wvE1, wbE0, wbE1);
+        iteration(it, 0, wvE0, wvE1, wbE, wvO0, wvO1, wbO);
+        if (it + 1 < n_it) iteration(it + 1, 1, wvO0, wvO1, wbO, wvE0, wvE1, wbE);
     }
     if constexpr (CHUNK) {
         if (wave_w && chunk_cur >= 0) {

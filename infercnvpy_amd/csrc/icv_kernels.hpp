@@ -85,8 +85,10 @@ struct KParams {
     int64_t chunksize, row_phase;
     double* chunk_part;
     // k_smooth_x16: per thread, first block (bits 0-11) and first window (12-23) of its two adjacent windows,
-    // window valid (24, 25), full pyramid window (26, 27)
+    // window valid (24, 25), full pyramid window (26, 27); then per thread: 0, or for a flat first window its
+    // block count | gene count << 16
     const uint32_t* x16_wdesc;
+    int32_t x16_half, _pad4;  // k_smooth_x16: slots of the even-block {S0,S1} array
 };
 
 struct Scratch {

@@ -23,7 +23,6 @@ constexpr int kWsUMax = 12;            // same for the 448 worker threads of k_s
 constexpr int kWsMaxB = 5, kWsMaxW = 5, kWsMaxK = 30;
 constexpr int kX16Threads = 1024;      // k_smooth_x16: 16 wavefronts, one workgroup per CU
 constexpr int kX16UMax = 5;            // 16-byte row vectors per lane in flight
-constexpr int kX16HistBytes = 2 * (4096 * 4 + 16 * 64 * 4);  // fine + 16 coarse replicas, both cell parities
 
 struct Layout {
     int elem_bytes = 4;
@@ -68,6 +67,8 @@ struct Plan {
     // k_smooth_x16 (one 1024-thread workgroup per CU, tables in registers): row | {S0,S1} | histogram | scratch
     bool x16_ok = false;
     int x16_s01_off = 0, x16_hist_off = 0, x16_scratch_off = 0, x16_lds = 0;
+    int x16_half = 0;  // slots of the even-block {S0,S1} array (odd blocks follow)
+    int x16_fine = 0;  // fine histogram bins: 4096, or 1024 where LDS is short (window 250: twice the blocks)
     std::vector<uint32_t> x16_wdesc;  // per thread: the pair of adjacent windows it owns (icv_kernels.hpp KParams)
     Layout lay32, lay64;
 };
@@ -254,13 +255,25 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         p.sp_lds = p.sp_scratch_off + kFastScratchBytes;
         p.sp_ok = p.ws_ok && p.sp_lds <= kLdsLimit && p.NB <= kThreads * 4 && p.W <= kThreads * 4;
         p.x16_s01_off = round_up((p.Gp + 1) * 4, 16);
-        p.x16_hist_off = p.x16_s01_off + 16 * 2048;  // even blocks | odd blocks, 1024 slots each
-        p.x16_scratch_off = p.x16_hist_off + kX16HistBytes;
-        p.x16_lds = p.x16_scratch_off + kFastScratchBytes + round_up(4 * p.W, 16);  // + x_res staging row
-        p.x16_ok = p.fast_ok && n_cols_all <= kX16UMax * kX16Threads * 4 && p.x16_lds <= kLdsLimit &&
-                   p.NB <= kX16Threads * 2 - 16 && p.W <= 4095;
+        // {S0,S1} of block b: array b % inter, slot b / inter (inter = 2 * step / B: adjacent windows of a thread
+        // are step / B blocks apart, threads 2 * step / B); the reads of a window pair may pass the last block
+        const int sbk = (B > 0 && step % B == 0) ? step / B : 1, inter = 2 * sbk;
+        p.x16_half = round_up((p.NB + window / B + 2 * sbk + inter) / inter + 1, 8);
+        p.x16_hist_off = p.x16_s01_off + inter * 16 * p.x16_half;
+        p.x16_ok = false;
+        for (int fine : {4096, 1024}) {
+            const int hist_bytes = 2 * (fine * 4 + 16 * (fine / 64) * 4);  // fine + 16 coarse replicas, both parities
+            p.x16_fine = fine;
+            p.x16_scratch_off = p.x16_hist_off + hist_bytes;
+            p.x16_lds = p.x16_scratch_off + kFastScratchBytes + round_up(4 * p.W, 16);  // + x_res staging row
+            if (p.x16_lds <= kLdsLimit) {
+                p.x16_ok = true;
+                break;
+            }
+        }
+        p.x16_ok = p.x16_ok && p.fast_ok && n_cols_all <= kX16UMax * kX16Threads * 4 && p.NB <= 4080 && p.W <= 4095;
         // windows dealt to threads in pairs of adjacent windows of one chromosome
-        p.x16_wdesc.assign(kX16Threads, 0u);
+        p.x16_wdesc.assign(2 * kX16Threads, 0u);  // [threads] pair descriptors, then [threads] flat-window info
         {
             int idx = 0;
             for (int c = 0; c < n_chr && p.x16_ok; ++c) {
@@ -274,6 +287,11 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
                     const bool v1 = q + 1 < wc;
                     const uint32_t full0 = p.w_len[j0] == window ? 1u : 0u;
                     const uint32_t full1 = (v1 && p.w_len[j0 + 1] == window) ? 1u : 0u;
+                    if (!full0) {  // flat window (the only one of its chromosome): blocks | gene count << 16
+                        const int nbk = -p.w_len[j0] / B, gcn = (int)p.w_denom[j0];
+                        if (v1 || nbk > 0xffff || gcn > 0x7fff) p.x16_ok = false;
+                        p.x16_wdesc[kX16Threads + idx] = (uint32_t)nbk | ((uint32_t)gcn << 16);
+                    }
                     p.x16_wdesc[idx++] = (uint32_t)(p.w_start[j0] / B) | ((uint32_t)j0 << 12) | (1u << 24) |
                                          ((v1 ? 1u : 0u) << 25) | (full0 << 26) | (full1 << 27);
                 }
