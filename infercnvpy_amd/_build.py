@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
         "-ffp-contract=off",  # float64 evaluation order is part of the parity contract
+        "-mllvm", "-amdgpu-mfma-vgpr-form=1",  # k_gram_mfma keeps both accumulator levels in VGPRs
         "-Wall", "-Wno-unused-function",
         "-o", LIB + ".tmp",
     ] + os.environ.get("ICV_EXTRA_HIPCC_FLAGS", "").split() + SOURCES

@@ -1069,6 +1069,52 @@ int icv_csr_fill(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, con
     return ICV_OK;
 }
 
+}  // extern "C"
+
+// ---- Gram / distance tile jobs (icv_corr.hpp) -------------------------------------------------------
+namespace {
+struct GramWork {  // device side of one k_gram_mfma launch: the super-tile descriptors
+    char* buf = nullptr;
+    ~GramWork() { (void)hipFree(buf); }
+};
+
+template <bool DIST, bool SYM>
+int launch_gram(hipStream_t st, GramWork& w, const float* z, int kz, const double* norm,
+                const std::vector<icv::GramSuper>& supers, int64_t row_end, int64_t col_end, float* c_dir,
+                int64_t ld_dir, float* c_mir, int64_t ld_mir) {
+    if (supers.empty()) return ICV_OK;
+    HIP_TRY(hipMalloc((void**)&w.buf, supers.size() * sizeof(icv::GramSuper)));
+    HIP_TRY(hipMemcpyAsync(w.buf, supers.data(), supers.size() * sizeof(icv::GramSuper), hipMemcpyHostToDevice, st));
+    icv::GramJob J;
+    J.supers = reinterpret_cast<const icv::GramSuper*>(w.buf);
+    J.n_supers = (int)supers.size();
+    J.row_end = row_end;
+    J.col_end = col_end;
+    J.c_dir = c_dir;
+    J.ld_dir = ld_dir;
+    J.c_mir = c_mir;
+    J.ld_mir = ld_mir;
+    const unsigned grid = 512u * (unsigned)((supers.size() + 7) / 8);
+    hipLaunchKernelGGL((icv::k_gram_mfma<DIST, SYM>), dim3(grid), dim3(256), 0, st, z, kz, norm, J);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+// super-tiles of the full symmetric n x n result (upper triangle, row-major)
+std::vector<icv::GramSuper> gram_supers_sym(int64_t n, int64_t ld) {
+    const int64_t ss = (int64_t)icv::GT * icv::GSUPER;
+    const int64_t ns = (n + ss - 1) / ss;
+    std::vector<icv::GramSuper> v;
+    v.reserve((size_t)(ns * (ns + 1) / 2));
+    for (int64_t sy = 0; sy < ns; ++sy)
+        for (int64_t sx = sy; sx < ns; ++sx)
+            v.push_back({(int)(sy * ss), (int)(sx * ss), sy * ss * ld + sx * ss, sx * ss * ld + sy * ss});
+    return v;
+}
+}  // namespace
+
+extern "C" {
+
 int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr, void* stream) {
     if (!x || !h_iqr || n < 2 || k < 1 || ld < k) return fail(ICV_ERR_INVALID, "bad corr_iqr arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1088,10 +1134,8 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     HIP_TRY(hipMalloc((void**)&c, (size_t)n * n * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&d_cnt, 5 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
-    const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
-    hipLaunchKernelGGL((icv::k_gram_mfma<false, true>), dim3(gt, gt), dim3(256), 0, st, z, n, kz, c, n, (const double*)nullptr,
-                       (int64_t)0, n);
-    HIP_TRY(hipGetLastError());
+    GramWork gw;
+    if (int rc = launch_gram<false, true>(st, gw, z, kz, nullptr, gram_supers_sym(n, n), n, n, c, n, c, n)) return rc;
     // the 25 % and 75 % percentiles interpolate between order statistics floor(pos), floor(pos) + 1
     const double m1 = (double)n * (double)n - 1.0;
     const double pos[2] = {0.25 * m1, 0.75 * m1};
@@ -1168,15 +1212,17 @@ int icv_pairwise_sqeuclidean(const float* x, int64_t n, int32_t d, int64_t ld, i
     hipLaunchKernelGGL(icv::k_colmean_finish, dim3(gd), dim3(256), 0, st, partial, n, d, n_slabs, mean);
     hipLaunchKernelGGL(icv::k_center_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, d, ld, mean, z, kz,
                        norm);
-    const unsigned gt = (unsigned)((n + icv::GT - 1) / icv::GT);
-    const unsigned gr = (unsigned)((row_end - row_begin + icv::GT - 1) / icv::GT);
-    if (row_begin == 0 && row_end == n)
-        hipLaunchKernelGGL((icv::k_gram_mfma<true, true>), dim3(gt, gt), dim3(256), 0, st, z, n, kz, out, ldo, norm,
-                           (int64_t)0, n);
-    else
-        hipLaunchKernelGGL((icv::k_gram_mfma<true, false>), dim3(gt, gr), dim3(256), 0, st, z, n, kz, out, ldo, norm,
-                           row_begin, row_end);
-    HIP_TRY(hipGetLastError());
+    GramWork gw;
+    if (row_begin == 0 && row_end == n) {
+        if (int rc = launch_gram<true, true>(st, gw, z, kz, norm, gram_supers_sym(n, ldo), n, n, out, ldo, out, ldo))
+            return rc;
+    } else {  // a row block against all columns
+        const int64_t ss = (int64_t)icv::GT * icv::GSUPER;
+        std::vector<icv::GramSuper> v;
+        for (int64_t r0 = row_begin; r0 < row_end; r0 += ss)
+            for (int64_t c0 = 0; c0 < n; c0 += ss) v.push_back({(int)r0, (int)c0, (r0 - row_begin) * ldo + c0, 0});
+        if (int rc = launch_gram<true, false>(st, gw, z, kz, norm, v, row_end, n, out, ldo, out, ldo)) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(st));  // the temporaries are freed on return
     return ICV_OK;
 }

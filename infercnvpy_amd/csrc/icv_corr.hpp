@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 
 #include "icv_kernels.hpp"
 
@@ -40,96 +41,229 @@ __global__ void __launch_bounds__(256) k_row_normalize(const float* x, int64_t n
 
 // C = Z Z^T, Z row-major n x kz (kz multiple of 16, zero padded), C row-major float32.
 // Workgroup = 256 threads = 4 wavefronts, 128 x 128 output tile, each wavefront a 64 x 64 quadrant as
-// 2 x 2 MFMA tiles of 32 x 32; K advances 16 per LDS stage, the next stage's global loads are in flight
-// (registers) while the current one is multiplied.  mfma_f32_32x32x2f32 operand layout:
+// 2 x 2 MFMA tiles of 32 x 32; K advances 16 per LDS stage.  mfma_f32_32x32x2f32 operand layout:
 // A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; D: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// Operand panels in LDS: row stride 20 floats (16-byte aligned rows; a 16-lane group of a ds_read_b128 covers
+// the 64 banks exactly once).  A lane reads four consecutive K values of its row with one ds_read_b128 and
+// feeds them to four MFMAs: the lower half of the wavefront takes K = 8g .. 8g+3, the upper half 8g+4 .. 8g+7
+// (a permutation of the summation index, the same for both operands).  The panels are double buffered: the
+// global loads of stage s+2 are in flight (registers) and stage s+1 is written to the other buffer while stage s
+// is multiplied -- one barrier per stage.
+//
+// Instruction order is pinned (sched_barrier): the MFMA pipe issues in order and the two wavefronts that share a
+// SIMD run in lock step (same code, same barriers), so a wait that is exposed in one wavefront is exposed in
+// both.  Every LDS read is issued >= 8 MFMAs (512 cycles) before its first use, the LDS writes 8 MFMAs before
+// the barrier, the global loads a whole stage before they are written to LDS.  Measured (tools/bench_gram.hip):
+// the MFMA sequence alone sustains 155 TFLOP/s; with compiler-placed waits the same kernel reached 112.
+//
+// Accumulation is two-level: every 32 x 32 tile's MFMA chain runs over 128 columns of K (8 stages) and is then
+// added to a second float32 accumulator -- the rounding walk of a K = 5000 chain is ~6x shorter.  The four
+// tiles of a wavefront are flushed in different stages (tile T in stage 2T of every block of 8): its 16 adds sit
+// in the shadow of the other tiles' MFMAs and the chain restarts from a literal zero C operand.  Both accumulator
+// sets live in VGPRs (-mllvm -amdgpu-mfma-vgpr-form: no v_accvgpr traffic; the first version of this kernel moved
+// all 64 accumulators between the register classes in every stage).
 // DIST = false: C = clip(Z Z^T, -1, 1) (np.corrcoef); DIST = true: C[i][j] = max(0, |z_i|^2 + |z_j|^2 - 2 z_i.z_j),
 // 0 on the diagonal (squared Euclidean distances; norm[] float64 from k_center_rows).
-// SYM = true (square result, row0 = 0): only tiles on or above the diagonal are computed; an off-diagonal tile
-// is also written transposed (through a 32 x 33 LDS patch per wavefront, so both writes are coalesced) --
-// half the flops and a bit-exactly symmetric matrix.  SYM = false: rows [row0, row1) against all columns (the
-// row block of a sharded matrix; c points at row row0).
-// Accumulation is two-level: the MFMA chain runs over GSEG columns of K, then is added to a second float32
-// accumulator -- the rounding walk of a K = 5000 chain is ~6x shorter.
-constexpr int GT = 128, GK = 16, GLD = GK + 1;  // +1: conflict-free column reads
-constexpr int GSEG = 128;
-template <bool DIST, bool SYM>
-__global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, int kz, float* c, int64_t ldc,
-                                                   const double* norm, int64_t row0, int64_t row1) {
-    __shared__ float smem[2 * GT * GLD];
-    if (SYM && blockIdx.x < blockIdx.y) return;  // the mirror image of tile (x, y) is written by tile (y, x)
-    float* sa = smem;
-    float* sb = smem + GT * GLD;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t i0 = row0 + (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
-    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
-    f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[a][b][r] = 0.0f;
-                tot[a][b][r] = 0.0f;
-            }
+//
+// Work list: super-tiles of 8 x 8 tiles (1024 x 1024 outputs), GramSuper descriptors built by the host.  The grid
+// is one-dimensional; workgroup id -> XCD = id % 8 (round-robin dispatch), and XCD x takes the super-tiles
+// x, x + 8, ...: the 64 tiles in flight on an XCD share 8 + 8 operand panels through its L2.
+// SYM = true: tiles below the diagonal are skipped; an off-diagonal tile is also written transposed (through a
+// 32 x 33 LDS patch per wavefront, so both writes are coalesced) to the mirror target -- half the flops and a
+// bit-exactly symmetric matrix.  Direct and mirror targets are separate (pointer, stride, offset per super-tile):
+// one GPU writes both into the same n x n matrix, a rank of a sharded job writes its own rows directly and the
+// mirror blocks into the buffer that travels to the owners of those rows (dist.py).
+// The value of an entry depends only on the unordered pair {i, j} (same K order, flush stages symmetric in the
+// tile coordinates), so separately computed mirror images agree bit for bit as well.
+//
+// Measured on MI355X (tools/bench_gram.hip, n = 32768, K = 5008): 142.8 TFLOP/s executed = 0.91 of the fp32 MFMA
+// peak (round 1: 0.69; compiler-placed waits 0.71; pinned order on the old two-dimensional grid with its empty
+// below-diagonal workgroups 0.80).  A start-up skew of the two workgroups sharing a CU (so that their epilogues
+// do not coincide) was measured on top of this and changed nothing.
+struct GramSuper {
+    int row0, col0;   // first row / column of the super-tile
+    int64_t dir_off;  // element offset of (row0, col0) in the direct target
+    int64_t mir_off;  // element offset of the transposed block's origin in the mirror target
+};
+struct GramJob {
+    const GramSuper* supers;
+    int n_supers;
+    int64_t row_end, col_end;  // valid rows / columns
+    float* c_dir;
+    int64_t ld_dir;
+    float* c_mir;
+    int64_t ld_mir;
+};
+constexpr int GT = 128, GK = 16, GLD = 20, GSUPER = 8;
+constexpr int GPANEL = GT * GLD;  // floats per operand panel
+template <int V>
+using gint = std::integral_constant<int, V>;
 
-    // this thread stages rows r = idx / 4 (idx = t, t + 256), columns k0 + 4 (idx % 4) .. + 3 of both panels
-    float4 va[2], vb[2];
+#define ICV_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <bool DIST, bool SYM, int EXP = 0>  // EXP != 0: tools/bench_gram.hip experiments (wrong results)
+__global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int kz, const double* norm, const GramJob J) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * GPANEL];  // {A, B} x 2 buffers: 40 KB
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int seq = blockIdx.x >> 3;
+    const int sidx = (seq >> 6) * 8 + (blockIdx.x & 7);
+    if (sidx >= J.n_supers) return;
+    const GramSuper S = J.supers[sidx];
+    const int qy = (seq >> 3) & 7, qx = seq & 7;
+    const int64_t i0 = (int64_t)S.row0 + qy * GT, j0 = (int64_t)S.col0 + qx * GT;
+    if (i0 >= J.row_end || j0 >= J.col_end || (SYM && j0 < i0)) return;
+    const int64_t row1 = J.row_end, n = J.col_end;
+    const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+    f32x16 acc[4], tot[4];  // tile T = 2 a + b: rows wi + 32 a, columns wj + 32 b
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.0f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        acc[T] = zero;
+        tot[T] = zero;
+    }
+
+    // this thread stages rows r = t / 4 and r + 64, columns k0 + 4 (t % 4) .. + 3 of both panels.  Buffer loads
+    // against one descriptor per panel (its valid rows only: rows past the end read zeros without traffic); the
+    // per-thread offsets are two registers, the stage offset is scalar.
+    const int64_t rows_a = row1 - i0 < GT ? row1 - i0 : GT, rows_b = n - j0 < GT ? n - j0 : GT;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(z + i0 * (int64_t)kz, (unsigned)(rows_a * kz * 4));
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(z + j0 * (int64_t)kz, (unsigned)(rows_b * kz * 4));
+    // (the scalar offset of a buffer load is not range checked: the row half goes into the vector offset)
+    unsigned g_off[2];
+    g_off[0] = (unsigned)(((t >> 2) * kz + (t & 3) * 4) * 4);
+    g_off[1] = g_off[0] + (unsigned)(64 * kz * 4);
+    u32x4 va[2], vb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int idx = t + h * 256;
-            const int r = idx >> 2, qd = idx & 3;
-            va[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vb[h] = va[h];
-            if (i0 + r < row1) va[h] = *reinterpret_cast<const float4*>(z + (i0 + r) * (int64_t)kz + k0 + qd * 4);
-            if (j0 + r < n) vb[h] = *reinterpret_cast<const float4*>(z + (j0 + r) * (int64_t)kz + k0 + qd * 4);
+            va[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, g_off[h], (unsigned)k0 * 4u, 0);
+            vb[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, g_off[h], (unsigned)k0 * 4u, 0);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < kz; k0 += GK) {
+    const int st_off = (t >> 2) * GLD + (t & 3) * 4;
+    auto store = [&](int buf) {
+        float* sa = smem + buf * 2 * GPANEL + st_off;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int idx = t + h * 256;
-            const int r = idx >> 2, qd = idx & 3;
-            float* pa = sa + r * GLD + qd * 4;
-            float* pb = sb + r * GLD + qd * 4;
-            pa[0] = va[h].x; pa[1] = va[h].y; pa[2] = va[h].z; pa[3] = va[h].w;
-            pb[0] = vb[h].x; pb[1] = vb[h].y; pb[2] = vb[h].z; pb[3] = vb[h].w;
+            *reinterpret_cast<u32x4*>(sa + h * 64 * GLD) = va[h];
+            *reinterpret_cast<u32x4*>(sa + GPANEL + h * 64 * GLD) = vb[h];
         }
-        __syncthreads();
-        if (k0 + GK < kz) fetch(k0 + GK);
+    };
+    const int a_off = (wi + (lane & 31)) * GLD + 4 * (lane >> 5);
+    const int b_off = GPANEL + (wj + (lane & 31)) * GLD + 4 * (lane >> 5);
+    float4 av[2][2], bv[2][2];  // [slot][tile row / tile column]
+    auto operands = [&](int buf, int g, int slot) {
+        const float* s = smem + buf * 2 * GPANEL + 8 * g;
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-            const int kc = kk + (lane >> 5);
-            float av[2], bv[2];
+        for (int a = 0; a < 2; ++a) av[slot][a] = *reinterpret_cast<const float4*>(s + a_off + a * 32 * GLD);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[a] = sa[(wi + a * 32 + (lane & 31)) * GLD + kc];
+        for (int b = 0; b < 2; ++b) bv[slot][b] = *reinterpret_cast<const float4*>(s + b_off + b * 32 * GLD);
+    };
+    auto comp = [](const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+    // one MFMA: tile T, K element e of operand slot `slot`; fresh: the chain restarts (C = 0)
+    auto mf = [&](int slot, int T, int e, bool fresh) {
+        const float x = comp(av[slot][T >> 1], e), y = comp(bv[slot][T & 1], e);
+        if (fresh)
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        else
+            acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[T], 0, 0, 0);
+    };
+
+    // One stage (16 columns of K) from buffer cur.  Operand slot 0 holds group 0 of this stage on entry and
+    // group 0 of the next stage on exit.  FM: tiles flushed to the second-level sums in this stage (bit mask);
+    // ZM: tiles whose chains restart from zero in this stage (flushed in the previous one).
+    auto stage = [&](int k0, int cur, bool more, bool more2, auto FM_, auto ZM_) {
+        constexpr int FM = decltype(FM_)::value, ZM = decltype(ZM_)::value;
+        constexpr int NF = ((FM >> 0) & 1) + ((FM >> 1) & 1) + ((FM >> 2) & 1) + ((FM >> 3) & 1);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bv[b] = sb[(wj + b * 32 + (lane & 31)) * GLD + kc];
+        for (int T = 0; T < 4; ++T) mf(0, T, 0, (ZM >> T) & 1);
+        ICV_SB();
+        if (EXP < 2) operands(cur, 1, 1);
+        ICV_SB();
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int T = 0; T < 4; ++T) mf(0, T, 1, false);
+        ICV_SB();
+        if (more) {
+            if (EXP < 2) store(cur ^ 1);  // the buffer stage s-1 was read from (all its reads precede the last barrier)
+            if (EXP == 0 && more2) fetch(k0 + 2 * GK);
         }
-        __syncthreads();
-        if (((k0 + GK) & (GSEG - 1)) == 0 || k0 + GK >= kz) {
+        ICV_SB();
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int e = 2; e < 4; ++e)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+            for (int T = 0; T < 4; ++T) mf(0, T, e, false);
+        ICV_SB();
+        if (EXP < 3) __syncthreads();
+        ICV_SB();
+        // group 1: the flushed tiles' MFMAs first; their adds follow >= 4 MFMAs later in the shadow of the others'
+        auto rest = [&](int e) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        tot[a][b][r] += acc[a][b][r];
-                        acc[a][b][r] = 0.0f;
-                    }
+            for (int T = 0; T < 4; ++T)
+                if (!((FM >> T) & 1)) mf(1, T, e, false);
+        };
+        auto flush = [&](int half) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+                if ((FM >> T) & 1) {
+#pragma unroll
+                    for (int r = 8 * half; r < 8 * half + 8; ++r) tot[T][r] += acc[T][r];
+                }
+        };
+        if constexpr (NF > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+                    if ((FM >> T) & 1) mf(1, T, e, false);
         }
+        rest(0);
+        ICV_SB();
+        if (more && EXP < 2) operands(cur ^ 1, 0, 0);
+        ICV_SB();
+        rest(1);
+        ICV_SB();
+        if constexpr (NF > 0) flush(0);
+        ICV_SB();
+        rest(2);
+        ICV_SB();
+        if constexpr (NF > 0) flush(1);
+        ICV_SB();
+        rest(3);
+        ICV_SB();
+    };
+
+    const int ns = kz / GK;
+    fetch(0);
+    store(0);
+    if (ns > 1) fetch(GK);
+    __syncthreads();
+    operands(0, 0, 0);
+    int s = 0;
+    for (; s + 10 <= ns; s += 8) {  // 8 stages, every tile flushed once; stages s+8, s+9 exist: no bounds tests
+        const int k0 = s * GK;
+        // tile T = 2 a + b; tiles 1 and 2 (mirror images of each other) are flushed in the same stage
+        stage(k0, 0, true, true, gint<1>{}, gint<0>{});
+        stage(k0 + GK, 1, true, true, gint<0>{}, gint<1>{});
+        stage(k0 + 2 * GK, 0, true, true, gint<0>{}, gint<0>{});
+        stage(k0 + 3 * GK, 1, true, true, gint<6>{}, gint<0>{});
+        stage(k0 + 4 * GK, 0, true, true, gint<0>{}, gint<6>{});
+        stage(k0 + 5 * GK, 1, true, true, gint<0>{}, gint<0>{});
+        stage(k0 + 6 * GK, 0, true, true, gint<8>{}, gint<0>{});
+        stage(k0 + 7 * GK, 1, true, true, gint<0>{}, gint<8>{});
     }
-    const bool mirror = SYM && blockIdx.x != blockIdx.y;
-    float* patch = smem + wave * (32 * 33);  // 4 x 4224 B <= the operand panels (dead after the last barrier)
+    for (; s < ns; ++s) stage(s * GK, s & 1, s + 1 < ns, s + 2 < ns, gint<0>{}, gint<0>{});
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[T][r] += acc[T][r];
+    const bool mirror = SYM && i0 != j0;
+    __syncthreads();  // the last stage has no trailing barrier of its own
+    float* patch = smem + wave * (32 * 33);  // 4 x 4224 B <= the operand panels (dead now)
+    float* cd = J.c_dir + S.dir_off;
+    float* cm = J.c_mir + S.mir_off;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -139,7 +273,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                 const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int64_t row = i0 + wi + a * 32 + rl;
                 const int64_t col = j0 + wj + b * 32 + (lane & 31);
-                float v = tot[a][b][r];
+                float v = tot[2 * a + b][r];
                 if (row < row1 && col < n) {
                     if (DIST) {
                         const double d2 = norm[row] + norm[col] - 2.0 * (double)v;
@@ -147,7 +281,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                     } else {
                         v = v > 1.0f ? 1.0f : (v < -1.0f ? -1.0f : v);  // np.corrcoef clips to [-1, 1]
                     }
-                    c[(row - row0) * ldc + col] = v;
+                    cd[(row - S.row0) * J.ld_dir + (col - S.col0)] = v;
                 }
                 if (mirror) patch[rl * 33 + (lane & 31)] = v;
             }
@@ -159,7 +293,7 @@ __global__ void __launch_bounds__(256) k_gram_mfma(const float* z, int64_t n, in
                     const int64_t orow = j0 + wj + b * 32 + cl;           // a column of the tile above the diagonal
                     const int64_t ocol = i0 + wi + a * 32 + (lane & 31);  // its row index
                     const float v = patch[(lane & 31) * 33 + cl];
-                    if (orow < n && ocol < row1) c[orow * ldc + ocol] = v;
+                    if (orow < n && ocol < row1) cm[(orow - S.col0) * J.ld_mir + (ocol - S.row0)] = v;
                 }
             }
         }
