@@ -235,6 +235,53 @@ int icv_pairwise_sqeuclidean(const float *x, int64_t n, int32_t d, int64_t ld, i
                              float *out, int64_t ldo, void *stream);
 int icv_ward_linkage(float *dist_sq, int64_t n, int64_t ld, double *h_linkage, int32_t *h_rounds, void *stream);
 
+/* The same two steps for a distance matrix SHARDED by rows over several GPUs (one process per GPU; the exchanges
+ * between the calls are the caller's: infercnvpy_amd/dist.py does them with torch.distributed over RCCL).
+ * Rows are owned in super-rows of ICV_SUPER_ROWS rows.
+ *
+ * icv_pairwise_sqeuclidean_tiles: this rank's share of the upper-triangular super-tiles (ICV_SUPER_ROWS x
+ * ICV_SUPER_ROWS outputs each; x = ALL n points, resident).  Tile k covers rows row0[k].. and columns col0[k]..
+ * (multiples of ICV_SUPER_ROWS, col0 >= row0); it is written to dir + dir_off[k] (row stride ld_dir) and, for the
+ * part strictly above the diagonal, transposed to mir + mir_off[k] (row stride ld_mir): the rank writes its own
+ * rows directly and the mirror blocks into the buffer that travels to the owners of those rows.  All arrays of
+ * length n_tiles are HOST arrays.  Values are bit-identical to icv_pairwise_sqeuclidean's. */
+#define ICV_SUPER_ROWS 1024
+int icv_pairwise_sqeuclidean_tiles(const float *x, int64_t n, int32_t d, int64_t ld, int32_t n_tiles,
+                                   const int32_t *h_row0, const int32_t *h_col0, const int64_t *h_dir_off,
+                                   const int64_t *h_mir_off, float *dir, int64_t ld_dir, float *mir, int64_t ld_mir,
+                                   void *stream);
+
+/* Step-wise Ward rounds on a row-sharded matrix.  Every rank creates the same state (the bookkeeping is replicated
+ * and deterministic); h_sr_local[g] = local super-row index of global super-row g on THIS rank (0 .. k-1) or -1
+ * (NULL: all rows are local).  One round:
+ *   icv_ward_merge     rows merged in the previous round, by their owners: new row, its nearest neighbour;
+ *                      h_pslot[p] = row of `stage` holding the partner row of merge p (received from its owner) or
+ *                      -1 if the partner is stored locally; scatter != 0: also push the new column into the local
+ *                      rows (single-GPU form; sharded callers use icv_ward_scatter on the exchanged rows instead)
+ *   icv_ward_scatter   column update from n_v new rows v[q][local row] (row stride ldv) of slots h_vrow_i[q]
+ *   icv_ward_scan      nearest neighbour of the local rows whose cached neighbour merged or died
+ *   icv_ward_pack_nn / icv_ward_unpack_nn   the round's (neighbour, distance) results, n_pairs + n_act entries in
+ *                      list order, zero where another rank owns the row: all-reduce(SUM) them in between
+ *   icv_ward_pairs     reciprocal pairs of the round (replicated); h_counts = {n_live, n_merges, n_pairs, n_act}
+ *                      (synchronises the stream); all_active != 0: list every live row for the next scan
+ *   icv_ward_round_pairs  slots (i kept, j absorbed) of the pairs just found, HOST arrays of n_pairs
+ * until n_live == 1; icv_ward_finish writes the linkage matrix as icv_ward_linkage does.  One in-flight call per
+ * state. */
+typedef struct icv_ward_s *icv_ward_t;
+int icv_ward_create(int64_t n, const int32_t *h_sr_local, int32_t n_super, int32_t super_shift, icv_ward_t *out,
+                    void *stream);
+void icv_ward_destroy(icv_ward_t w);
+int icv_ward_merge(icv_ward_t w, float *d_local, int64_t ld, const float *stage, int64_t ld_stage,
+                   const int32_t *h_pslot, int32_t scatter, void *stream);
+int icv_ward_scatter(icv_ward_t w, float *d_local, int64_t ld, const float *v, int64_t ldv, const int32_t *h_vrow_i,
+                     int32_t n_v, void *stream);
+int icv_ward_scan(icv_ward_t w, const float *d_local, int64_t ld, void *stream);
+int icv_ward_pack_nn(icv_ward_t w, int32_t *d_nn, float *d_dmin, void *stream);
+int icv_ward_unpack_nn(icv_ward_t w, const int32_t *d_nn, const float *d_dmin, void *stream);
+int icv_ward_pairs(icv_ward_t w, int32_t all_active, int32_t *h_counts /* 4 */, void *stream);
+int icv_ward_round_pairs(icv_ward_t w, int32_t *h_i, int32_t *h_j);
+int icv_ward_finish(icv_ward_t w, double *h_linkage, int32_t *h_rounds);
+
 /* ---- cnv_score (tl/_scores.py:65-68): per-row sum of |x| in float64 ----------------------- */
 int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, double *row_sum,
                     void *stream);

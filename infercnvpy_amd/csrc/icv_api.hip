@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "icv_kernels.hpp"
@@ -1186,110 +1187,230 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     return ICV_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// centred float32 copy of the points (distances are translation invariant) + float64 squared norms
+struct CentredPoints {
+    float* z = nullptr;
+    double* work = nullptr;  // partial[n_slabs * d] | mean[d] | norm[n]
+    double* norm = nullptr;
+    int kz = 0;
+    ~CentredPoints() {
+        (void)hipFree(z);
+        (void)hipFree(work);
+    }
+};
+int centre_points(hipStream_t st, const float* x, int64_t n, int32_t d, int64_t ld, CentredPoints& c) {
+    c.kz = icv::round_up(d, icv::GK);
+    const int n_slabs = (int)std::min<int64_t>(256, (n + 63) / 64);
+    HIP_TRY(hipMalloc((void**)&c.z, (size_t)n * c.kz * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c.work, ((size_t)n_slabs * d + d + n) * sizeof(double)));
+    double *partial = c.work, *mean = c.work + (size_t)n_slabs * d;
+    c.norm = mean + d;
+    const unsigned gd = (unsigned)((d + 255) / 256);
+    hipLaunchKernelGGL(icv::k_colsum_slabs, dim3(gd, n_slabs), dim3(256), 0, st, x, n, d, ld, n_slabs, partial);
+    hipLaunchKernelGGL(icv::k_colmean_finish, dim3(gd), dim3(256), 0, st, partial, n, d, n_slabs, mean);
+    hipLaunchKernelGGL(icv::k_center_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, d, ld, mean, c.z, c.kz,
+                       c.norm);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int icv_pairwise_sqeuclidean(const float* x, int64_t n, int32_t d, int64_t ld, int64_t row_begin, int64_t row_end,
                              float* out, int64_t ldo, void* stream) {
     if (!x || !out || n < 1 || d < 1 || ld < d || ldo < n || row_begin < 0 || row_end > n || row_begin > row_end)
         return fail(ICV_ERR_INVALID, "bad pairwise arguments");
     if (row_begin == row_end) return ICV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int kz = icv::round_up(d, icv::GK);
-    const int n_slabs = (int)std::min<int64_t>(256, (n + 63) / 64);
-    float* z = nullptr;
-    double* work = nullptr;  // partial[n_slabs * d] | mean[d] | norm[n]
-    struct Guard {
-        float*& z;
-        double*& w;
-        ~Guard() {
-            (void)hipFree(z);
-            (void)hipFree(w);
-        }
-    } guard{z, work};
-    HIP_TRY(hipMalloc((void**)&z, (size_t)n * kz * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&work, ((size_t)n_slabs * d + d + n) * sizeof(double)));
-    double *partial = work, *mean = work + (size_t)n_slabs * d, *norm = mean + d;
-    const unsigned gd = (unsigned)((d + 255) / 256);
-    hipLaunchKernelGGL(icv::k_colsum_slabs, dim3(gd, n_slabs), dim3(256), 0, st, x, n, d, ld, n_slabs, partial);
-    hipLaunchKernelGGL(icv::k_colmean_finish, dim3(gd), dim3(256), 0, st, partial, n, d, n_slabs, mean);
-    hipLaunchKernelGGL(icv::k_center_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, d, ld, mean, z, kz,
-                       norm);
+    CentredPoints c;
+    if (int rc = centre_points(st, x, n, d, ld, c)) return rc;
     GramWork gw;
     if (row_begin == 0 && row_end == n) {
-        if (int rc = launch_gram<true, true>(st, gw, z, kz, norm, gram_supers_sym(n, ldo), n, n, out, ldo, out, ldo))
+        if (int rc = launch_gram<true, true>(st, gw, c.z, c.kz, c.norm, gram_supers_sym(n, ldo), n, n, out, ldo, out, ldo))
             return rc;
     } else {  // a row block against all columns
         const int64_t ss = (int64_t)icv::GT * icv::GSUPER;
         std::vector<icv::GramSuper> v;
         for (int64_t r0 = row_begin; r0 < row_end; r0 += ss)
             for (int64_t c0 = 0; c0 < n; c0 += ss) v.push_back({(int)r0, (int)c0, (r0 - row_begin) * ldo + c0, 0});
-        if (int rc = launch_gram<true, false>(st, gw, z, kz, norm, v, row_end, n, out, ldo, out, ldo)) return rc;
+        if (int rc = launch_gram<true, false>(st, gw, c.z, c.kz, c.norm, v, row_end, n, out, ldo, out, ldo)) return rc;
     }
     HIP_TRY(hipStreamSynchronize(st));  // the temporaries are freed on return
     return ICV_OK;
 }
 
-int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, int32_t* h_rounds, void* stream) {
-    if (!dist_sq || !h_linkage || n < 1 || ld < n || n > 0x7fffffff / 2)
-        return fail(ICV_ERR_INVALID, "bad ward_linkage arguments");
-    if (h_rounds) *h_rounds = 0;
-    if (n == 1) return ICV_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int ni = (int)n;
-    // device bookkeeping: 8 int/float arrays of n + log (4 x n) + alive bytes + counts
-    char* buf = nullptr;
-    struct Guard {
-        char*& b;
-        ~Guard() { (void)hipFree(b); }
-    } guard{buf};
-    const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
-    HIP_TRY(hipMalloc((void**)&buf, arr * 19 + 256));
-    int* live = (int*)(buf + arr * 0);
-    int* role = (int*)(buf + arr * 1);
-    float* pair_d = (float*)(buf + arr * 2);
-    int* size_old = (int*)(buf + arr * 3);
-    int* size_new = (int*)(buf + arr * 4);
-    int* nn = (int*)(buf + arr * 5);
-    float* dmin = (float*)(buf + arr * 6);
-    int* log_i = (int*)(buf + arr * 7);
-    int* log_j = (int*)(buf + arr * 8);
-    float* log_d = (float*)(buf + arr * 9);
-    int* log_size = (int*)(buf + arr * 10);
-    unsigned char* alive = (unsigned char*)(buf + arr * 11);
-    icv::WardCounts* counts = (icv::WardCounts*)(buf + arr * 12);
-    int* cstate = (int*)(buf + arr * 13);
-    unsigned char* qmask = (unsigned char*)(buf + arr * 14);
-    int4* mdesc = (int4*)(buf + arr * 15);  // n x 16 bytes: one packed descriptor per merge
-    hipLaunchKernelGGL(icv::k_ward_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ni, live, role, cstate,
-                       qmask, size_old, size_new, alive, counts);
-    const bool vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist_sq) & 15) == 0);
-    int n_live = ni, rounds = 0, merged_begin = 0, merged_count = 0;  // the previous round's slice of the merge log
-    while (n_live > 1) {
-        if (vec_ok && (int64_t)n_live * 4 >= n)  // most columns alive: contiguous vector loads over all columns
-            hipLaunchKernelGGL(icv::k_ward_round_dense, dim3((unsigned)n_live), dim3(256), 0, st, dist_sq, ld, ni, live,
-                               cstate, qmask, mdesc + merged_begin, log_d + merged_begin, merged_count, pair_d, size_old, size_new,
-                               nn, dmin);
-        else
-            hipLaunchKernelGGL(icv::k_ward_round, dim3((unsigned)n_live), dim3(256), 0, st, dist_sq, ld, live, n_live,
-                               role, pair_d, size_old, size_new, nn, dmin);
-        hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, ni, live, role, cstate, qmask, mdesc,
-                           pair_d, size_old, size_new, alive, nn, dmin, log_i, log_j, log_d, log_size, counts);
-        icv::WardCounts h;
-        HIP_TRY(hipMemcpyAsync(&h, counts, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        ++rounds;
-        if (h.n_pairs < 1) return fail(ICV_ERR_INVALID, "ward_linkage: distances are not finite");
-        n_live = h.n_live;
-        merged_begin = h.n_merges - h.n_pairs;
-        merged_count = h.n_pairs;
+int icv_pairwise_sqeuclidean_tiles(const float* x, int64_t n, int32_t d, int64_t ld, int32_t n_tiles,
+                                   const int32_t* h_row0, const int32_t* h_col0, const int64_t* h_dir_off,
+                                   const int64_t* h_mir_off, float* dir, int64_t ld_dir, float* mir, int64_t ld_mir,
+                                   void* stream) {
+    static_assert(ICV_SUPER_ROWS == icv::GT * icv::GSUPER, "super-tile size");
+    if (!x || n < 1 || d < 1 || ld < d || n_tiles < 0) return fail(ICV_ERR_INVALID, "bad pairwise tile arguments");
+    if (n_tiles == 0) return ICV_OK;
+    if (!h_row0 || !h_col0 || !h_dir_off || !h_mir_off || !dir || !mir)
+        return fail(ICV_ERR_INVALID, "bad pairwise tile arguments");
+    std::vector<icv::GramSuper> v((size_t)n_tiles);
+    for (int32_t k = 0; k < n_tiles; ++k) {
+        if (h_row0[k] < 0 || h_row0[k] % ICV_SUPER_ROWS || h_col0[k] % ICV_SUPER_ROWS || h_col0[k] < h_row0[k] ||
+            h_col0[k] >= n)
+            return fail(ICV_ERR_INVALID, "pairwise tiles: origins must be multiples of ICV_SUPER_ROWS on or above the diagonal");
+        v[(size_t)k] = {h_row0[k], h_col0[k], h_dir_off[k], h_mir_off[k]};
     }
-    if (h_rounds) *h_rounds = rounds;
-    // merge log -> scipy linkage matrix: monotone heights, stable sort, union-find relabelling
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CentredPoints c;
+    if (int rc = centre_points(st, x, n, d, ld, c)) return rc;
+    GramWork gw;
+    if (int rc = launch_gram<true, true>(st, gw, c.z, c.kz, c.norm, v, n, n, dir, ld_dir, mir, ld_mir)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return ICV_OK;
+}
+
+}  // extern "C"
+
+// ---- Ward rounds: device bookkeeping shared by the one-call and the step-wise entry points ---------------
+struct icv_ward_s {
+    int64_t n = 0;
+    char* buf = nullptr;
+    int *live, *cstate, *size_old, *size_new, *nn, *log_i, *log_j, *log_size, *act, *pslot, *vrow_i;
+    float *pair_d, *dmin, *log_d;
+    unsigned char *alive, *qmask;
+    int4* mdesc;
+    icv::WardCounts* counts;
+    int *sr_local = nullptr, *sr_global = nullptr;  // device copies (sharded matrices)
+    icv::WardMap map{nullptr, nullptr, 10, 0};
+    icv::WardCounts h{0, 0, 0, 0};  // after the last icv_ward_pairs
+    int rounds = 0;
+    ~icv_ward_s() { (void)hipFree(buf); }
+    bool dense(const void* D, int64_t ld) const {
+        return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(D) & 15) == 0) && (int64_t)h.n_live * 4 >= n;
+    }
+    int merged_begin() const { return h.n_merges - h.n_pairs; }
+};
+
+namespace {
+int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, hipStream_t st,
+                icv_ward_s** out) {
+    if (n < 2 || n > 0x7fffffff / 2 || !out) return fail(ICV_ERR_INVALID, "bad ward arguments");
+    if (sr_local && (n_super < 1 || super_shift < 2 || super_shift > 20 || ((int64_t)n_super << super_shift) < n))
+        return fail(ICV_ERR_INVALID, "bad ward storage map");
+    std::unique_ptr<icv_ward_s> w(new icv_ward_s);
+    w->n = n;
+    const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
+    const size_t map_bytes = sr_local ? ((size_t)n_super * 8 + 255) / 256 * 256 : 0;
+    HIP_TRY(hipMalloc((void**)&w->buf, arr * 21 + 256 + map_bytes));
+    char* b = w->buf;
+    auto take = [&](size_t k) {
+        char* p = b;
+        b += arr * k;
+        return p;
+    };
+    w->live = (int*)take(1);
+    w->cstate = (int*)take(1);
+    w->pair_d = (float*)take(1);
+    w->size_old = (int*)take(1);
+    w->size_new = (int*)take(1);
+    w->nn = (int*)take(1);
+    w->dmin = (float*)take(1);
+    w->log_i = (int*)take(1);
+    w->log_j = (int*)take(1);
+    w->log_d = (float*)take(1);
+    w->log_size = (int*)take(1);
+    w->alive = (unsigned char*)take(1);
+    w->qmask = (unsigned char*)take(1);
+    w->act = (int*)take(1);
+    w->pslot = (int*)take(1);
+    w->vrow_i = (int*)take(1);
+    w->mdesc = (int4*)take(4);  // n x 16 bytes: one packed descriptor per merge
+    w->counts = (icv::WardCounts*)take(1);
+    if (sr_local) {
+        // local super-row index per global super-row and its inverse
+        std::vector<int> inv;
+        for (int g = 0; g < n_super; ++g)
+            if (sr_local[g] >= 0) {
+                if ((size_t)sr_local[g] >= inv.size()) inv.resize((size_t)sr_local[g] + 1, -1);
+                inv[(size_t)sr_local[g]] = g;
+            }
+        for (int v : inv)
+            if (v < 0) return fail(ICV_ERR_INVALID, "ward storage map: local super-rows must be 0 .. k-1");
+        w->sr_local = (int*)b;
+        w->sr_global = w->sr_local + n_super;
+        HIP_TRY(hipMemcpyAsync(w->sr_local, sr_local, (size_t)n_super * 4, hipMemcpyHostToDevice, st));
+        if (!inv.empty())
+            HIP_TRY(hipMemcpyAsync(w->sr_global, inv.data(), inv.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        int64_t n_local = 0;
+        for (size_t l = 0; l < inv.size(); ++l) {
+            const int64_t r0 = (int64_t)inv[l] << super_shift;
+            n_local = std::max<int64_t>(n_local, ((int64_t)l << super_shift) + std::min<int64_t>(n - r0, (int64_t)1 << super_shift));
+        }
+        w->map = icv::WardMap{w->sr_local, w->sr_global, super_shift, (int)n_local};
+    } else {
+        w->map = icv::WardMap{nullptr, nullptr, 10, (int)n};
+    }
+    hipLaunchKernelGGL(icv::k_ward_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int)n, w->live,
+                       w->cstate, w->qmask, w->size_old, w->size_new, w->alive, w->act, w->counts);
+    HIP_TRY(hipGetLastError());
+    w->h = icv::WardCounts{(int)n, 0, 0, (int)n};
+    *out = w.release();
+    return ICV_OK;
+}
+
+int ward_merge(icv_ward_s* w, float* D, int64_t ld, const float* stage, int64_t ld_stage, const int32_t* h_pslot,
+               bool scatter, hipStream_t st) {
+    if (w->h.n_pairs < 1) return ICV_OK;
+    const int mb = w->merged_begin();
+    if (h_pslot) HIP_TRY(hipMemcpyAsync(w->pslot, h_pslot, (size_t)w->h.n_pairs * 4, hipMemcpyHostToDevice, st));
+    const icv::WardPairView V{w->mdesc + mb, w->log_d + mb, h_pslot ? w->pslot : nullptr, stage, ld_stage};
+    const bool stage_ok = !h_pslot || ((ld_stage % 4 == 0) && ((reinterpret_cast<uintptr_t>(stage) & 15) == 0));
+    if (w->dense(D, ld) && stage_ok)
+        hipLaunchKernelGGL(icv::k_ward_merge<true>, dim3((unsigned)w->h.n_pairs), dim3(256), 0, st, D, ld, (int)w->n,
+                           w->live, w->h.n_live, w->cstate, V, w->pair_d, w->size_old, w->size_new, w->map, scatter,
+                           w->nn, w->dmin);
+    else
+        hipLaunchKernelGGL(icv::k_ward_merge<false>, dim3((unsigned)w->h.n_pairs), dim3(256), 0, st, D, ld, (int)w->n,
+                           w->live, w->h.n_live, w->cstate, V, w->pair_d, w->size_old, w->size_new, w->map, scatter,
+                           w->nn, w->dmin);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int ward_scan(icv_ward_s* w, const float* D, int64_t ld, hipStream_t st) {
+    if (w->h.n_act < 1) return ICV_OK;
+    if (w->dense(D, ld))
+        hipLaunchKernelGGL(icv::k_ward_scan<true>, dim3((unsigned)w->h.n_act), dim3(256), 0, st, D, ld, (int)w->n, w->act,
+                           w->live, w->h.n_live, w->qmask, w->map, w->nn, w->dmin);
+    else
+        hipLaunchKernelGGL(icv::k_ward_scan<false>, dim3((unsigned)w->h.n_act), dim3(256), 0, st, D, ld, (int)w->n,
+                           w->act, w->live, w->h.n_live, w->qmask, w->map, w->nn, w->dmin);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int ward_pairs(icv_ward_s* w, bool all_active, hipStream_t st) {
+    hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, (int)w->n, w->live, w->cstate, w->qmask, w->mdesc,
+                       w->pair_d, w->size_old, w->size_new, w->alive, w->nn, w->dmin, w->log_i, w->log_j, w->log_d,
+                       w->log_size, w->act, all_active ? 1 : 0, w->counts);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&w->h, w->counts, sizeof(w->h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ++w->rounds;
+    return ICV_OK;
+}
+
+// merge log -> scipy linkage matrix: monotone heights, stable sort, union-find relabelling
+int ward_finish(icv_ward_s* w, double* h_linkage) {
+    const int64_t n = w->n;
     const size_t m = (size_t)n - 1;
+    if ((size_t)w->h.n_merges != m) return fail(ICV_ERR_INVALID, "ward_finish: the rounds are not complete");
     std::vector<int> li(m), lj(m), ls(m);
     std::vector<float> ldq(m);
-    HIP_TRY(hipMemcpy(li.data(), log_i, m * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(lj.data(), log_j, m * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ls.data(), log_size, m * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ldq.data(), log_d, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(li.data(), w->log_i, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lj.data(), w->log_j, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ls.data(), w->log_size, m * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ldq.data(), w->log_d, m * 4, hipMemcpyDeviceToHost));
     std::vector<double> height(m), slot_h((size_t)n, 0.0);
     for (size_t p = 0; p < m; ++p) {
         double h = std::sqrt((double)ldq[p]);
@@ -1312,6 +1433,112 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
         cluster[li[p]] = n + (int64_t)q;
     }
     return ICV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, int32_t* h_rounds, void* stream) {
+    if (!dist_sq || !h_linkage || n < 1 || ld < n || n > 0x7fffffff / 2)
+        return fail(ICV_ERR_INVALID, "bad ward_linkage arguments");
+    if (h_rounds) *h_rounds = 0;
+    if (n == 1) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    icv_ward_s* raw = nullptr;
+    if (int rc = ward_create(n, nullptr, 0, 0, st, &raw)) return rc;
+    std::unique_ptr<icv_ward_s> w(raw);
+    bool retry = false;
+    while (w->h.n_live > 1) {
+        if (int rc = ward_merge(w.get(), dist_sq, ld, nullptr, 0, nullptr, true, st)) return rc;
+        if (int rc = ward_scan(w.get(), dist_sq, ld, st)) return rc;
+        if (int rc = ward_pairs(w.get(), retry, st)) return rc;
+        if (w->h.n_pairs < 1) {
+            // no reciprocal pair: impossible with fresh neighbours and finite distances; search every row again
+            // once (cached neighbours of tied distances) before giving up
+            if (retry) return fail(ICV_ERR_INVALID, "ward_linkage: distances are not finite");
+            retry = true;
+        } else {
+            retry = false;
+        }
+    }
+    if (h_rounds) *h_rounds = w->rounds;
+    return ward_finish(w.get(), h_linkage);
+}
+
+int icv_ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, icv_ward_t* out,
+                    void* stream) {
+    return ward_create(n, sr_local, n_super, super_shift, static_cast<hipStream_t>(stream), out);
+}
+void icv_ward_destroy(icv_ward_t w) { delete w; }
+
+int icv_ward_merge(icv_ward_t w, float* d_local, int64_t ld, const float* stage, int64_t ld_stage,
+                   const int32_t* h_pslot, int32_t scatter, void* stream) {
+    if (!w || !d_local || ld < w->n) return fail(ICV_ERR_INVALID, "bad ward_merge arguments");
+    return ward_merge(w, d_local, ld, stage, ld_stage, h_pslot, scatter != 0, static_cast<hipStream_t>(stream));
+}
+
+int icv_ward_scatter(icv_ward_t w, float* d_local, int64_t ld, const float* v, int64_t ldv, const int32_t* h_vrow_i,
+                     int32_t n_v, void* stream) {
+    if (!w || !d_local || ld < w->n || n_v < 0 || n_v > w->n) return fail(ICV_ERR_INVALID, "bad ward_scatter arguments");
+    if (n_v == 0 || w->map.n_local < 1) return ICV_OK;
+    if (!v || !h_vrow_i || ldv < w->map.n_local) return fail(ICV_ERR_INVALID, "bad ward_scatter arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(w->vrow_i, h_vrow_i, (size_t)n_v * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(icv::k_ward_scatter, dim3((unsigned)((w->map.n_local + 255) / 256), (unsigned)n_v), dim3(256), 0,
+                       st, d_local, ld, v, ldv, w->vrow_i, w->cstate, w->map);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_ward_scan(icv_ward_t w, const float* d_local, int64_t ld, void* stream) {
+    if (!w || !d_local || ld < w->n) return fail(ICV_ERR_INVALID, "bad ward_scan arguments");
+    return ward_scan(w, d_local, ld, static_cast<hipStream_t>(stream));
+}
+
+int icv_ward_pack_nn(icv_ward_t w, int32_t* d_nn, float* d_dmin, void* stream) {
+    if (!w || !d_nn || !d_dmin) return fail(ICV_ERR_INVALID, "bad ward_pack_nn arguments");
+    const int k = w->h.n_pairs + w->h.n_act;
+    if (k < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_ward_pack_nn, dim3((unsigned)((k + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w->mdesc + w->merged_begin(), w->h.n_pairs, w->act, w->h.n_act,
+                       w->nn, w->dmin, w->map, d_nn, d_dmin);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_ward_unpack_nn(icv_ward_t w, const int32_t* d_nn, const float* d_dmin, void* stream) {
+    if (!w || !d_nn || !d_dmin) return fail(ICV_ERR_INVALID, "bad ward_unpack_nn arguments");
+    const int k = w->h.n_pairs + w->h.n_act;
+    if (k < 1) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_ward_unpack_nn, dim3((unsigned)((k + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w->mdesc + w->merged_begin(), w->h.n_pairs, w->act, w->h.n_act,
+                       d_nn, d_dmin, w->nn, w->dmin);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_ward_pairs(icv_ward_t w, int32_t all_active, int32_t* h_counts, void* stream) {
+    if (!w || !h_counts) return fail(ICV_ERR_INVALID, "bad ward_pairs arguments");
+    if (int rc = ward_pairs(w, all_active != 0, static_cast<hipStream_t>(stream))) return rc;
+    h_counts[0] = w->h.n_live;
+    h_counts[1] = w->h.n_merges;
+    h_counts[2] = w->h.n_pairs;
+    h_counts[3] = w->h.n_act;
+    return ICV_OK;
+}
+
+int icv_ward_round_pairs(icv_ward_t w, int32_t* h_i, int32_t* h_j) {
+    if (!w || !h_i || !h_j) return fail(ICV_ERR_INVALID, "bad ward_round_pairs arguments");
+    if (w->h.n_pairs < 1) return ICV_OK;
+    HIP_TRY(hipMemcpy(h_i, w->log_i + w->merged_begin(), (size_t)w->h.n_pairs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_j, w->log_j + w->merged_begin(), (size_t)w->h.n_pairs * 4, hipMemcpyDeviceToHost));
+    return ICV_OK;
+}
+
+int icv_ward_finish(icv_ward_t w, double* h_linkage, int32_t* h_rounds) {
+    if (!w || !h_linkage) return fail(ICV_ERR_INVALID, "bad ward_finish arguments");
+    if (h_rounds) *h_rounds = w->rounds;
+    return ward_finish(w, h_linkage);
 }
 
 int icv_row_abs_sum(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, double* row_sum, void* stream) {

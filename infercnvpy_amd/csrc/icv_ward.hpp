@@ -7,11 +7,12 @@
 // round can be merged at once -- the whole matrix is processed by data-parallel passes instead of
 // scipy's sequential nearest-neighbour chain:
 //
-//   round:  k_ward_round   one workgroup per live row: apply the previous round's merges to the row
-//                          (Lance-Williams in float64 on the float32 squared distances, in place),
-//                          and find the row's nearest live neighbour
+//   round:  k_ward_merge   one workgroup per pair merged in the previous round: the merged row (Lance-Williams
+//                          in float64 on the float32 squared distances, in place), its nearest neighbour, the
+//                          new column pushed into the rows that did not merge
+//           k_ward_scan    one workgroup per row whose cached nearest neighbour merged or died
 //           k_ward_pairs   one workgroup: detect RNN pairs in row order (deterministic), append them to
-//                          the merge log, set the column roles for the next round, compact the live list
+//                          the merge log, set the column states for the next round, compact the live list
 //
 // Distances are stored squared: Ward's update is linear in d^2
 //   d2(k, i+j) = ((n_i+n_k) d2(k,i) + (n_j+n_k) d2(k,j) - n_k d2(i,j)) / (n_i+n_j+n_k)
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256) k_center_rows(const float* x, int64_t n, 
 
 // ---- Ward rounds ------------------------------------------------------------------------------------
 struct WardCounts {
-    int n_live, n_merges, n_pairs, pad;
+    int n_live, n_merges, n_pairs, n_act;
 };
 
 __device__ __forceinline__ float ward_lw(float dac, float dbc, float dab, int na, int nb, int nc) {
@@ -77,8 +78,9 @@ __device__ __forceinline__ float ward_lw(float dac, float dbc, float dab, int na
     return v > 0.0 ? (float)v : 0.0f;
 }
 
-// Updated value of entry (r, c) after the merges of the previous round (role[x] >= 0: x absorbed role[x]);
-// changed = the stored value has to be rewritten.  rj = role[r], cl = role[c].
+// Entry (r, c) of a row r that merged in the previous round (r absorbed rj) for a column c that merged in the
+// same round (c absorbed cl): both merges are applied through one canonical order (lower slot first), so that
+// row c evaluates bit for bit the same value for its column r.
 struct WardRow {
     const float* Dr;
     const float* Dj;
@@ -88,14 +90,6 @@ struct WardRow {
 __device__ __forceinline__ float ward_entry(const WardRow& R, int c, int cl, float drc, const float* pair_d,
                                             const int* size_old, const int* size_new, bool& changed) {
     changed = true;
-    if (R.rj < 0) {
-        if (cl < 0) {
-            changed = false;
-            return drc;
-        }
-        return ward_lw(drc, R.Dr[cl], pair_d[c], size_old[c], size_old[cl], R.sn_r);
-    }
-    if (cl < 0) return ward_lw(drc, R.Dj[c], R.pdr, R.so_r, R.so_j, size_old[c]);
     if (R.r < c) {  // row merge first, then the column merge
         const float xk = ward_lw(drc, R.Dj[c], R.pdr, R.so_r, R.so_j, size_old[c]);
         const float xl = ward_lw(R.Dr[cl], R.Dj[cl], R.pdr, R.so_r, R.so_j, size_old[cl]);
@@ -136,65 +130,144 @@ __device__ __forceinline__ void ward_argmin_publish(float best, int best_c, int 
     }
 }
 
-// One workgroup per live row r (slot index): bring the row up to date with the merges of the previous
-// round and find the nearest live neighbour.  size_old = sizes before those merges, size_new = after.
-// List form: iterates the compacted live list (late rounds, few live columns).
-__global__ void __launch_bounds__(256) k_ward_round(float* D, int64_t ld, const int* live, int n_live, const int* role,
-                                                    const float* pair_d, const int* size_old, const int* size_new,
-                                                    int* nn, float* dmin) {
-    const int r = live[blockIdx.x];
+// ---- storage map of a (possibly sharded) distance matrix ------------------------------------------------
+// Rows are owned in super-rows of 1 << shift rows (1024, the super-tile of the distance kernel).  sr_local ==
+// nullptr: one GPU holds all rows, row r is stored at row r.  Otherwise sr_local[r >> shift] is the local
+// super-row index on this rank (-1: another rank's rows) and sr_global its inverse.
+struct WardMap {
+    const int* sr_local;
+    const int* sr_global;
+    int shift;
+    int n_local;  // rows stored here
+    __device__ __forceinline__ bool mine(int r) const { return !sr_local || sr_local[r >> shift] >= 0; }
+    __device__ __forceinline__ int64_t lrow(int r) const {
+        return sr_local ? ((int64_t)sr_local[r >> shift] << shift) + (r & ((1 << shift) - 1)) : (int64_t)r;
+    }
+    __device__ __forceinline__ int grow(int lr) const {
+        return sr_global ? (sr_global[lr >> shift] << shift) + (lr & ((1 << shift) - 1)) : lr;
+    }
+};
+
+// ---- round kernels ----------------------------------------------------------------------------------------
+// The matrix is kept UP TO DATE at the end of every round ("push" form):
+//   k_ward_merge   one workgroup per pair (i, j) merged in the previous round, run by the owner of row i: the new
+//                  row D[i][c] = LW(D[i][c], D[j][c]) for every live column c (two streaming reads, one
+//                  streaming write), its nearest neighbour, and -- on one GPU -- the scatter of the new value
+//                  into column i of every row that did not merge (one 4-byte write per (row, merge); round 1
+//                  spent two gathers and a write per (row, merge) in every live row: 3-4x the streaming time).
+//                  Rows that merged in the same round are not written by others: each evaluates the shared entry
+//                  itself, through one canonical order, so that the two values agree bit for bit.
+//   k_ward_scatter (sharded matrices) the same column update from the new rows received from their owners.
+//   k_ward_scan    nearest live neighbour of the rows whose cached neighbour merged or died.  Ward is reducible:
+//                  a merged cluster is never closer to a bystander than the nearer of its parts was, so the
+//                  cached nearest neighbour of every other row stays valid and the row is not read at all.
+// Dense form (most columns alive, ld % 4 == 0): float4 streams over all n columns with per-column state;
+// list form: gathers over the compacted live list.
+// cstate[c] = -2 dead, -1 unchanged in the previous round, >= 0 the slot column c absorbed.
+struct WardPairView {
+    const int4* mdesc;   // {i, j, size_i, size_j} of the previous round's merges
+    const float* mdist;  // their squared distances
+    const int* pslot;    // staging slot of row j per merge (-1 / nullptr: row j is stored locally)
+    const float* stage;
+    int64_t ld_stage;
+};
+
+template <bool DENSE>
+__global__ void __launch_bounds__(256) k_ward_merge(float* D, int64_t ld, int n, const int* live, int n_live,
+                                                    const int* cstate, const WardPairView V, const float* pair_d,
+                                                    const int* size_old, const int* size_new, const WardMap M,
+                                                    bool scatter, int* nn, float* dmin) {
+    const int4 m = V.mdesc[blockIdx.x];
+    const int r = m.x;
+    if (!M.mine(r)) return;
     WardRow R;
     R.r = r;
-    R.rj = role[r];
-    float* Dr = D + (int64_t)r * ld;
+    R.rj = m.y;
+    float* Dr = D + M.lrow(r) * ld;
     R.Dr = Dr;
-    R.Dj = R.rj >= 0 ? D + (int64_t)R.rj * ld : nullptr;
-    R.pdr = R.rj >= 0 ? pair_d[r] : 0.0f;
-    R.so_r = size_old[r];
-    R.sn_r = size_new[r];
-    R.so_j = R.rj >= 0 ? size_old[R.rj] : 0;
+    const int ps = V.pslot ? V.pslot[blockIdx.x] : -1;
+    R.Dj = ps >= 0 ? V.stage + (int64_t)ps * V.ld_stage : D + M.lrow(m.y) * ld;
+    R.pdr = V.mdist[blockIdx.x];
+    R.so_r = m.z;
+    R.so_j = m.w;
+    R.sn_r = m.z + m.w;
 
     float best = __builtin_inff();
     int best_c = -1;
-    for (int idx = threadIdx.x; idx < n_live; idx += 256) {
-        const int c = live[idx];
-        if (c == r) continue;
-        bool changed;
-        const float v = ward_entry(R, c, role[c], Dr[c], pair_d, size_old, size_new, changed);
-        if (changed) Dr[c] = v;
+    auto elem = [&](int c, int cl, float drc, float djc, int so_c, float& out) {
+        if (cl == -2 || c == r) return;
+        float v;
+        if (cl < 0) {
+            v = ward_lw(drc, djc, R.pdr, R.so_r, R.so_j, so_c);
+            // one 4-byte write per 128-byte line of row c: a read-modify-write of the line in HBM, the dominant
+            // cost of the rounds (a non-temporal store was measured: 5 % slower)
+            if (scatter && M.mine(c)) D[M.lrow(c) * ld + r] = v;
+        } else {
+            bool changed;
+            v = ward_entry(R, c, cl, drc, pair_d, size_old, size_new, changed);
+        }
+        out = v;
         if (v < best) {  // c ascends within a thread: strict < keeps the lowest index on ties
             best = v;
             best_c = c;
+        }
+    };
+    if (DENSE) {
+        const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
+        const float4* Dj4 = reinterpret_cast<const float4*>(R.Dj);
+        const int4* cs4 = reinterpret_cast<const int4*>(cstate);
+        const int4* so4 = reinterpret_cast<const int4*>(size_old);
+        const int nq = n >> 2;
+        for (int q = threadIdx.x; q < nq; q += 256) {
+            const float4 d = Dr4[q], e = Dj4[q];
+            const int4 cs = cs4[q], so = so4[q];
+            float4 o = d;
+            elem(4 * q, cs.x, d.x, e.x, so.x, o.x);
+            elem(4 * q + 1, cs.y, d.y, e.y, so.y, o.y);
+            elem(4 * q + 2, cs.z, d.z, e.z, so.z, o.z);
+            elem(4 * q + 3, cs.w, d.w, e.w, so.w, o.w);
+            reinterpret_cast<float4*>(Dr)[q] = o;
+        }
+        for (int c = 4 * nq + threadIdx.x; c < n; c += 256) {
+            float o = Dr[c];
+            elem(c, cstate[c], o, R.Dj[c], size_old[c], o);
+            Dr[c] = o;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < n_live; idx += 256) {
+            const int c = live[idx];
+            float o = Dr[c];
+            const float o0 = o;
+            elem(c, cstate[c], o, R.Dj[c], size_old[c], o);
+            if (c != r && o != o0) Dr[c] = o;
         }
     }
     ward_argmin_publish(best, best_c, r, nn, dmin);
 }
 
-// Dense form (early rounds, most columns alive, ld % 4 == 0).  An unchanged row (the common case) is one
-// contiguous float4 stream with a byte mask per four columns (bit i: column 4q + i is alive and did not merge)
-// followed by the few merged columns from the round's merge list; a merged row updates every live column.
-// cstate[c] = -2 dead, -1 unchanged, >= 0 the slot column c absorbed.
-__global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, int n, const int* live,
-                                                          const int* cstate, const unsigned char* qmask,
-                                                          const int4* mdesc, const float* mdist, int n_merged,
-                                                          const float* pair_d, const int* size_old,
-                                                          const int* size_new, int* nn, float* dmin) {
-    const int r = live[blockIdx.x];
-    WardRow R;
-    R.r = r;
-    R.rj = cstate[r];
-    float* Dr = D + (int64_t)r * ld;
-    R.Dr = Dr;
-    R.Dj = R.rj >= 0 ? D + (int64_t)R.rj * ld : nullptr;
-    R.pdr = R.rj >= 0 ? pair_d[r] : 0.0f;
-    R.so_r = size_old[r];
-    R.sn_r = size_new[r];
-    R.so_j = R.rj >= 0 ? size_old[R.rj] : 0;
+// D[c][i_q] = V[q][c] for every local row c that is alive and did not merge; V[q] = new row of merge q (the
+// columns this rank owns, in local order), vrow_i[q] its slot.  grid (ceil(n_local / 256), n_v).
+__global__ void __launch_bounds__(256) k_ward_scatter(float* D, int64_t ld, const float* V, int64_t ldv,
+                                                      const int* vrow_i, const int* cstate, const WardMap M) {
+    const int lr = blockIdx.x * 256 + threadIdx.x;
+    if (lr >= M.n_local) return;
+    const int c = M.grow(lr);
+    if (cstate[c] != -1) return;
+    D[(int64_t)lr * ld + vrow_i[blockIdx.y]] = V[(int64_t)blockIdx.y * ldv + lr];
+}
 
+// nearest live neighbour of row act[blockIdx.x] (a row that did not merge; every entry is up to date)
+template <bool DENSE>
+__global__ void __launch_bounds__(256) k_ward_scan(const float* D, int64_t ld, int n, const int* act, const int* live,
+                                                   int n_live, const unsigned char* qmask, const WardMap M, int* nn,
+                                                   float* dmin) {
+    const int r = act[blockIdx.x];
+    if (!M.mine(r)) return;
+    const float* Dr = D + M.lrow(r) * ld;
     float best = __builtin_inff();
     int best_c = -1;
-    const int n4 = (n + 3) >> 2;  // the row stride is padded to a multiple of 4; padding columns have mask 0
-    if (R.rj < 0) {
+    if (DENSE) {
+        const int n4 = (n + 3) >> 2;  // the row stride is padded to a multiple of 4; padding columns have mask 0
         const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
         const int rq = r >> 2;
         const unsigned rbit = 1u << (r & 3);
@@ -216,103 +289,58 @@ __global__ void __launch_bounds__(256) k_ward_round_dense(float* D, int64_t ld, 
             quad(q + 768, d3, m3);
         }
         for (; q < n4; q += 256) quad(q, Dr4[q], qmask[q]);
-        // columns that merged in the previous round (Lance-Williams on this row's two entries).  The round's
-        // merges are packed as {column, absorbed column, their sizes} + distance, so that the only dependent
-        // accesses are the two gathers from this row; two merges per thread are in flight.
-        auto merged_col = [&](const int4& m, float pd, float drc, float drl) {
-            const float v = ward_lw(drc, drl, pd, m.z, m.w, R.sn_r);
-            Dr[m.x] = v;
-            if (v < best || (v == best && m.x < best_c)) {
-                best = v;
-                best_c = m.x;
-            }
-        };
-        int idx = threadIdx.x;
-        for (; idx + 256 < n_merged; idx += 512) {
-            const int4 ma = mdesc[idx], mb = mdesc[idx + 256];
-            const float pa = mdist[idx], pb = mdist[idx + 256];
-            const float a0 = Dr[ma.x], a1 = Dr[ma.y], b0 = Dr[mb.x], b1 = Dr[mb.y];
-            merged_col(ma, pa, a0, a1);
-            merged_col(mb, pb, b0, b1);
-        }
-        for (; idx < n_merged; idx += 256) {
-            const int4 ma = mdesc[idx];
-            merged_col(ma, mdist[idx], Dr[ma.x], Dr[ma.y]);
-        }
     } else {
-        // a row that merged: every live column is updated.  Vector loads of both rows, the column states and
-        // the column sizes; only columns that merged as well need gathers.
-        const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
-        const float4* Dj4 = reinterpret_cast<const float4*>(R.Dj);
-        const int4* cs4 = reinterpret_cast<const int4*>(cstate);
-        const int4* so4 = reinterpret_cast<const int4*>(size_old);
-        const int nq = n >> 2;
-        auto elem = [&](int c, int cl, float drc, float djc, int so_c, float& out) {
-            if (cl == -2 || c == r) return;
-            float v;
-            if (cl < 0) {
-                v = ward_lw(drc, djc, R.pdr, R.so_r, R.so_j, so_c);
-            } else {
-                bool changed;
-                v = ward_entry(R, c, cl, drc, pair_d, size_old, size_new, changed);
-            }
-            out = v;
+        for (int idx = threadIdx.x; idx < n_live; idx += 256) {
+            const int c = live[idx];
+            if (c == r) continue;
+            const float v = Dr[c];
             if (v < best) {
                 best = v;
                 best_c = c;
             }
-        };
-        for (int q = threadIdx.x; q < nq; q += 256) {
-            const float4 d = Dr4[q], e = Dj4[q];
-            const int4 cs = cs4[q], so = so4[q];
-            float4 o = d;
-            elem(4 * q, cs.x, d.x, e.x, so.x, o.x);
-            elem(4 * q + 1, cs.y, d.y, e.y, so.y, o.y);
-            elem(4 * q + 2, cs.z, d.z, e.z, so.z, o.z);
-            elem(4 * q + 3, cs.w, d.w, e.w, so.w, o.w);
-            reinterpret_cast<float4*>(Dr)[q] = o;
-        }
-        for (int c = 4 * nq + threadIdx.x; c < n; c += 256) {
-            float o = Dr[c];
-            elem(c, cstate[c], o, R.Dj[c], size_old[c], o);
-            Dr[c] = o;
         }
     }
     ward_argmin_publish(best, best_c, r, nn, dmin);
 }
 
-// Single workgroup (1024 threads).  Finalises the previous round's bookkeeping, detects the reciprocal
-// nearest-neighbour pairs of this round in ascending slot order, logs them and compacts the live list.
-__global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role, int* cstate, unsigned char* qmask,
-                                                     int4* mdesc, float* pair_d,
-                                                     int* size_old, int* size_new, unsigned char* alive, const int* nn,
-                                                     const float* dmin, int* log_i, int* log_j, float* log_d,
-                                                     int* log_size, WardCounts* counts) {
-    __shared__ int s_scan[1024];
+// Single workgroup (1024 threads).  Detects the reciprocal nearest-neighbour pairs of this round in ascending
+// slot order, logs them, compacts the live list and lists the rows whose nearest neighbour has to be searched
+// again in the next round (act: alive, did not merge, cached neighbour merged or died; all_active: every such row).
+__global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* cstate, unsigned char* qmask, int4* mdesc,
+                                                     float* pair_d, int* size_old, int* size_new, unsigned char* alive,
+                                                     const int* nn, const float* dmin, int* log_i, int* log_j,
+                                                     float* log_d, int* log_size, int* act, int all_active,
+                                                     WardCounts* counts) {
+    __shared__ int s_scan[16];
     __shared__ int s_base;
     const int t = threadIdx.x;
     const int n_live = counts->n_live;
     const int m0 = counts->n_merges;
     for (int c = t; c < n; c += 1024) {
         size_old[c] = size_new[c];
-        role[c] = -1;
         cstate[c] = alive[c] ? -1 : -2;
     }
     if (t == 0) s_base = 0;
     __syncthreads();
 
-    auto block_scan = [&](int flag) {  // exclusive prefix over the workgroup + running base
-        s_scan[t] = flag;
+    // exclusive prefix of a 0/1 flag over the workgroup + running base: ballot / popcount inside the wavefront,
+    // the 16 wavefront totals through LDS
+    auto block_scan = [&](int flag) {
+        const unsigned long long b = __ballot(flag != 0);
+        const int lane = t & 63, wv = t >> 6;
+        const int within = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_scan[wv] = __popcll(b);
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = t >= o ? s_scan[t - o] : 0;
-            __syncthreads();
-            s_scan[t] += v;
-            __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = s_scan[w];
+            before += w < wv ? c : 0;
+            total += c;
         }
-        const int excl = s_scan[t] - flag + s_base;
+        const int excl = s_base + before + within;
         __syncthreads();
-        if (t == 1023) s_base += s_scan[1023];
+        if (t == 0) s_base += total;
         __syncthreads();
         return excl;
     };
@@ -334,7 +362,6 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
             log_d[m0 + p] = dmin[r];
             log_size[m0 + p] = sz;
             mdesc[m0 + p] = make_int4(r, c, size_old[r], size_old[c]);
-            role[r] = c;
             cstate[r] = c;
             cstate[c] = -2;
             pair_d[r] = dmin[r];
@@ -346,13 +373,29 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
     const int n_pairs = s_base;
     __syncthreads();
     if (t == 0) s_base = 0;
-    for (int q = t; q < (n + 3) / 4; q += 1024) {  // bit i: column 4q + i takes part in the plain arg-min stream
+    for (int q = t; q < (n + 3) / 4; q += 1024) {  // bit i: column 4q + i is alive
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (4 * q + i < n && cstate[4 * q + i] == -1) m |= 1u << i;
+            if (4 * q + i < n && alive[4 * q + i]) m |= 1u << i;
         qmask[q] = (unsigned char)m;
     }
+    __syncthreads();
+    // rows to search again (before the compaction: reads the old live list)
+    for (int base = 0; base < n_live; base += 1024) {
+        const int idx = base + t;
+        int r = -1, a = 0;
+        if (idx < n_live) {
+            r = live[idx];
+            a = cstate[r] == -1 && (all_active || cstate[nn[r]] != -1);
+        }
+        const int p = block_scan(a);
+        if (a) act[p] = r;
+    }
+    __syncthreads();
+    const int n_act = s_base;
+    __syncthreads();
+    if (t == 0) s_base = 0;
     __syncthreads();
     // live-list compaction in place (writes never pass the chunk being read)
     for (int base = 0; base < n_live; base += 1024) {
@@ -370,12 +413,12 @@ __global__ void __launch_bounds__(1024) k_ward_pairs(int n, int* live, int* role
         counts->n_live = s_base;
         counts->n_merges = m0 + n_pairs;
         counts->n_pairs = n_pairs;
+        counts->n_act = n_act;
     }
 }
 
-__global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* role, int* cstate, unsigned char* qmask,
-                                                   int* size_old, int* size_new, unsigned char* alive,
-                                                   WardCounts* counts) {
+__global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* cstate, unsigned char* qmask, int* size_old,
+                                                   int* size_new, unsigned char* alive, int* act, WardCounts* counts) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < (n + 3) / 4) {
         unsigned m = 0;
@@ -385,7 +428,7 @@ __global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* role, 
     }
     if (c < n) {
         live[c] = c;
-        role[c] = -1;
+        act[c] = c;
         cstate[c] = -1;
         size_old[c] = 1;
         size_new[c] = 1;
@@ -395,8 +438,30 @@ __global__ void __launch_bounds__(256) k_ward_init(int n, int* live, int* role, 
         counts->n_live = n;
         counts->n_merges = 0;
         counts->n_pairs = 0;
-        counts->pad = 0;
+        counts->n_act = n;
     }
+}
+
+// (nn, dmin) of the rows searched in this round, packed in list order for one all-reduce: entries of rows owned
+// by other ranks are zero, so that the sum over ranks is the owner's value.  list = the round's merged rows
+// (mdesc[.].x) followed by act.
+__global__ void __launch_bounds__(256) k_ward_pack_nn(const int4* mdesc, int n_pairs, const int* act, int n_act,
+                                                      const int* nn, const float* dmin, const WardMap M, int* out_nn,
+                                                      float* out_d) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_pairs + n_act) return;
+    const int r = k < n_pairs ? mdesc[k].x : act[k - n_pairs];
+    const bool mine = M.mine(r);
+    out_nn[k] = mine ? nn[r] : 0;
+    out_d[k] = mine ? dmin[r] : 0.0f;
+}
+__global__ void __launch_bounds__(256) k_ward_unpack_nn(const int4* mdesc, int n_pairs, const int* act, int n_act,
+                                                        const int* in_nn, const float* in_d, int* nn, float* dmin) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_pairs + n_act) return;
+    const int r = k < n_pairs ? mdesc[k].x : act[k - n_pairs];
+    nn[r] = in_nn[k];
+    dmin[r] = in_d[k];
 }
 
 }  // namespace icv

@@ -209,18 +209,109 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
 
 
 # --------------------------------------------------------------------------------------------------
-# BASELINE config 5: cell x cell distances sharded by row block, Ward rounds on the gathered matrix
+# BASELINE config 5: cell x cell distances and Ward rounds on a matrix sharded by rows
 # --------------------------------------------------------------------------------------------------
-def _hip_distance_rows(x_all, r0, r1, out):
-    from . import _engine
-
-    return _engine.pairwise_sqeuclidean(x_all, out=out, rows=(r0, r1))
+SUPER = 1024  # rows per super-row = ICV_SUPER_ROWS (the distance kernel's super-tile)
+SUPER_SHIFT = 10
 
 
-def _hip_ward(dist_sq):
-    from . import _engine
+class WardLayout:
+    """Ownership of the n x n distance matrix: super-rows of 1024 rows dealt out in a folded cyclic order
+    (rank 0 .. R-1, R-1 .. 0, 0 .. R-1, ...).  Row g of the upper triangle holds ``n_super - g`` super-tiles, so
+    pairing a long row with a short one gives every rank the same number of tiles to compute (to within one row
+    of super-tiles) and the same number of matrix rows to hold."""
 
-    return _engine.ward_linkage(dist_sq)[0]
+    def __init__(self, n: int, world_size: int, rank: int, super_rows: int = SUPER):
+        # super_rows: 1024 for the HIP kernels (ICV_SUPER_ROWS); the CPU tests of the exchanges use small ones
+        assert super_rows >= 8 and super_rows & (super_rows - 1) == 0
+        self.n, self.world, self.rank = int(n), int(world_size), int(rank)
+        self.S = int(super_rows)
+        self.shift = self.S.bit_length() - 1
+        self.n_super = (self.n + self.S - 1) // self.S
+        g = np.arange(self.n_super)
+        m = g % (2 * self.world)
+        self.owner = np.where(m < self.world, m, 2 * self.world - 1 - m).astype(np.int64)
+        # local super-row index of every global super-row on its owner, and per rank the list of its super-rows
+        self.local_index = np.zeros(self.n_super, dtype=np.int64)
+        self.supers_of = []
+        for r in range(self.world):
+            mine = np.flatnonzero(self.owner == r)
+            self.local_index[mine] = np.arange(len(mine))
+            self.supers_of.append(mine)
+        self.k = [len(v) for v in self.supers_of]  # super-rows per rank
+        self.sr_local = np.where(self.owner == self.rank, self.local_index, -1).astype(np.int32)
+        self.ld = (self.n + 3) // 4 * 4  # 16-byte row stride (vector loads in the Ward rounds)
+        self.rows_padded = self.k[self.rank] * self.S
+        # first row of every rank's block in the mirror buffer (all ranks' local rows, concatenated)
+        self.dest_row0 = np.concatenate([[0], np.cumsum([k * self.S for k in self.k])]).astype(np.int64)
+
+    def lrow(self, rows):
+        """Local row index of global rows (on their owners)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        return self.local_index[rows >> self.shift] * self.S + (rows & (self.S - 1))
+
+    def row_owner(self, rows):
+        return self.owner[np.asarray(rows, dtype=np.int64) >> self.shift]
+
+    def columns_of(self, r):
+        """Global column index of every (padded) local row of rank r, clipped to n - 1."""
+        g = self.supers_of[r]
+        cols = (g[:, None] * self.S + np.arange(self.S)[None, :]).reshape(-1)
+        return np.minimum(cols, self.n - 1)
+
+    def tile_plan(self):
+        """This rank's super-tiles (its super-rows of the upper triangle): row0, col0, offset of the direct
+        block in the local matrix, offset of the transposed block in the mirror buffer (row stride
+        ``rows_padded``: the columns of the mirror block are this rank's local rows)."""
+        row0, col0, dir_off, mir_off = [], [], [], []
+        for ly, gy in enumerate(self.supers_of[self.rank]):
+            for gx in range(gy, self.n_super):
+                d = self.owner[gx]
+                row0.append(gy * self.S)
+                col0.append(gx * self.S)
+                dir_off.append(ly * self.S * self.ld + gx * self.S)
+                mir_off.append((self.dest_row0[d] + self.local_index[gx] * self.S) * self.rows_padded + ly * self.S)
+        return (np.asarray(row0, dtype=np.int32), np.asarray(col0, dtype=np.int32),
+                np.asarray(dir_off, dtype=np.int64), np.asarray(mir_off, dtype=np.int64))
+
+
+def _group_rank(group, r):
+    dist = _dist()
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def _host_staged(t, group):
+    """Collectives on device tensors go through the host when the backend cannot take them (gloo in the tests)."""
+    dist = _dist()
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def _all_to_all_rows(send, send_rows, recv_rows, group=None):
+    """all_to_all of row blocks of a 2-D tensor: ``send_rows[d]`` consecutive rows go to rank d."""
+    import torch
+
+    dist = _dist()
+    recv = torch.empty((int(sum(recv_rows)), send.shape[1]), dtype=send.dtype, device=send.device)
+    if _host_staged(send, group):
+        r_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r_h, send.cpu().contiguous(), [int(v) for v in recv_rows], [int(v) for v in send_rows],
+                               group=group)
+        recv.copy_(r_h)
+    else:
+        dist.all_to_all_single(recv, send.contiguous(), [int(v) for v in recv_rows], [int(v) for v in send_rows],
+                               group=group)
+    return recv
+
+
+def _all_reduce_sum(t, group=None):
+    dist = _dist()
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
 
 
 def gather_rows(x_local, group=None):
@@ -231,79 +322,246 @@ def gather_rows(x_local, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return x_local, [(0, x_local.shape[0])]
     ws = dist.get_world_size(group)
-    counts = [torch.zeros(1, dtype=torch.int64, device=x_local.device) for _ in range(ws)]
-    dist.all_gather(counts, torch.tensor([x_local.shape[0]], dtype=torch.int64, device=x_local.device), group=group)
+    staged = _host_staged(x_local, group)
+    dev = "cpu" if staged else x_local.device
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    dist.all_gather(counts, torch.tensor([x_local.shape[0]], dtype=torch.int64, device=dev), group=group)
     counts = [int(c.item()) for c in counts]
-    full = torch.empty((sum(counts), x_local.shape[1]), dtype=x_local.dtype, device=x_local.device)
+    full = torch.empty((sum(counts), x_local.shape[1]), dtype=x_local.dtype, device=dev)
     bounds, r0 = [], 0
     for c in counts:
         bounds.append((r0, r0 + c))
         r0 += c
+    xl = x_local.cpu() if staged else x_local
     if len(set(counts)) == 1:
-        dist.all_gather_into_tensor(full, x_local.contiguous(), group=group)
+        dist.all_gather_into_tensor(full, xl.contiguous(), group=group)
     else:  # ragged shards: one broadcast per owner
         for r, (a, b) in enumerate(bounds):
             if r == dist.get_rank(group):
-                full[a:b] = x_local
-            dist.broadcast(full[a:b], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
-    return full, bounds
+                full[a:b] = xl
+            dist.broadcast(full[a:b], src=_group_rank(group, r), group=group)
+    return (full.to(x_local.device) if staged else full), bounds
 
 
-def ward_linkage_sharded(x_local, *, group=None, distance_rows=None, ward=None):
-    """Ward linkage of all cells of a row-sharded ``X_cnv`` (device float32, this rank's rows).
+class HipWardSteps:
+    """The step kernels of the sharded linkage behind the C ABI (``include/infercnv_hip.h``)."""
 
-    1. the shards are all-gathered (n x d float32: 4 GB for 200 000 x 5 000), so every GPU holds all cells;
-    2. every rank computes ITS row block of the squared distance matrix, i.e. its diagonal block and all of its
-       off-diagonal blocks, on fp32 MFMA tiles (``icv_pairwise_sqeuclidean`` with a row range) -- the
-       2 n^2 d flop are divided by the world size;
-    3. the row blocks travel to rank 0 over xGMI (point-to-point ``send``/``recv`` straight into the rows of
-       the resident n x n matrix: 160 GB for 200 000 cells, inside one MI355X's 288 GB);
-    4. rank 0 runs the reciprocal-nearest-neighbour Ward rounds (``icv_ward_linkage``; HBM-bound, ~2 matrix
-       passes in total) and broadcasts the (n-1) x 4 linkage matrix.
+    def __init__(self, n, layout):
+        import ctypes as C
 
-    ``distance_rows(x_all, r0, r1, out)`` / ``ward(dist_sq)`` default to the HIP entry points; the gloo tests
-    inject CPU stand-ins to exercise the exchange logic.
-    Returns the float64 linkage matrix (numpy) on every rank.
+        from . import _engine, _lib
+
+        self._C, self._engine, self._lib = C, _engine, _lib
+        self.lib = _lib.load()
+        self.torch = _engine._torch()
+        self.layout = layout
+        h = C.c_void_p()
+        sr = np.ascontiguousarray(layout.sr_local, dtype=np.int32)
+        assert layout.S == SUPER, "the HIP kernels own rows in super-rows of ICV_SUPER_ROWS"
+        _lib.check(self.lib.icv_ward_create(int(n), sr.ctypes.data, int(layout.n_super), SUPER_SHIFT, C.byref(h),
+                                            self._st()))
+        self.handle = h
+
+    def _st(self):
+        return self._engine._stream_ptr(self.torch)
+
+    def close(self):
+        if self.handle:
+            self.lib.icv_ward_destroy(self.handle)
+            self.handle = None
+
+    def distances(self, x_all, d_local, mirror):
+        row0, col0, dir_off, mir_off = self.layout.tile_plan()
+        if not len(row0):
+            return
+        p = self._engine._ptr
+        self._lib.check(self.lib.icv_pairwise_sqeuclidean_tiles(
+            p(x_all), x_all.shape[0], x_all.shape[1], x_all.stride(0), len(row0), row0.ctypes.data, col0.ctypes.data,
+            dir_off.ctypes.data, mir_off.ctypes.data, p(d_local), d_local.stride(0), p(mirror), mirror.stride(0),
+            self._st()))
+
+    def merge(self, d_local, stage, pslot):
+        if not self.layout.rows_padded:
+            return
+        p = self._engine._ptr
+        ps = np.ascontiguousarray(pslot, dtype=np.int32)
+        self._lib.check(self.lib.icv_ward_merge(self.handle, p(d_local), d_local.stride(0),
+                                                p(stage) if stage is not None and stage.numel() else None,
+                                                stage.stride(0) if stage is not None and stage.numel() else 0,
+                                                ps.ctypes.data, 0, self._st()))
+        self.torch.cuda.current_stream().synchronize()  # pslot is a host array
+
+    def scatter(self, d_local, v, vrow_i):
+        p = self._engine._ptr
+        vi = np.ascontiguousarray(vrow_i, dtype=np.int32)
+        self._lib.check(self.lib.icv_ward_scatter(self.handle, p(d_local), d_local.stride(0), p(v), v.stride(0),
+                                                  vi.ctypes.data, len(vi), self._st()))
+        self.torch.cuda.current_stream().synchronize()
+
+    def scan(self, d_local):
+        if not self.layout.rows_padded:
+            return
+        self._lib.check(self.lib.icv_ward_scan(self.handle, self._engine._ptr(d_local), d_local.stride(0), self._st()))
+
+    def pack(self, k, device):
+        t = self.torch
+        nn = t.empty(max(k, 1), dtype=t.int32, device=device)
+        dm = t.empty(max(k, 1), dtype=t.float32, device=device)
+        self._lib.check(self.lib.icv_ward_pack_nn(self.handle, self._engine._ptr(nn), self._engine._ptr(dm), self._st()))
+        return nn, dm
+
+    def unpack(self, nn, dm):
+        self._lib.check(self.lib.icv_ward_unpack_nn(self.handle, self._engine._ptr(nn), self._engine._ptr(dm), self._st()))
+
+    def pairs(self, all_active):
+        c = (self._C.c_int32 * 4)()
+        self._lib.check(self.lib.icv_ward_pairs(self.handle, int(bool(all_active)), c, self._st()))
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
+    def round_pairs(self, n_pairs):
+        i = np.empty(max(n_pairs, 1), dtype=np.int32)
+        j = np.empty(max(n_pairs, 1), dtype=np.int32)
+        self._lib.check(self.lib.icv_ward_round_pairs(self.handle, i.ctypes.data, j.ctypes.data))
+        return i[:n_pairs].astype(np.int64), j[:n_pairs].astype(np.int64)
+
+    def finish(self, n):
+        Z = np.empty((n - 1, 4), dtype=np.float64)
+        rounds = self._C.c_int32(0)
+        self._lib.check(self.lib.icv_ward_finish(self.handle, Z.ctypes.data, self._C.byref(rounds)))
+        return Z, int(rounds.value)
+
+
+def _unpack_mirror(layout, d_local, recv_from):
+    """Blocks below the diagonal of this rank's rows, from the mirror blocks the other ranks (and this one)
+    computed as transposes of their tiles above the diagonal.  ``recv_from[s]``: [my padded rows, s's padded rows]."""
+    n, S = layout.n, layout.S
+    T = S // 8  # the distance kernel's tile
+    for lx, gx in enumerate(layout.supers_of[layout.rank]):
+        r0 = lx * S
+        for s in range(layout.world):
+            blk = recv_from[s]
+            for ly, gy in enumerate(layout.supers_of[s]):
+                if gy > gx:
+                    break
+                c0, w = gy * S, min(S, n - gy * S)
+                if gy < gx:
+                    d_local[r0:r0 + S, c0:c0 + w] = blk[r0:r0 + S, ly * S:ly * S + w]
+                else:  # the diagonal super-tile: tiles strictly below the diagonal
+                    for a in range(1, 8):
+                        wa = min(a * T, w)
+                        d_local[r0 + a * T:r0 + (a + 1) * T, c0:c0 + wa] = \
+                            blk[r0 + a * T:r0 + (a + 1) * T, ly * S:ly * S + wa]
+
+
+def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False, super_rows=SUPER):
+    """Ward linkage of all cells of a row-sharded ``X_cnv`` (float32 device matrix: this rank's rows).
+
+    The n x n distance matrix is never gathered: every rank owns ``n / R`` of its rows (super-rows of 1024 in a
+    folded cyclic order, :class:`WardLayout`) and the Ward rounds run on the shards.
+
+    1. the cells are all-gathered (n x d float32: 4 GB for 200 000 x 5 000);
+    2. every rank computes the super-tiles ON OR ABOVE the diagonal of its super-rows on fp32 MFMA tiles
+       (``icv_pairwise_sqeuclidean_tiles``: n (n + 1024) d flop in total over all ranks, the same as one GPU) --
+       directly into its rows, and transposed into a mirror buffer that one ``all_to_all`` (RCCL over xGMI)
+       delivers to the owners of those rows: the off-diagonal blocks travel once;
+    3. Ward rounds (``icv_ward_*``): the owner of a merged row receives the partner row (``all_to_all`` of rows),
+       computes the new row and its nearest neighbour, sends every rank its columns of the new rows (``all_to_all``)
+       for the column update of the rows that did not merge; rows whose cached nearest neighbour merged are searched
+       again; one small all-reduce per round makes the (neighbour, distance) results of the round known to all
+       ranks, which then find the reciprocal pairs redundantly (replicated O(n) bookkeeping, deterministic).
+
+    Arithmetic per entry is that of the one-GPU path, so the result is bit-identical to ``tl.ward_linkage``.
+    ``steps``: factory ``(n, layout) -> object`` with the methods of :class:`HipWardSteps`, and ``super_rows``: the
+    gloo tests inject a numpy implementation with small super-rows to exercise the exchanges on CPU.  Returns the float64 linkage matrix on every rank.
     """
     import torch
 
     dist = _dist()
-    distance_rows = distance_rows or _hip_distance_rows
-    ward = ward or _hip_ward
     x_all, bounds = gather_rows(x_local, group)
     n = x_all.shape[0]
     if n < 2:
         raise ValueError("at least two cells are needed for a linkage")
-    rank, ws = (dist.get_rank(group), dist.get_world_size(group)) if len(bounds) > 1 else (0, 1)
-    r0, r1 = bounds[rank]
-    ld = (n + 3) // 4 * 4  # 16-byte row stride (vector loads in the Ward rounds)
-    if ws == 1:
-        d2 = torch.empty((n, ld), dtype=torch.float32, device=x_all.device)[:, :n]
-        distance_rows(x_all, 0, n, d2)
-        return np.asarray(ward(d2))
+    if len(bounds) == 1:
+        from . import _engine
 
-    def peer(r):
-        return dist.get_global_rank(group, r) if group is not None else r
+        d2 = torch.empty((n, (n + 3) // 4 * 4), dtype=torch.float32, device=x_all.device)[:, :n]
+        _engine.pairwise_sqeuclidean(x_all, out=d2)
+        Z, rounds = _engine.ward_linkage(d2)
+        return (Z, rounds) if return_rounds else Z
+    rank, ws = dist.get_rank(group), dist.get_world_size(group)
+    L = WardLayout(n, ws, rank, super_rows)
+    ops = (steps or HipWardSteps)(n, L)
+    dev = x_all.device
+    try:
+        # ---- distances: own rows directly, mirror blocks to their owners -------------------------------
+        d_local = torch.empty((L.rows_padded, L.ld), dtype=torch.float32, device=dev)
+        mirror = torch.empty((int(L.dest_row0[-1]), L.rows_padded), dtype=torch.float32, device=dev)
+        ops.distances(x_all, d_local, mirror)
+        del x_all
+        # what rank s sends me is [my padded rows, its padded rows]: a different width per source, so the
+        # exchange is one all_to_all per distinct width (flattened to 1-D)
+        send_counts = [L.k[d] * L.S * L.rows_padded for d in range(ws)]
+        recv_counts = [L.rows_padded * L.k[s] * L.S for s in range(ws)]
+        flat = _all_to_all_rows(mirror.reshape(-1, 1), send_counts, recv_counts, group)
+        del mirror
+        recv_from, o = [], 0
+        for s in range(ws):
+            recv_from.append(flat[o:o + recv_counts[s]].view(L.rows_padded, L.k[s] * L.S))
+            o += recv_counts[s]
+        _unpack_mirror(L, d_local, recv_from)
+        del flat, recv_from
 
-    if rank == 0:
-        d2 = torch.empty((n, ld), dtype=torch.float32, device=x_all.device)
-        distance_rows(x_all, r0, r1, d2[r0:r1, :n])
-        # the peers' row blocks arrive with the padded stride, so they land in place as contiguous memory
-        reqs = [dist.irecv(d2[a:b], src=peer(r), group=group) for r, (a, b) in enumerate(bounds) if r != 0 and b > a]
-        for q in reqs:
-            q.wait()
-        d2 = d2[:, :n]
-        Z = torch.from_numpy(np.ascontiguousarray(ward(d2), dtype=np.float64))
-        del d2
-    else:
-        block = torch.empty((r1 - r0, ld), dtype=torch.float32, device=x_all.device)
-        if r1 > r0:
-            if ld > n:
-                block[:, n:] = 0
-            distance_rows(x_all, r0, r1, block[:, :n])
-            dist.send(block, dst=peer(0), group=group)
-        del block
-        Z = torch.empty((n - 1, 4), dtype=torch.float64)
-    Zd = Z.to(x_all.device)
-    dist.broadcast(Zd, src=peer(0), group=group)
-    return Zd.cpu().numpy()
+        # ---- Ward rounds -------------------------------------------------------------------------------
+        n_live, n_merges, n_pairs, n_act = n, 0, 0, n
+        pi = pj = np.zeros(0, dtype=np.int64)
+        cols_of = [torch.from_numpy(L.columns_of(r)).to(dev) for r in range(ws)]
+        retry = False
+        while n_live > 1:
+            if n_pairs > 0:
+                oi, oj = L.row_owner(pi), L.row_owner(pj)
+                # partner rows j -> the owners of the rows i that absorbed them
+                send_idx = [L.lrow(pj[(oj == rank) & (oi == d)]) if d != rank else np.zeros(0, dtype=np.int64)
+                            for d in range(ws)]
+                recv_n = [int(((oi == rank) & (oj == s)).sum()) if s != rank else 0 for s in range(ws)]
+                idx = np.concatenate(send_idx)
+                sendbuf = d_local[torch.from_numpy(idx).to(dev)] if len(idx) else d_local[:0]
+                stage = _all_to_all_rows(sendbuf, [len(v) for v in send_idx], recv_n, group)
+                pslot = np.full(n_pairs, -1, dtype=np.int32)
+                base = 0
+                for s in range(ws):
+                    sel = np.flatnonzero((oi == rank) & (oj == s)) if s != rank else np.zeros(0, dtype=np.int64)
+                    pslot[sel] = base + np.arange(len(sel))
+                    base += len(sel)
+                ops.merge(d_local, stage, pslot)
+                del stage, sendbuf
+                # the new rows: every rank gets its columns of them (the sender's own share included)
+                mine = pi[oi == rank]
+                rows_t = torch.from_numpy(L.lrow(mine)).to(dev)
+                parts = [d_local[rows_t][:, cols_of[d]].reshape(-1, 1) if len(mine) else d_local[:0, :1]
+                         for d in range(ws)]
+                send_counts = [len(mine) * L.k[d] * L.S for d in range(ws)]
+                recv_counts = [int((oi == s).sum()) * L.rows_padded for s in range(ws)]
+                v = _all_to_all_rows(torch.cat(parts) if len(mine) else d_local[:0, :1].reshape(-1, 1),
+                                     send_counts, recv_counts, group)
+                vrow_i = np.concatenate([pi[oi == s] for s in range(ws)])
+                if len(vrow_i) and L.rows_padded:
+                    ops.scatter(d_local, v.view(len(vrow_i), L.rows_padded), vrow_i)
+                del v, parts
+            ops.scan(d_local)
+            nn_t, dm_t = ops.pack(n_pairs + n_act, dev)
+            _all_reduce_sum(nn_t, group)
+            _all_reduce_sum(dm_t, group)
+            ops.unpack(nn_t, dm_t)
+            n_live, n_merges, n_pairs, n_act = ops.pairs(retry)
+            if n_pairs < 1:
+                if retry:
+                    raise ValueError("ward_linkage: distances are not finite")
+                retry = True
+                pi = pj = np.zeros(0, dtype=np.int64)
+                continue
+            retry = False
+            pi, pj = ops.round_pairs(n_pairs)
+        Z, rounds = ops.finish(n)
+    finally:
+        ops.close()
+    return (Z, rounds) if return_rounds else Z

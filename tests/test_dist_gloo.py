@@ -168,35 +168,171 @@ def test_chunk_moments_segments():
 
 
 # --------------------------------------------------------------------------- #
-# config 5: row-block distances on every rank -> gathered on rank 0 -> Ward -> broadcast
+# config 5: sharded distance tiles + sharded Ward rounds.  The step kernels are replaced by a numpy
+# restatement with the same interface (icd.HipWardSteps) and small super-rows, so that the exchanges of
+# ward_linkage_sharded (mirror blocks, partner rows, new columns, neighbour all-reduce) run on CPU.
 # --------------------------------------------------------------------------- #
-def _cpu_distance_rows(x_all, r0, r1, out):
-    x = x_all.numpy().astype(np.float64)
-    d = ((x[r0:r1, None, :] - x[None, :, :]) ** 2).sum(-1)
-    out[: r1 - r0, : x.shape[0]] = torch.from_numpy(d.astype(np.float32))
-    return out
+class NumpyWardSteps:
+    def __init__(self, n, layout):
+        self.n, self.L = n, layout
+        self.alive = np.ones(n, bool)
+        self.cstate = np.full(n, -1, np.int64)   # -2 dead, -1 unchanged, >= 0 absorbed slot
+        self.size_old = np.ones(n, np.int64)
+        self.size_new = np.ones(n, np.int64)
+        self.nn = np.zeros(n, np.int64)
+        self.dmin = np.zeros(n, np.float32)
+        self.pair_d = np.zeros(n, np.float32)
+        self.act = np.arange(n)
+        self.merges = []      # (i, j, d, size) in log order
+        self.last = []        # the previous round's (i, j, size_i, size_j, d)
+        self.rounds = 0
+
+    def close(self):
+        pass
+
+    def _mine(self, r):
+        return self.L.row_owner([r])[0] == self.L.rank
+
+    def _row(self, d_local, r):
+        return d_local[int(self.L.lrow([r])[0])]
+
+    def distances(self, x_all, d_local, mirror):
+        L, S, T = self.L, self.L.S, self.L.S // 8
+        x = x_all.numpy().astype(np.float64)
+        n = x.shape[0]
+        row0, col0, dir_off, mir_off = L.tile_plan()
+        dl, mr = d_local.numpy().reshape(-1), mirror.numpy().reshape(-1)
+        for r0, c0, do, mo in zip(row0, col0, dir_off, mir_off):
+            for ty in range(r0, min(r0 + S, n), T):
+                for tx in range(c0, min(c0 + S, n), T):
+                    if tx < ty:
+                        continue
+                    rr, cc = np.arange(ty, min(ty + T, n)), np.arange(tx, min(tx + T, n))
+                    blk = ((x[rr][:, None, :] - x[cc][None, :, :]) ** 2).sum(-1).astype(np.float32)
+                    dl[(do + (rr[:, None] - r0) * L.ld + (cc[None, :] - c0)).ravel()] = blk.ravel()
+                    if tx > ty:
+                        mr[(mo + (cc[None, :] - c0) * L.rows_padded + (rr[:, None] - r0)).ravel()] = blk.ravel()
+
+    @staticmethod
+    def _lw(dac, dbc, dab, na, nb, nc):
+        v = ((na + nc) * np.float64(dac) + (nb + nc) * np.float64(dbc) - nc * np.float64(dab)) / (na + nb + nc)
+        return np.maximum(v, 0).astype(np.float32)
+
+    def merge(self, d_local, stage, pslot):
+        D = d_local.numpy()
+        st = stage.numpy() if stage is not None else None
+        cs, so, sn = self.cstate, self.size_old, self.size_new
+        for p, (i, j, si, sj, pd) in enumerate(self.last):
+            if not self._mine(i):
+                continue
+            Dr = self._row(D, i)
+            Dj = st[pslot[p]] if pslot[p] >= 0 else self._row(D, j)
+            new = Dr.copy()
+            best, best_c = np.inf, -1
+            for c in np.flatnonzero(cs != -2):
+                if c == i:
+                    continue
+                if cs[c] == -1:
+                    v = self._lw(Dr[c], Dj[c], pd, si, sj, so[c])
+                else:
+                    cl = cs[c]
+                    xk = self._lw(Dr[c], Dj[c], pd, si, sj, so[c])
+                    xl = self._lw(Dr[cl], Dj[cl], pd, si, sj, so[cl])
+                    v = self._lw(xk, xl, self.pair_d[c], so[c], so[cl], si + sj)
+                new[c] = v
+                if v < best:
+                    best, best_c = v, c
+            Dr[:] = new
+            self.nn[i], self.dmin[i] = best_c, best
+
+    def scatter(self, d_local, v, vrow_i):
+        D, V = d_local.numpy(), v.numpy()
+        for lr in range(self.L.rows_padded):
+            c = int(self.L.supers_of[self.L.rank][lr // self.L.S]) * self.L.S + lr % self.L.S
+            if c < self.n and self.cstate[c] == -1:
+                D[lr, np.asarray(vrow_i)] = V[:, lr]
+
+    def scan(self, d_local):
+        D = d_local.numpy()
+        for r in self.act:
+            if not self._mine(r):
+                continue
+            row = self._row(D, r)[: self.n].copy()
+            row[~self.alive] = np.inf
+            row[r] = np.inf
+            c = int(np.argmin(row))  # first minimum: lowest index on ties
+            self.nn[r], self.dmin[r] = c, row[c]
+
+    def _listed(self):
+        return np.concatenate([np.asarray([m[0] for m in self.last], dtype=np.int64), np.asarray(self.act, dtype=np.int64)])
+
+    def pack(self, k, device):
+        rows = self._listed()
+        mine = self.L.row_owner(rows) == self.L.rank if len(rows) else np.zeros(0, bool)
+        nn = torch.from_numpy(np.where(mine, self.nn[rows], 0).astype(np.int32))
+        dm = torch.from_numpy(np.where(mine, self.dmin[rows], 0).astype(np.float32))
+        assert len(rows) == k
+        return nn, dm
+
+    def unpack(self, nn, dm):
+        rows = self._listed()
+        self.nn[rows] = nn.numpy()
+        self.dmin[rows] = dm.numpy()
+
+    def pairs(self, all_active):
+        self.size_old[:] = self.size_new
+        self.cstate[:] = np.where(self.alive, -1, -2)
+        live = np.flatnonzero(self.alive)
+        self.last = []
+        for r in live:
+            c = self.nn[r]
+            if c > r and self.nn[c] == r:
+                self.last.append((int(r), int(c), int(self.size_old[r]), int(self.size_old[c]), float(self.dmin[r])))
+                self.merges.append((int(r), int(c), float(self.dmin[r]), int(self.size_old[r] + self.size_old[c])))
+                self.cstate[r], self.cstate[c] = c, -2
+                self.pair_d[r] = self.dmin[r]
+                self.size_new[r] = self.size_old[r] + self.size_old[c]
+                self.alive[c] = False
+        self.act = [int(r) for r in live if self.cstate[r] == -1 and (all_active or self.cstate[self.nn[r]] != -1)]
+        self.rounds += 1
+        return int(self.alive.sum()), len(self.merges), len(self.last), len(self.act)
+
+    def round_pairs(self, n_pairs):
+        return (np.asarray([m[0] for m in self.last], dtype=np.int64), np.asarray([m[1] for m in self.last], dtype=np.int64))
+
+    def finish(self, n):
+        # merge log -> scipy linkage matrix (the host part of icv_ward_finish)
+        m = len(self.merges)
+        height, slot_h = np.zeros(m), np.zeros(n)
+        for p, (i, j, d, _) in enumerate(self.merges):
+            height[p] = max(np.sqrt(d), slot_h[i], slot_h[j])
+            slot_h[i] = height[p]
+        order = np.argsort(height, kind="stable")
+        cluster = np.arange(n)
+        Z = np.zeros((m, 4))
+        for q, p in enumerate(order):
+            i, j, _, size = self.merges[p]
+            a, b = cluster[i], cluster[j]
+            Z[q] = [min(a, b), max(a, b), height[p], size]
+            cluster[i] = n + q
+        return Z, self.rounds
 
 
-def _cpu_ward(dist_sq):
-    from scipy.cluster.hierarchy import linkage
-    from scipy.spatial.distance import squareform
-
-    d = np.sqrt(dist_sq.numpy().astype(np.float64))
-    return linkage(squareform((d + d.T) / 2, checks=False), method="ward")
-
-
-def _ward_worker(rank, world, port, ragged, q):
+def _ward_worker(rank, world, port, n, ragged, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.RandomState(8)
-        n = 61 if ragged else 60
         X = (rng.standard_normal((n, 12)) + 3 * rng.randint(0, 3, (n, 1))).astype(np.float32)
-        bounds = [(0, 25), (25, n)] if ragged else [(0, 30), (30, 60)]
-        r0, r1 = bounds[rank]
-        Z = icd.ward_linkage_sharded(torch.from_numpy(X[r0:r1]), distance_rows=_cpu_distance_rows, ward=_cpu_ward)
+        cut = np.linspace(0, n, world + 1).astype(int)
+        if ragged:
+            cut[1] -= 5
+        r0, r1 = cut[rank], cut[rank + 1]
+        Z, rounds = icd.ward_linkage_sharded(torch.from_numpy(X[r0:r1]), steps=NumpyWardSteps, super_rows=16,
+                                             return_rounds=True)
         Zs = O.ward_linkage(X)
+        assert 1 < rounds < n - 1
         np.testing.assert_allclose(Z[:, 2], Zs[:, 2], rtol=1e-5)
         np.testing.assert_array_equal(Z[:, [0, 1, 3]], Zs[:, [0, 1, 3]])
         q.put((rank, "ok", None))
@@ -208,12 +344,14 @@ def _ward_worker(rank, world, port, ragged, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ragged", [False, True])
-def test_two_rank_sharded_ward_linkage(ragged):
+@pytest.mark.parametrize("world,n,ragged", [(2, 60, False), (2, 61, True), (3, 150, False), (2, 10, False)])
+def test_sharded_ward_rounds(world, n, ragged):
+    """Sharded distance tiles + sharded Ward rounds (numpy step kernels, gloo): same tree as scipy.
+    n = 10 with super-rows of 16: the second rank owns no rows at all."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ward_worker, args=(r, 2, port, ragged, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ward_worker, args=(r, world, port, n, ragged, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
@@ -221,3 +359,23 @@ def test_two_rank_sharded_ward_linkage(ragged):
         p.join(timeout=60)
     for rank, status, _ in results:
         assert status == "ok", f"rank {rank}: {status}"
+
+
+def test_ward_layout_is_balanced_and_complete():
+    """Folded cyclic ownership: every super-tile of the upper triangle is computed exactly once, the tile counts
+    of the ranks differ by at most one row of super-tiles, and every rank holds about n / R rows."""
+    for n, world in [(200_000, 8), (100_000, 4), (5000, 2), (1500, 3)]:
+        seen = set()
+        counts = []
+        for r in range(world):
+            L = icd.WardLayout(n, world, r)
+            row0, col0, dir_off, mir_off = L.tile_plan()
+            counts.append(len(row0))
+            for a, b in zip(row0, col0):
+                assert (a, b) not in seen and b >= a
+                seen.add((int(a), int(b)))
+            assert np.all(np.diff(dir_off) > 0)
+        ns = -(-n // icd.SUPER)
+        assert len(seen) == ns * (ns + 1) // 2
+        assert max(counts) - min(counts) <= ns, (n, world, counts)
+        assert sum(L.k) == ns and max(L.k) - min(L.k) <= 1

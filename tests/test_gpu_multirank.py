@@ -3,7 +3,11 @@
 Skipped on boxes with fewer than 2 GPUs.  What runs on every rank is the product path: ``icv_colsum`` on the rank's
 rows -> ``dist.reference_means`` (one all-reduce) -> ``dist.run_shard`` (chunk-aligned: no further collective;
 unaligned: the chunk-moment all-reduce + ``icv_apply_threshold``).  The concatenated shards must equal the
-single-GPU run bit for bit; the sharded Ward linkage must equal ``tl.ward_linkage`` on one GPU."""
+single-GPU run bit for bit; the sharded Ward linkage must equal ``tl.ward_linkage`` on one GPU.
+
+``test_sharded_ward_two_processes_one_gpu`` runs the sharded distance tiles and Ward rounds (the HIP step kernels
+behind ``icv_pairwise_sqeuclidean_tiles`` / ``icv_ward_*``) with two processes on ONE GPU: the collectives go
+through gloo and host copies there, everything else is the code path of the multi-GPU job."""
 import os
 import socket
 
@@ -53,8 +57,8 @@ def _worker(rank, world, port, q):
                 torch.cuda.synchronize()
                 out[(align, ab is None)] = (r0, r1, res.out.cpu().numpy(), ref.cpu().numpy())
         # config 5: sharded distances + Ward against the single-GPU linkage
-        Xc = torch.from_numpy(np.random.RandomState(3).standard_normal((900, 64)).astype(np.float32)).cuda()
-        b2 = icd.shard_bounds(900, world, 1)
+        Xc = torch.from_numpy(np.random.RandomState(3).standard_normal((2500, 64)).astype(np.float32)).cuda()
+        b2 = icd.shard_bounds(2500, world, 1)
         Z = icd.ward_linkage_sharded(Xc[b2[rank][0]:b2[rank][1]].contiguous())
         q.put((rank, "ok", out, Z))
     except Exception:  # pragma: no cover
@@ -104,7 +108,60 @@ def test_two_ranks_match_single_gpu():
             assert np.array_equal(got, whole), key
         else:  # a mean differs in its last bit: values agree to rounding, the zero pattern up to threshold ties
             assert np.mean((got == 0) != (whole == 0)) < 1e-4
-    Xc = np.random.RandomState(3).standard_normal((900, 64)).astype(np.float32)
+    Xc = np.random.RandomState(3).standard_normal((2500, 64)).astype(np.float32)
     Z1 = ward_linkage(Xc)
     for r in range(2):
         np.testing.assert_array_equal(results[r][3], Z1)
+
+
+def _ward_one_gpu_worker(rank, world, port, n, d, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infercnvpy_amd import dist as icd
+
+        X = _ward_points(n, d)
+        cut = np.linspace(0, n, world + 1).astype(int)
+        Z, rounds = icd.ward_linkage_sharded(torch.from_numpy(X[cut[rank]:cut[rank + 1]]).cuda(), return_rounds=True)
+        q.put((rank, "ok", Z, rounds))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _ward_points(n, d):
+    rng = np.random.RandomState(n)
+    return (rng.standard_normal((n, d)) * 0.4 + rng.standard_normal((7, d))[rng.randint(0, 7, n)]).astype(np.float32)
+
+
+@pytest.mark.parametrize("world,n,d", [(2, 2500, 64), (3, 5300, 40), (2, 700, 16)])
+def test_sharded_ward_two_processes_one_gpu(world, n, d):
+    """Sharded tiles + sharded rounds equal the one-GPU linkage bit for bit (n = 700: one super-row, the second
+    rank holds nothing; n = 5300: six super-rows over three ranks, the last one partial)."""
+    import torch.multiprocessing as mp
+
+    from infercnvpy_amd.tl import ward_linkage
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ward_one_gpu_worker, args=(r, world, port, n, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"
+    Z1, rounds1 = ward_linkage(_ward_points(n, d), return_rounds=True)
+    for r in range(world):
+        assert results[r][3] == rounds1
+        np.testing.assert_array_equal(results[r][2], Z1)

@@ -12,13 +12,22 @@ python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/ward_prof/**/ward_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-rounds = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", "")) for r in rows if r["Kernel_Name"].startswith("icv::k_ward_round")]
-rounds.sort()
+def sel(prefix):
+    v = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+          int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) // 256)
+         for r in rows if prefix in r["Kernel_Name"]]
+    v.sort()
+    return v
+scan, merge, pairs = sel("k_ward_scan"), sel("k_ward_merge"), sel("k_ward_pairs")
 with open("gpurun_out/ward_prof/rounds.txt", "w") as o:
-    for i, (_, us, g) in enumerate(rounds):
-        o.write(f"round {i:3d} grid {g:>10s} {us:10.1f} us\n")
-    o.write(f"total {sum(u for _, u, _ in rounds) / 1e3:.1f} ms over {len(rounds)} rounds\n")
-print(open("gpurun_out/ward_prof/rounds.txt").read()[-1500:])
+    o.write("round: rows searched, us | rows merged, us | pairs kernel us\n")
+    for i, (_, us, g) in enumerate(scan):
+        m = merge[i - 1] if 0 < i <= len(merge) else (0, 0.0, 0)
+        pk = pairs[i][1] if i < len(pairs) else 0.0
+        o.write(f"round {i:3d} scan {g:7d} {us:9.1f} | merge {m[2]:6d} {m[1]:9.1f} | pairs {pk:7.1f}\n")
+    o.write(f"total scan {sum(u for _, u, _ in scan) / 1e3:.1f} ms, merge {sum(u for _, u, _ in merge) / 1e3:.1f} ms, "
+            f"pairs {sum(u for _, u, _ in pairs) / 1e3:.1f} ms over {len(scan)} rounds\n")
+print(open("gpurun_out/ward_prof/rounds.txt").read()[:6000])
 s = glob.glob("gpurun_out/ward_prof/**/ward_kernel_stats.csv", recursive=True)[0]
 print(open(s).read()[:1500])
 PY
