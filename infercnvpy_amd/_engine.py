@@ -253,38 +253,100 @@ def threshold_mask(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc
     return PackedRows(res.out, mask, counts, res.thr)
 
 
-def packed_to_host_csr(parts, n_cols):
-    """Pieces of :class:`PackedRows` (consecutive row ranges) -> one scipy CSR float64 on the host.
+class CsrDrain:
+    """CSR pack + copy back of finished pieces on a side stream while the caller computes the next ones.
 
-    One prefix sum per piece on the device, one synchronisation for the sizes, then the indices / values of
-    every piece are packed on the device straight into its slice of the final host arrays."""
-    torch = _torch()
-    lib = _lib.load()
-    indptrs = []
-    for p in parts:
-        ip = torch.zeros(p.counts.shape[0] + 1, dtype=torch.int64, device="cuda")
-        torch.cumsum(p.counts, 0, out=ip[1:])
-        indptrs.append(ip)
-    nnzs = [int(ip[-1].item()) for ip in indptrs]
-    total, rows = sum(nnzs), sum(p.counts.shape[0] for p in parts)
-    indptr_h = np.zeros(rows + 1, dtype=np.int64)
-    indices_h = np.empty(total, dtype=np.int32)
-    data_h = np.empty(total, dtype=np.float64)
-    cap = max(nnzs + [1])
-    idx_d = torch.empty(cap, dtype=torch.int32, device="cuda")
-    dat_d = torch.empty(cap, dtype=torch.float64, device="cuda")
-    r, o = 0, 0
-    for p, ip, nnz in zip(parts, indptrs, nnzs):
-        n = p.counts.shape[0]
-        if nnz:
-            _lib.check(lib.icv_csr_fill_masked(_ptr(p.out), n, n_cols, p.out.stride(0), _ptr(p.mask), _ptr(ip),
-                                               _ptr(idx_d), _ptr(dat_d), _stream_ptr(torch)))
-            torch.from_numpy(indices_h[o:o + nnz]).copy_(idx_d[:nnz])
-            torch.from_numpy(data_h[o:o + nnz]).copy_(dat_d[:nnz])
-        indptr_h[r + 1:r + n + 1] = ip[1:].cpu().numpy() + o
-        r += n
-        o += nnz
-    return sp.csr_matrix((data_h, indices_h, indptr_h), shape=(rows, n_cols))
+    ``submit(part)`` (a :class:`PackedRows`, consecutive row ranges in order) returns at once; a helper thread waits
+    for the piece on its own stream, forms the row offsets, packs indices / float64 values on the device and copies
+    them into the final host arrays (sized from the first piece's density, grown if that was too small).
+    ``finish()`` returns the scipy CSR matrix of all rows."""
+
+    def __init__(self, n_rows, n_cols):
+        import queue
+        import threading
+
+        torch = _torch()
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self._q = queue.Queue()
+        self._stream = torch.cuda.Stream()
+        self._err = None
+        self.indptr_h = np.zeros(self.n_rows + 1, dtype=np.int64)
+        self.indices_h = np.empty(0, dtype=np.int32)
+        self.data_h = np.empty(0, dtype=np.float64)
+        self.rows_done, self.nnz = 0, 0
+        self.busy_seconds = 0.0
+        device = torch.cuda.current_device()
+        lib = _lib.load()
+
+        def reserve(extra, rows_after):
+            need = self.nnz + extra
+            if need <= self.indices_h.shape[0]:
+                return
+            # density so far extrapolated to all rows, + 25 %
+            est = int(need / max(rows_after, 1) * self.n_rows * 1.25) + 1024 if rows_after < self.n_rows else need
+            cap = max(need, est)
+            # (plain allocations: huge-page-advised mappings were measured and are 2x slower to fill from the device)
+            idx, dat = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.float64)
+            idx[: self.nnz] = self.indices_h[: self.nnz]
+            dat[: self.nnz] = self.data_h[: self.nnz]
+            self.indices_h, self.data_h = idx, dat
+
+        def work():
+            import time
+
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(self._stream):
+                    while True:
+                        item = self._q.get()
+                        if item is None:
+                            return
+                        part, ev = item
+                        t0 = time.perf_counter()
+                        self._stream.wait_event(ev)
+                        n = part.counts.shape[0]
+                        ip = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+                        torch.cumsum(part.counts, 0, out=ip[1:])
+                        ip_h = ip.cpu().numpy()
+                        nnz = int(ip_h[-1])
+                        reserve(nnz, self.rows_done + n)
+                        if nnz:
+                            idx_d = torch.empty(nnz, dtype=torch.int32, device="cuda")
+                            dat_d = torch.empty(nnz, dtype=torch.float64, device="cuda")
+                            _lib.check(lib.icv_csr_fill_masked(
+                                _ptr(part.out), n, self.n_cols, part.out.stride(0), _ptr(part.mask), _ptr(ip), _ptr(idx_d),
+                                _ptr(dat_d), self._stream.cuda_stream))
+                            o = self.nnz
+                            torch.from_numpy(self.indices_h[o:o + nnz]).copy_(idx_d)
+                            torch.from_numpy(self.data_h[o:o + nnz]).copy_(dat_d)
+                            del idx_d, dat_d
+                        self.indptr_h[self.rows_done + 1:self.rows_done + n + 1] = ip_h[1:] + self.nnz
+                        self.rows_done += n
+                        self.nnz += nnz
+                        del part, item, ip
+                        self.busy_seconds += time.perf_counter() - t0
+            except BaseException as e:  # surfaced in finish()
+                self._err = e
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def submit(self, part):
+        torch = _torch()
+        if self._err is not None:
+            raise self._err
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._q.put((part, ev))
+
+    def finish(self):
+        self._q.put(None)
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        assert self.rows_done == self.n_rows, (self.rows_done, self.n_rows)
+        return sp.csr_matrix((self.data_h[: self.nnz], self.indices_h[: self.nnz], self.indptr_h),
+                             shape=(self.n_rows, self.n_cols))
 
 
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,

@@ -211,38 +211,34 @@ def infercnv(
         elif X.dtype in (np.float32, np.float16) and compute == np.float64:
             flags |= _lib.ICV_FLAG_ROUND_F32
 
-    pieces, gene_pieces = [], []
-    t_pack = 0.0
+    gene_pieces = []
     t0 = _time.perf_counter()
+    drain = _engine.CsrDrain(n_obs, plan.n_windows)  # packs and copies back finished pieces behind the kernels
     for i in range(len(bounds)):
         ss = slab_stream(i)  # a single slab that a reference pass has already brought in is not uploaded again
-        parts, thrs = [], []
+        thrs = []
         for r0, r1 in ss.pieces():
             res = _engine.run_hot_path(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                        dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
                                        row0=r0, row1=r1, apply=False)
-            parts.append(_engine.threshold_mask(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
+            drain.submit(_engine.threshold_mask(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
                                                 chunksize=chunksize, flags=flags, row0=r0, row1=r1))
             if res.thr is not None:
                 thrs.append(res.thr)
-        tp = _time.perf_counter()
-        pieces.append(_engine.packed_to_host_csr(parts, plan.n_windows))
-        t_pack += _time.perf_counter() - tp
+            del res
         if calculate_gene_values:
             thr_all = torch.cat(thrs) if thrs else None
             gv = _engine.gene_values(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=thr_all,
                                      chunksize=chunksize, flags=flags)
             gene_pieces.append(gv.cpu().numpy())
-        del parts
     for k in list(streams):
         t_h2d[0] += streams.pop(k).h2d_seconds
-    tm["stream_and_kernels"] = _time.perf_counter() - t0 - t_pack
+    tm["stream_and_kernels"] = _time.perf_counter() - t0
+    tp = _time.perf_counter()
+    res_mat = drain.finish()
     tm["h2d"] = t_h2d[0]
-    tm["csr_pack_d2h"] = t_pack
-    if pieces:
-        res_mat = sp.vstack(pieces).tocsr() if len(pieces) > 1 else pieces[0]
-    else:
-        res_mat = sp.csr_matrix((0, plan.n_windows), dtype=np.float64)
+    tm["csr_pack_d2h"] = drain.busy_seconds        # mostly hidden behind the uploads and kernels
+    tm["csr_pack_d2h_tail"] = _time.perf_counter() - tp  # what was left after the last kernel was launched
 
     chr_pos = dict(plan.chr_pos)
     per_gene_mtx = None
