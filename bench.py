@@ -305,8 +305,14 @@ def main():
     avg_smooth_ms = sum(smooth_ms) / max(len(smooth_ms), 1)
     achieved = bytes_per_cell * n_local / (avg_smooth_ms * 1e-3) / 1e9
     x16 = args.format == "dense" and args.window == 100 and args.step == 10
-    kernel_name = ("k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10)" if x16 else
-                   "k_smooth_ws (variant for this window / format; generic k_smooth if the plan does not fit)")
+    if x16:
+        kernel_name = "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10)"
+    elif args.format == "dense" and args.window == 250 and args.step == 10:
+        kernel_name = "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
+    elif args.format == "csr":
+        kernel_name = "k_smooth_ws<..., CSR> after k_csr_prepare (prepared-entry CSR variant for this window)"
+    else:
+        kernel_name = "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     # HBM bytes from the PMC counters are collected by tools/gpu_profile.sh (separate rocprofv3 --pmc passes) for

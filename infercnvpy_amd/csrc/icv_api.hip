@@ -556,9 +556,10 @@ int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipS
     const int64_t n = K.n_rows;
     if (n < 1) return ICV_OK;
     const int W = pl->p.W;
-    double *win = nullptr, *med = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&win, (size_t)n * W * sizeof(double), st));
-    HIP_TRY(hipMallocAsync((void**)&med, (size_t)n * sizeof(double), st));
+    AsyncBuf win_b, med_b;
+    HIP_TRY(win_b.alloc((size_t)n * W * sizeof(double), st));
+    HIP_TRY(med_b.alloc((size_t)n * sizeof(double), st));
+    double *win = win_b.as<double>(), *med = med_b.as<double>();
     int rc = split_windows(pl, m, K, win, st);
     if (!rc) {
         hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, win, n, W, med);
@@ -566,8 +567,6 @@ int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipS
                            K.cell_median, K.cell_stats);
         if (hipGetLastError() != hipSuccess) rc = fail(ICV_ERR_HIP, "split smoothing launch failed");
     }
-    (void)hipFreeAsync(win, st);
-    (void)hipFreeAsync(med, st);
     return rc;
 }
 
@@ -730,8 +729,9 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
         const int n_tiles = (nc + icv::kCsrTileCols - 1) / icv::kCsrTileCols;
         const int lds = (nc < icv::kCsrTileCols ? nc : icv::kCsrTileCols) * (int)sizeof(double);
-        double* partial = nullptr;
-        HIP_TRY(hipMallocAsync((void**)&partial, (size_t)n_slabs * nc * sizeof(double), st));
+        AsyncBuf partial_b;
+        HIP_TRY(partial_b.alloc((size_t)n_slabs * nc * sizeof(double), st));
+        double* partial = partial_b.as<double>();
         dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(64);
         void (*kf)(const float*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
             icv::k_colsum_csr<float>;
@@ -750,13 +750,13 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
                                sums + (int64_t)g * nc);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipFreeAsync(partial, st));
         return ICV_OK;
     }
     const int rows_per_slab = 256;
     const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
-    double* partial = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&partial, (size_t)n_slabs * nc * sizeof(double), st));
+    AsyncBuf partial_b;
+    HIP_TRY(partial_b.alloc((size_t)n_slabs * nc * sizeof(double), st));
+    double* partial = partial_b.as<double>();
     dim3 grid((nc + 255) / 256, (unsigned)n_slabs), block(256);
     for (int g = 0; g < n_groups; ++g) {
         if (m->dtype == ICV_F32)
@@ -769,7 +769,6 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
                            sums + (int64_t)g * nc);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(partial, st));
     return ICV_OK;
 }
 

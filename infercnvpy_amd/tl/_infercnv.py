@@ -105,6 +105,12 @@ def infercnv(
     each ``chunksize``-cell chunk, reference :449-451).  ``_timings`` (not part of the reference API): a dict
     that receives the wall-clock seconds of the stages (plan, host -> HBM copy, kernels, CSR pack + copy back).
 
+    Precision of ``X_cnv``: every window is accumulated, centred and compared with the noise threshold in float64
+    (as the reference's ``np.convolve`` is) and stored on the device as float32; the CSR values are those float32
+    numbers widened to float64.  For float64 / integer input the reference keeps full float64 values, so entries
+    differ from it by up to half a float32 ulp (|x| <= lfc_clip = 3: 1.2e-7 absolute; the tests bound 1e-6); the
+    zero pattern is exact (ties with the threshold are re-decided in float64).
+
     Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
     while the pieces that have landed are smoothed (reference means: summed); X_cnv is packed to CSR on the
     GPU from the un-thresholded result and a keep-mask (x_res is never rewritten) and only the packed arrays
