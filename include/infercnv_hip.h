@@ -228,7 +228,7 @@ int icv_corr_iqr(const float *x, int64_t n, int32_t k, int64_t ld, double *h_iqr
  * of temporary device memory.
  *
  * icv_ward_linkage: Ward linkage of the n points whose squared distances are in dist_sq (n x n float32 in
- * HBM, symmetric; OVERWRITTEN).  h_linkage is a HOST array of (n-1) x 4 doubles in scipy's linkage-matrix
+ * HBM, symmetric, row stride ld >= n; OVERWRITTEN, the spare columns of a larger stride included).  h_linkage is a HOST array of (n-1) x 4 doubles in scipy's linkage-matrix
  * format (cluster ids, height, size; rows sorted by height).  Synchronous; *h_rounds (optional) returns
  * the number of reciprocal-nearest-neighbour rounds.  ICV_ERR_INVALID if a distance is NaN. */
 int icv_pairwise_sqeuclidean(const float *x, int64_t n, int32_t d, int64_t ld, int64_t row_begin, int64_t row_end,
@@ -251,34 +251,47 @@ int icv_pairwise_sqeuclidean_tiles(const float *x, int64_t n, int32_t d, int64_t
                                    const int64_t *h_mir_off, float *dir, int64_t ld_dir, float *mir, int64_t ld_mir,
                                    void *stream);
 
-/* Step-wise Ward rounds on a row-sharded matrix.  Every rank creates the same state (the bookkeeping is replicated
+/* Column layout of the Ward rounds (both entry points).  When the row stride leaves at least n / 2 spare columns
+ * (ld >= n + (n + 1) / 2, ld % 4 == 0) a merged cluster keeps its row but moves to a NEW column: the clusters
+ * merged in a round take consecutive columns of the spare region, so that the update of every other row is one
+ * contiguous strip instead of one 4-byte write per 128-byte line; the alive columns are compacted in place when
+ * the region is full.  Smaller strides use the columns in place.  Results are identical either way, bit for bit.
+ *
+ * Step-wise Ward rounds on a row-sharded matrix.  Every rank creates the same state (the bookkeeping is replicated
  * and deterministic); h_sr_local[g] = local super-row index of global super-row g on THIS rank (0 .. k-1) or -1
- * (NULL: all rows are local).  One round:
+ * (NULL: all rows are local); ld = row stride of the local matrix, the same in every later call.  One round:
  *   icv_ward_merge     rows merged in the previous round, by their owners: new row, its nearest neighbour;
  *                      h_pslot[p] = row of `stage` holding the partner row of merge p (received from its owner) or
- *                      -1 if the partner is stored locally; scatter != 0: also push the new column into the local
- *                      rows (single-GPU form; sharded callers use icv_ward_scatter on the exchanged rows instead)
- *   icv_ward_scatter   column update from n_v new rows v[q][local row] (row stride ldv) of slots h_vrow_i[q]
+ *                      -1 if the partner is stored locally; scatter != 0: also update the other local rows
+ *                      (single-GPU form; sharded callers use gather / exchange / scatter instead)
+ *   icv_ward_gather    out[q][k] = entry of local row d_rows[q] (a new row) for the cluster of slot d_slots[k]:
+ *                      the columns another rank needs, in the order of ITS local rows (device index arrays)
+ *   icv_ward_scatter   the update of the local rows that did not merge from the n_pairs new rows v[q][local row]
+ *                      (row stride ldv); v[q] belongs to merge h_vrow_p[q] of the round (a permutation)
  *   icv_ward_scan      nearest neighbour of the local rows whose cached neighbour merged or died
  *   icv_ward_pack_nn / icv_ward_unpack_nn   the round's (neighbour, distance) results, n_pairs + n_act entries in
  *                      list order, zero where another rank owns the row: all-reduce(SUM) them in between
- *   icv_ward_pairs     reciprocal pairs of the round (replicated); h_counts = {n_live, n_merges, n_pairs, n_act}
- *                      (synchronises the stream); all_active != 0: list every live row for the next scan
+ *   icv_ward_pairs     reciprocal pairs of the round (replicated); compacts the local rows first when the column
+ *                      layout asks for it; h_counts = {n_live, n_merges, n_pairs, n_act} (synchronises the
+ *                      stream); all_active != 0: list every live row for the next scan
  *   icv_ward_round_pairs  slots (i kept, j absorbed) of the pairs just found, HOST arrays of n_pairs
  * until n_live == 1; icv_ward_finish writes the linkage matrix as icv_ward_linkage does.  One in-flight call per
  * state. */
 typedef struct icv_ward_s *icv_ward_t;
-int icv_ward_create(int64_t n, const int32_t *h_sr_local, int32_t n_super, int32_t super_shift, icv_ward_t *out,
-                    void *stream);
+int icv_ward_create(int64_t n, const int32_t *h_sr_local, int32_t n_super, int32_t super_shift, int64_t ld,
+                    icv_ward_t *out, void *stream);
 void icv_ward_destroy(icv_ward_t w);
 int icv_ward_merge(icv_ward_t w, float *d_local, int64_t ld, const float *stage, int64_t ld_stage,
                    const int32_t *h_pslot, int32_t scatter, void *stream);
-int icv_ward_scatter(icv_ward_t w, float *d_local, int64_t ld, const float *v, int64_t ldv, const int32_t *h_vrow_i,
+int icv_ward_gather(icv_ward_t w, const float *d_local, int64_t ld, const int64_t *d_rows, int32_t n_rows,
+                    const int32_t *d_slots, int32_t n_slots, float *out, int64_t ldo, void *stream);
+int icv_ward_scatter(icv_ward_t w, float *d_local, int64_t ld, const float *v, int64_t ldv, const int32_t *h_vrow_p,
                      int32_t n_v, void *stream);
 int icv_ward_scan(icv_ward_t w, const float *d_local, int64_t ld, void *stream);
 int icv_ward_pack_nn(icv_ward_t w, int32_t *d_nn, float *d_dmin, void *stream);
 int icv_ward_unpack_nn(icv_ward_t w, const int32_t *d_nn, const float *d_dmin, void *stream);
-int icv_ward_pairs(icv_ward_t w, int32_t all_active, int32_t *h_counts /* 4 */, void *stream);
+int icv_ward_pairs(icv_ward_t w, float *d_local, int64_t ld, int32_t all_active, int32_t *h_counts /* 4 */,
+                   void *stream);
 int icv_ward_round_pairs(icv_ward_t w, int32_t *h_i, int32_t *h_j);
 int icv_ward_finish(icv_ward_t w, double *h_linkage, int32_t *h_rounds);
 

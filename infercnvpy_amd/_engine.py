@@ -460,8 +460,16 @@ def pairwise_sqeuclidean(x, out=None, rows=None):
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     n = x.shape[0]
     r0, r1 = (0, n) if rows is None else rows
-    if out is None:  # row stride padded to 16 bytes: the Ward rounds use vector loads then
-        out = torch.empty((r1 - r0, (n + 3) // 4 * 4), dtype=torch.float32, device=x.device)[:, :n]
+    if out is None:
+        # row stride: a multiple of 16 bytes (vector loads in the Ward rounds) and, for the full matrix when HBM
+        # allows, n / 2 spare columns (the rounds then write their column updates as dense strips)
+        ld = (n + 3) // 4 * 4
+        if rows is None:
+            ld_spare = (n + (n + 1) // 2 + 3) // 4 * 4
+            free_b, _ = torch.cuda.mem_get_info()
+            if 4 * n * ld_spare + 4 * n * (x.shape[1] + 16) + (1 << 30) < free_b:
+                ld = ld_spare
+        out = torch.empty((r1 - r0, ld), dtype=torch.float32, device=x.device)[:, :n]
     assert out.shape[0] >= r1 - r0 and out.shape[1] >= n and out.stride(1) == 1
     _lib.check(lib.icv_pairwise_sqeuclidean(_ptr(x), n, x.shape[1], x.stride(0), r0, r1, _ptr(out), out.stride(0),
                                             _stream_ptr(torch)))

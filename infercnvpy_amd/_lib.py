@@ -28,7 +28,7 @@ EXPORTS = (
     "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
-    "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
+    "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_gather", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
     "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_last_error", "icv_version",
     "icv_device_count",
 )
@@ -102,15 +102,16 @@ def load():
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]
     lib.icv_ward_linkage.argtypes = [vp, i64, i64, vp, P(i32), vp]
     lib.icv_pairwise_sqeuclidean_tiles.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp]
-    lib.icv_ward_create.argtypes = [i64, vp, i32, i32, P(vp), vp]
+    lib.icv_ward_create.argtypes = [i64, vp, i32, i32, i64, P(vp), vp]
     lib.icv_ward_destroy.argtypes = [vp]
     lib.icv_ward_destroy.restype = None
     lib.icv_ward_merge.argtypes = [vp, vp, i64, vp, i64, vp, i32, vp]
+    lib.icv_ward_gather.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i64, vp]
     lib.icv_ward_scatter.argtypes = [vp, vp, i64, vp, i64, vp, i32, vp]
     lib.icv_ward_scan.argtypes = [vp, vp, i64, vp]
     lib.icv_ward_pack_nn.argtypes = [vp, vp, vp, vp]
     lib.icv_ward_unpack_nn.argtypes = [vp, vp, vp, vp]
-    lib.icv_ward_pairs.argtypes = [vp, i32, P(i32), vp]
+    lib.icv_ward_pairs.argtypes = [vp, vp, i64, i32, P(i32), vp]
     lib.icv_ward_round_pairs.argtypes = [vp, vp, vp]
     lib.icv_ward_finish.argtypes = [vp, vp, P(i32)]
     lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]

@@ -21,6 +21,7 @@
 #include "icv_kernel_x16.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
+#include "icv_ward_strip.hpp"
 #include "icv_plan.hpp"
 
 namespace {
@@ -1270,60 +1271,79 @@ int icv_pairwise_sqeuclidean_tiles(const float* x, int64_t n, int32_t d, int64_t
 }  // extern "C"
 
 // ---- Ward rounds: device bookkeeping shared by the one-call and the step-wise entry points ---------------
+// Two column layouts (icv_ward.hpp / icv_ward_strip.hpp): "strip" when the row stride leaves n / 2 spare columns
+// (merged clusters get new, consecutive columns: dense strip updates), "in place" otherwise.
 struct icv_ward_s {
-    int64_t n = 0;
+    int64_t n = 0, ld = 0;
+    int cap = 0;         // usable columns of a row (strip layout)
+    bool strip = false;
     char* buf = nullptr;
-    int *live, *cstate, *size_old, *size_new, *nn, *log_i, *log_j, *log_size, *act, *pslot, *vrow_i;
+    int *live, *cstate, *size_old, *size_new, *nn, *log_i, *log_j, *log_size, *act, *pslot, *vrow, *ulist;
     float *pair_d, *dmin, *log_d;
     unsigned char *alive, *qmask;
-    int4* mdesc;
-    icv::WardCounts* counts;
+    int4 *mdesc, *mpos;
+    icv::WardStripCounts* counts;
+    icv::WardPos pos{};
     int *sr_local = nullptr, *sr_global = nullptr;  // device copies (sharded matrices)
     icv::WardMap map{nullptr, nullptr, 10, 0};
-    icv::WardCounts h{0, 0, 0, 0};  // after the last icv_ward_pairs
+    icv::WardStripCounts h{0, 0, 0, 0, 0, 0, 0, 0};  // after the last icv_ward_pairs
     int rounds = 0;
     ~icv_ward_s() { (void)hipFree(buf); }
-    bool dense(const void* D, int64_t ld) const {
-        return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(D) & 15) == 0) && (int64_t)h.n_live * 4 >= n;
-    }
+    bool vec_ok(const void* D, int64_t ld_) const { return (ld_ % 4 == 0) && ((reinterpret_cast<uintptr_t>(D) & 15) == 0); }
+    // stream over all columns, or gather over the live list?
+    bool dense(const void* D, int64_t ld_, int width) const { return vec_ok(D, ld_) && (int64_t)h.n_live * 4 >= width; }
     int merged_begin() const { return h.n_merges - h.n_pairs; }
 };
 
 namespace {
-int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, hipStream_t st,
+int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, int64_t ld, hipStream_t st,
                 icv_ward_s** out) {
-    if (n < 2 || n > 0x7fffffff / 2 || !out) return fail(ICV_ERR_INVALID, "bad ward arguments");
+    if (n < 2 || n > 0x7fffffff / 2 || !out || ld < n) return fail(ICV_ERR_INVALID, "bad ward arguments");
     if (sr_local && (n_super < 1 || super_shift < 2 || super_shift > 20 || ((int64_t)n_super << super_shift) < n))
         return fail(ICV_ERR_INVALID, "bad ward storage map");
     std::unique_ptr<icv_ward_s> w(new icv_ward_s);
     w->n = n;
+    w->ld = ld;
+    w->strip = ld % 4 == 0 && ld >= n + (n + 1) / 2 && !std::getenv("ICV_WARD_IN_PLACE");
+    w->cap = w->strip ? (int)std::min<int64_t>(ld, 2 * n) : (int)n;
     const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
+    const size_t parr = ((size_t)w->cap * 4 + 255) / 256 * 256;  // arrays indexed by column position
     const size_t map_bytes = sr_local ? ((size_t)n_super * 8 + 255) / 256 * 256 : 0;
-    HIP_TRY(hipMalloc((void**)&w->buf, arr * 21 + 256 + map_bytes));
+    HIP_TRY(hipMalloc((void**)&w->buf, arr * 28 + parr * 7 + 512 + map_bytes));
     char* b = w->buf;
-    auto take = [&](size_t k) {
+    auto take = [&](size_t bytes) {
         char* p = b;
-        b += arr * k;
+        b += bytes;
         return p;
     };
-    w->live = (int*)take(1);
-    w->cstate = (int*)take(1);
-    w->pair_d = (float*)take(1);
-    w->size_old = (int*)take(1);
-    w->size_new = (int*)take(1);
-    w->nn = (int*)take(1);
-    w->dmin = (float*)take(1);
-    w->log_i = (int*)take(1);
-    w->log_j = (int*)take(1);
-    w->log_d = (float*)take(1);
-    w->log_size = (int*)take(1);
-    w->alive = (unsigned char*)take(1);
-    w->qmask = (unsigned char*)take(1);
-    w->act = (int*)take(1);
-    w->pslot = (int*)take(1);
-    w->vrow_i = (int*)take(1);
-    w->mdesc = (int4*)take(4);  // n x 16 bytes: one packed descriptor per merge
-    w->counts = (icv::WardCounts*)take(1);
+    w->live = (int*)take(arr);
+    w->cstate = (int*)take(arr);
+    w->pair_d = (float*)take(arr);
+    w->size_old = (int*)take(arr);
+    w->size_new = (int*)take(arr);
+    w->nn = (int*)take(arr);
+    w->dmin = (float*)take(arr);
+    w->log_i = (int*)take(arr);
+    w->log_j = (int*)take(arr);
+    w->log_d = (float*)take(arr);
+    w->log_size = (int*)take(arr);
+    w->alive = (unsigned char*)take(arr);
+    w->act = (int*)take(arr);
+    w->pslot = (int*)take(arr);
+    w->vrow = (int*)take(arr);
+    w->ulist = (int*)take(arr);
+    w->mdesc = (int4*)take(arr * 4);  // n x 16 bytes: one packed descriptor per merge
+    w->mpos = (int4*)take(arr * 4);
+    w->pos.slot_pos = (int*)take(arr);
+    w->pos.oldpos = (int*)take(arr);
+    w->qmask = (unsigned char*)take(parr);
+    w->pos.pos_slot = (int*)take(parr);
+    w->pos.palive = (unsigned char*)take(parr);
+    w->pos.pstate = (int*)take(parr);
+    w->pos.psize = (int*)take(parr);
+    w->pos.pnew = (int*)take(parr);
+    w->pos.newpos = (int*)take(parr);
+    w->counts = (icv::WardStripCounts*)take(256);
     if (sr_local) {
         // local super-row index per global super-row and its inverse
         std::vector<int> inv;
@@ -1349,54 +1369,135 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     } else {
         w->map = icv::WardMap{nullptr, nullptr, 10, (int)n};
     }
+    // both layouts start from the same state: width n, every row to be searched
     hipLaunchKernelGGL(icv::k_ward_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int)n, w->live,
-                       w->cstate, w->qmask, w->size_old, w->size_new, w->alive, w->act, w->counts);
+                       w->cstate, w->qmask, w->size_old, w->size_new, w->alive, w->act,
+                       reinterpret_cast<icv::WardCounts*>(w->counts));
+    if (w->strip)
+        hipLaunchKernelGGL(icv::k_ward_init_s, dim3((unsigned)((w->cap + 255) / 256)), dim3(256), 0, st, (int)n, w->cap,
+                           w->pos, w->ulist, w->qmask, w->counts);
     HIP_TRY(hipGetLastError());
-    w->h = icv::WardCounts{(int)n, 0, 0, (int)n};
+    w->h = icv::WardStripCounts{(int)n, 0, 0, (int)n, (int)n, (int)n, 0, (int)n};
     *out = w.release();
     return ICV_OK;
 }
 
+int ward_check_ld(const icv_ward_s* w, int64_t ld) {
+    return ld == w->ld ? ICV_OK : fail(ICV_ERR_INVALID, "ward: the row stride differs from the one given to icv_ward_create");
+}
+
 int ward_merge(icv_ward_s* w, float* D, int64_t ld, const float* stage, int64_t ld_stage, const int32_t* h_pslot,
                bool scatter, hipStream_t st) {
+    if (int rc = ward_check_ld(w, ld)) return rc;
     if (w->h.n_pairs < 1) return ICV_OK;
     const int mb = w->merged_begin();
     if (h_pslot) HIP_TRY(hipMemcpyAsync(w->pslot, h_pslot, (size_t)w->h.n_pairs * 4, hipMemcpyHostToDevice, st));
     const icv::WardPairView V{w->mdesc + mb, w->log_d + mb, h_pslot ? w->pslot : nullptr, stage, ld_stage};
     const bool stage_ok = !h_pslot || ((ld_stage % 4 == 0) && ((reinterpret_cast<uintptr_t>(stage) & 15) == 0));
-    if (w->dense(D, ld) && stage_ok)
-        hipLaunchKernelGGL(icv::k_ward_merge<true>, dim3((unsigned)w->h.n_pairs), dim3(256), 0, st, D, ld, (int)w->n,
-                           w->live, w->h.n_live, w->cstate, V, w->pair_d, w->size_old, w->size_new, w->map, scatter,
-                           w->nn, w->dmin);
-    else
-        hipLaunchKernelGGL(icv::k_ward_merge<false>, dim3((unsigned)w->h.n_pairs), dim3(256), 0, st, D, ld, (int)w->n,
-                           w->live, w->h.n_live, w->cstate, V, w->pair_d, w->size_old, w->size_new, w->map, scatter,
-                           w->nn, w->dmin);
+    const dim3 grid((unsigned)w->h.n_pairs), block(256);
+    if (w->strip) {
+        if (w->dense(D, ld, w->h.width_prev) && stage_ok)
+            hipLaunchKernelGGL(icv::k_ward_merge_s<true>, grid, block, 0, st, D, ld, w->h.width_prev, w->live, w->h.n_live,
+                               w->cstate, V, w->mpos + mb, w->pos, w->pair_d, w->size_new, w->map, w->nn, w->dmin);
+        else
+            hipLaunchKernelGGL(icv::k_ward_merge_s<false>, grid, block, 0, st, D, ld, w->h.width_prev, w->live, w->h.n_live,
+                               w->cstate, V, w->mpos + mb, w->pos, w->pair_d, w->size_new, w->map, w->nn, w->dmin);
+        if (scatter && w->h.n_unmerged > 0) {  // one GPU: the strip update straight from the new rows
+            const dim3 g2((unsigned)((w->h.n_pairs + 63) / 64), (unsigned)((w->h.n_unmerged + 63) / 64));
+            hipLaunchKernelGGL(icv::k_ward_push, g2, block, 0, st, D, ld, w->h.width_prev, w->mdesc + mb, w->h.n_pairs,
+                               w->ulist, w->h.n_unmerged, w->pos.slot_pos);
+        }
+    } else if (w->dense(D, ld, (int)w->n) && stage_ok) {
+        hipLaunchKernelGGL(icv::k_ward_merge<true>, grid, block, 0, st, D, ld, (int)w->n, w->live, w->h.n_live, w->cstate,
+                           V, w->pair_d, w->size_old, w->size_new, w->map, scatter, w->nn, w->dmin);
+    } else {
+        hipLaunchKernelGGL(icv::k_ward_merge<false>, grid, block, 0, st, D, ld, (int)w->n, w->live, w->h.n_live, w->cstate,
+                           V, w->pair_d, w->size_old, w->size_new, w->map, scatter, w->nn, w->dmin);
+    }
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }
 
 int ward_scan(icv_ward_s* w, const float* D, int64_t ld, hipStream_t st) {
+    if (int rc = ward_check_ld(w, ld)) return rc;
     if (w->h.n_act < 1) return ICV_OK;
-    if (w->dense(D, ld))
-        hipLaunchKernelGGL(icv::k_ward_scan<true>, dim3((unsigned)w->h.n_act), dim3(256), 0, st, D, ld, (int)w->n, w->act,
-                           w->live, w->h.n_live, w->qmask, w->map, w->nn, w->dmin);
-    else
-        hipLaunchKernelGGL(icv::k_ward_scan<false>, dim3((unsigned)w->h.n_act), dim3(256), 0, st, D, ld, (int)w->n,
-                           w->act, w->live, w->h.n_live, w->qmask, w->map, w->nn, w->dmin);
+    const dim3 grid((unsigned)w->h.n_act), block(256);
+    if (w->strip) {
+        if (w->dense(D, ld, w->h.width))
+            hipLaunchKernelGGL(icv::k_ward_scan_s<true>, grid, block, 0, st, D, ld, w->h.width, w->act, w->live,
+                               w->h.n_live, w->qmask, w->pos, w->map, w->nn, w->dmin);
+        else
+            hipLaunchKernelGGL(icv::k_ward_scan_s<false>, grid, block, 0, st, D, ld, w->h.width, w->act, w->live,
+                               w->h.n_live, w->qmask, w->pos, w->map, w->nn, w->dmin);
+    } else if (w->dense(D, ld, (int)w->n)) {
+        hipLaunchKernelGGL(icv::k_ward_scan<true>, grid, block, 0, st, D, ld, (int)w->n, w->act, w->live, w->h.n_live,
+                           w->qmask, w->map, w->nn, w->dmin);
+    } else {
+        hipLaunchKernelGGL(icv::k_ward_scan<false>, grid, block, 0, st, D, ld, (int)w->n, w->act, w->live, w->h.n_live,
+                           w->qmask, w->map, w->nn, w->dmin);
+    }
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }
 
-int ward_pairs(icv_ward_s* w, bool all_active, hipStream_t st) {
-    hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, (int)w->n, w->live, w->cstate, w->qmask, w->mdesc,
-                       w->pair_d, w->size_old, w->size_new, w->alive, w->nn, w->dmin, w->log_i, w->log_j, w->log_d,
-                       w->log_size, w->act, all_active ? 1 : 0, w->counts);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&w->h, w->counts, sizeof(w->h), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    ++w->rounds;
+int ward_read_counts(icv_ward_s* w, hipStream_t st) {
+    if (w->strip) {
+        HIP_TRY(hipMemcpyAsync(&w->h, w->counts, sizeof(w->h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        icv::WardCounts c;
+        HIP_TRY(hipMemcpyAsync(&c, w->counts, sizeof(c), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        w->h = icv::WardStripCounts{c.n_live, c.n_merges, c.n_pairs, c.n_act, (int)w->n, (int)w->n, 0, 0};
+    }
     return ICV_OK;
+}
+
+// in-place compaction of the alive columns of the alive local rows (strip layout)
+int ward_compact(icv_ward_s* w, float* D, int64_t ld, hipStream_t st) {
+    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (!w->strip) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_ward_compact_map, dim3(1), dim3(1024), 0, st, w->cap, w->pos, w->qmask, w->counts);
+    if (w->h.n_live > 0 && w->map.n_local > 0)
+        hipLaunchKernelGGL(icv::k_ward_compact_rows, dim3((unsigned)w->h.n_live), dim3(256), 0, st, D, ld, w->h.width,
+                           w->live, w->pos.newpos, w->map);
+    HIP_TRY(hipGetLastError());
+    w->h.width_prev = w->h.width;
+    w->h.width = w->h.n_live;
+    w->h.need_compact = 0;
+    return ICV_OK;
+}
+
+// reciprocal pairs of the round; strip layout: compacts first when fewer than half of the positions are alive,
+// and again (then it must fit) when the round's new columns would not fit the spare region
+int ward_pairs(icv_ward_s* w, float* D, int64_t ld, bool all_active, hipStream_t st) {
+    if (!w->strip) {
+        hipLaunchKernelGGL(icv::k_ward_pairs, dim3(1), dim3(1024), 0, st, (int)w->n, w->live, w->cstate, w->qmask, w->mdesc,
+                           w->pair_d, w->size_old, w->size_new, w->alive, w->nn, w->dmin, w->log_i, w->log_j, w->log_d,
+                           w->log_size, w->act, all_active ? 1 : 0, reinterpret_cast<icv::WardCounts*>(w->counts));
+        HIP_TRY(hipGetLastError());
+        ++w->rounds;
+        return ward_read_counts(w, st);
+    }
+    if (w->h.width > 2 * w->h.n_live && w->h.width > 4096)
+        if (int rc = ward_compact(w, D, ld, st)) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(icv::k_ward_pairs_s, dim3(1), dim3(1024), 0, st, (int)w->n, w->cap, w->live, w->cstate, w->qmask,
+                           w->mdesc, w->mpos, w->pair_d, w->size_old, w->size_new, w->alive, w->nn, w->dmin, w->log_i,
+                           w->log_j, w->log_d, w->log_size, w->act, w->ulist, all_active ? 1 : 0, w->pos, w->counts);
+        HIP_TRY(hipGetLastError());
+        const int width_before = w->h.width;
+        if (int rc = ward_read_counts(w, st)) return rc;
+        if (!w->h.need_compact) {
+            ++w->rounds;
+            return ICV_OK;
+        }
+        if (attempt == 1) break;
+        // nothing was committed: the counters other than need_compact are those of the previous round
+        w->h.width = width_before;
+        if (int rc = ward_compact(w, D, ld, st)) return rc;
+    }
+    return fail(ICV_ERR_UNSUPPORTED, "ward_pairs: the spare columns do not hold one round");
 }
 
 // merge log -> scipy linkage matrix: monotone heights, stable sort, union-find relabelling
@@ -1444,18 +1545,22 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
     if (n == 1) return ICV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     icv_ward_s* raw = nullptr;
-    if (int rc = ward_create(n, nullptr, 0, 0, st, &raw)) return rc;
+    if (int rc = ward_create(n, nullptr, 0, 0, ld, st, &raw)) return rc;
     std::unique_ptr<icv_ward_s> w(raw);
     bool retry = false;
     while (w->h.n_live > 1) {
         if (int rc = ward_merge(w.get(), dist_sq, ld, nullptr, 0, nullptr, true, st)) return rc;
         if (int rc = ward_scan(w.get(), dist_sq, ld, st)) return rc;
-        if (int rc = ward_pairs(w.get(), retry, st)) return rc;
+        if (int rc = ward_pairs(w.get(), dist_sq, ld, false, st)) return rc;
         if (w->h.n_pairs < 1) {
-            // no reciprocal pair: impossible with fresh neighbours and finite distances; search every row again
-            // once (cached neighbours of tied distances) before giving up
+            // No reciprocal pair: possible only when cached neighbours of TIED distances point in a cycle (fresh
+            // neighbours under one total order always contain a reciprocal pair).  List every live row, search
+            // them all again, and give up if that does not help (non-finite distances).
             if (retry) return fail(ICV_ERR_INVALID, "ward_linkage: distances are not finite");
             retry = true;
+            if (int rc = ward_pairs(w.get(), dist_sq, ld, true, st)) return rc;
+            --w->rounds;  // bookkeeping only, not a round
+            if (w->h.n_pairs > 0) retry = false;
         } else {
             retry = false;
         }
@@ -1464,33 +1569,72 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
     return ward_finish(w.get(), h_linkage);
 }
 
-int icv_ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, icv_ward_t* out,
-                    void* stream) {
-    return ward_create(n, sr_local, n_super, super_shift, static_cast<hipStream_t>(stream), out);
+int icv_ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, int64_t ld,
+                    icv_ward_t* out, void* stream) {
+    return ward_create(n, sr_local, n_super, super_shift, ld, static_cast<hipStream_t>(stream), out);
 }
 void icv_ward_destroy(icv_ward_t w) { delete w; }
 
 int icv_ward_merge(icv_ward_t w, float* d_local, int64_t ld, const float* stage, int64_t ld_stage,
                    const int32_t* h_pslot, int32_t scatter, void* stream) {
-    if (!w || !d_local || ld < w->n) return fail(ICV_ERR_INVALID, "bad ward_merge arguments");
+    if (!w || !d_local) return fail(ICV_ERR_INVALID, "bad ward_merge arguments");
     return ward_merge(w, d_local, ld, stage, ld_stage, h_pslot, scatter != 0, static_cast<hipStream_t>(stream));
 }
 
-int icv_ward_scatter(icv_ward_t w, float* d_local, int64_t ld, const float* v, int64_t ldv, const int32_t* h_vrow_i,
+int icv_ward_gather(icv_ward_t w, const float* d_local, int64_t ld, const int64_t* d_rows, int32_t n_rows,
+                    const int32_t* d_slots, int32_t n_slots, float* out, int64_t ldo, void* stream) {
+    if (!w) return fail(ICV_ERR_INVALID, "bad ward_gather arguments");
+    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (n_rows < 1 || n_slots < 1) return ICV_OK;
+    if (!d_local || !d_rows || !d_slots || !out || ldo < n_slots) return fail(ICV_ERR_INVALID, "bad ward_gather arguments");
+    hipLaunchKernelGGL(icv::k_ward_gather, dim3((unsigned)((n_slots + 255) / 256), (unsigned)n_rows), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_local, ld, d_rows, d_slots, n_slots,
+                       w->strip ? w->pos.slot_pos : nullptr, w->strip ? w->h.width : (int)w->n, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_ward_scatter(icv_ward_t w, float* d_local, int64_t ld, const float* v, int64_t ldv, const int32_t* h_vrow_p,
                      int32_t n_v, void* stream) {
-    if (!w || !d_local || ld < w->n || n_v < 0 || n_v > w->n) return fail(ICV_ERR_INVALID, "bad ward_scatter arguments");
+    if (!w || !d_local || n_v < 0 || n_v > w->n) return fail(ICV_ERR_INVALID, "bad ward_scatter arguments");
+    if (int rc = ward_check_ld(w, ld)) return rc;
     if (n_v == 0 || w->map.n_local < 1) return ICV_OK;
-    if (!v || !h_vrow_i || ldv < w->map.n_local) return fail(ICV_ERR_INVALID, "bad ward_scatter arguments");
+    if (!v || !h_vrow_p || ldv < w->map.n_local || n_v != w->h.n_pairs)
+        return fail(ICV_ERR_INVALID, "bad ward_scatter arguments (one row per merge of the round)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(w->vrow_i, h_vrow_i, (size_t)n_v * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(icv::k_ward_scatter, dim3((unsigned)((w->map.n_local + 255) / 256), (unsigned)n_v), dim3(256), 0,
-                       st, d_local, ld, v, ldv, w->vrow_i, w->cstate, w->map);
+    const int mb = w->merged_begin();
+    if (w->strip) {
+        std::vector<int> inv((size_t)n_v, -1);  // merge index -> row of v
+        for (int q = 0; q < n_v; ++q) {
+            if (h_vrow_p[q] < 0 || h_vrow_p[q] >= n_v || inv[(size_t)h_vrow_p[q]] >= 0)
+                return fail(ICV_ERR_INVALID, "ward_scatter: h_vrow_p must be a permutation of the round's merges");
+            inv[(size_t)h_vrow_p[q]] = q;
+        }
+        HIP_TRY(hipMemcpyAsync(w->vrow, inv.data(), (size_t)n_v * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // inv is a temporary
+        const dim3 grid((unsigned)((n_v + 63) / 64), (unsigned)((w->map.n_local + 63) / 64));
+        hipLaunchKernelGGL(icv::k_ward_scatter_s, grid, dim3(256), 0, st, d_local, ld, w->h.width_prev, v, ldv, w->vrow, n_v,
+                           w->cstate, w->map);
+    } else {
+        std::vector<int> slots((size_t)n_v);
+        std::vector<int> li((size_t)n_v);
+        HIP_TRY(hipMemcpyAsync(li.data(), w->log_i + mb, (size_t)n_v * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int q = 0; q < n_v; ++q) {
+            if (h_vrow_p[q] < 0 || h_vrow_p[q] >= n_v) return fail(ICV_ERR_INVALID, "ward_scatter: bad merge index");
+            slots[(size_t)q] = li[(size_t)h_vrow_p[q]];
+        }
+        HIP_TRY(hipMemcpyAsync(w->vrow, slots.data(), (size_t)n_v * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(icv::k_ward_scatter, dim3((unsigned)((w->map.n_local + 255) / 256), (unsigned)n_v), dim3(256), 0,
+                           st, d_local, ld, v, ldv, w->vrow, w->cstate, w->map);
+    }
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }
 
 int icv_ward_scan(icv_ward_t w, const float* d_local, int64_t ld, void* stream) {
-    if (!w || !d_local || ld < w->n) return fail(ICV_ERR_INVALID, "bad ward_scan arguments");
+    if (!w || !d_local) return fail(ICV_ERR_INVALID, "bad ward_scan arguments");
     return ward_scan(w, d_local, ld, static_cast<hipStream_t>(stream));
 }
 
@@ -1516,9 +1660,10 @@ int icv_ward_unpack_nn(icv_ward_t w, const int32_t* d_nn, const float* d_dmin, v
     return ICV_OK;
 }
 
-int icv_ward_pairs(icv_ward_t w, int32_t all_active, int32_t* h_counts, void* stream) {
-    if (!w || !h_counts) return fail(ICV_ERR_INVALID, "bad ward_pairs arguments");
-    if (int rc = ward_pairs(w, all_active != 0, static_cast<hipStream_t>(stream))) return rc;
+int icv_ward_pairs(icv_ward_t w, float* d_local, int64_t ld, int32_t all_active, int32_t* h_counts, void* stream) {
+    if (!w || !h_counts || (!d_local && w->map.n_local > 0)) return fail(ICV_ERR_INVALID, "bad ward_pairs arguments");
+    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (int rc = ward_pairs(w, d_local, ld, all_active != 0, static_cast<hipStream_t>(stream))) return rc;
     h_counts[0] = w->h.n_live;
     h_counts[1] = w->h.n_merges;
     h_counts[2] = w->h.n_pairs;

@@ -240,7 +240,9 @@ class WardLayout:
             self.supers_of.append(mine)
         self.k = [len(v) for v in self.supers_of]  # super-rows per rank
         self.sr_local = np.where(self.owner == self.rank, self.local_index, -1).astype(np.int32)
-        self.ld = (self.n + 3) // 4 * 4  # 16-byte row stride (vector loads in the Ward rounds)
+        # row stride: n / 2 spare columns (the Ward rounds then write their column updates as dense strips,
+        # include/infercnv_hip.h), a multiple of 4 floats (vector loads)
+        self.ld = (self.n + (self.n + 1) // 2 + 3) // 4 * 4
         self.rows_padded = self.k[self.rank] * self.S
         # first row of every rank's block in the mirror buffer (all ranks' local rows, concatenated)
         self.dest_row0 = np.concatenate([[0], np.cumsum([k * self.S for k in self.k])]).astype(np.int64)
@@ -358,8 +360,8 @@ class HipWardSteps:
         h = C.c_void_p()
         sr = np.ascontiguousarray(layout.sr_local, dtype=np.int32)
         assert layout.S == SUPER, "the HIP kernels own rows in super-rows of ICV_SUPER_ROWS"
-        _lib.check(self.lib.icv_ward_create(int(n), sr.ctypes.data, int(layout.n_super), SUPER_SHIFT, C.byref(h),
-                                            self._st()))
+        _lib.check(self.lib.icv_ward_create(int(n), sr.ctypes.data, int(layout.n_super), SUPER_SHIFT, int(layout.ld),
+                                            C.byref(h), self._st()))
         self.handle = h
 
     def _st(self):
@@ -391,12 +393,17 @@ class HipWardSteps:
                                                 ps.ctypes.data, 0, self._st()))
         self.torch.cuda.current_stream().synchronize()  # pslot is a host array
 
-    def scatter(self, d_local, v, vrow_i):
+    def gather(self, d_local, rows_t, slots_t, out):
+        """out[q][k] = entry of local row rows_t[q] for the cluster of slot slots_t[k] (device index tensors)."""
         p = self._engine._ptr
-        vi = np.ascontiguousarray(vrow_i, dtype=np.int32)
+        self._lib.check(self.lib.icv_ward_gather(self.handle, p(d_local), d_local.stride(0), p(rows_t), rows_t.numel(),
+                                                 p(slots_t), slots_t.numel(), p(out), out.stride(0), self._st()))
+
+    def scatter(self, d_local, v, vrow_p):
+        p = self._engine._ptr
+        vp = np.ascontiguousarray(vrow_p, dtype=np.int32)
         self._lib.check(self.lib.icv_ward_scatter(self.handle, p(d_local), d_local.stride(0), p(v), v.stride(0),
-                                                  vi.ctypes.data, len(vi), self._st()))
-        self.torch.cuda.current_stream().synchronize()
+                                                  vp.ctypes.data, len(vp), self._st()))
 
     def scan(self, d_local):
         if not self.layout.rows_padded:
@@ -413,9 +420,10 @@ class HipWardSteps:
     def unpack(self, nn, dm):
         self._lib.check(self.lib.icv_ward_unpack_nn(self.handle, self._engine._ptr(nn), self._engine._ptr(dm), self._st()))
 
-    def pairs(self, all_active):
+    def pairs(self, d_local, all_active):
         c = (self._C.c_int32 * 4)()
-        self._lib.check(self.lib.icv_ward_pairs(self.handle, int(bool(all_active)), c, self._st()))
+        self._lib.check(self.lib.icv_ward_pairs(self.handle, self._engine._ptr(d_local) if d_local.numel() else None,
+                                                d_local.stride(0), int(bool(all_active)), c, self._st()))
         return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
     def round_pairs(self, n_pairs):
@@ -465,8 +473,8 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
        directly into its rows, and transposed into a mirror buffer that one ``all_to_all`` (RCCL over xGMI)
        delivers to the owners of those rows: the off-diagonal blocks travel once;
     3. Ward rounds (``icv_ward_*``): the owner of a merged row receives the partner row (``all_to_all`` of rows),
-       computes the new row and its nearest neighbour, sends every rank its columns of the new rows (``all_to_all``)
-       for the column update of the rows that did not merge; rows whose cached nearest neighbour merged are searched
+       computes the new row and its nearest neighbour, sends every rank the new rows' entries for the clusters of
+       that rank's rows (``icv_ward_gather`` + ``all_to_all``) for the update of the rows that did not merge; rows whose cached nearest neighbour merged are searched
        again; one small all-reduce per round makes the (neighbour, distance) results of the round known to all
        ranks, which then find the reciprocal pairs redundantly (replicated O(n) bookkeeping, deterministic).
 
@@ -484,8 +492,7 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
     if len(bounds) == 1:
         from . import _engine
 
-        d2 = torch.empty((n, (n + 3) // 4 * 4), dtype=torch.float32, device=x_all.device)[:, :n]
-        _engine.pairwise_sqeuclidean(x_all, out=d2)
+        d2 = _engine.pairwise_sqeuclidean(x_all)
         Z, rounds = _engine.ward_linkage(d2)
         return (Z, rounds) if return_rounds else Z
     rank, ws = dist.get_rank(group), dist.get_world_size(group)
@@ -514,7 +521,7 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
         # ---- Ward rounds -------------------------------------------------------------------------------
         n_live, n_merges, n_pairs, n_act = n, 0, 0, n
         pi = pj = np.zeros(0, dtype=np.int64)
-        cols_of = [torch.from_numpy(L.columns_of(r)).to(dev) for r in range(ws)]
+        cols_of = [torch.from_numpy(L.columns_of(r).astype(np.int32)).to(dev) for r in range(ws)]  # slots
         retry = False
         while n_live > 1:
             if n_pairs > 0:
@@ -534,31 +541,38 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
                     base += len(sel)
                 ops.merge(d_local, stage, pslot)
                 del stage, sendbuf
-                # the new rows: every rank gets its columns of them (the sender's own share included)
+                # the new rows: every rank gets the entries for the clusters of ITS rows (the sender's own share
+                # included), gathered through the column layout of the rounds
                 mine = pi[oi == rank]
                 rows_t = torch.from_numpy(L.lrow(mine)).to(dev)
-                parts = [d_local[rows_t][:, cols_of[d]].reshape(-1, 1) if len(mine) else d_local[:0, :1]
-                         for d in range(ws)]
+                parts = []
+                for d in range(ws):
+                    out_d = torch.empty((len(mine), L.k[d] * L.S), dtype=torch.float32, device=dev)
+                    if len(mine) and L.k[d]:
+                        ops.gather(d_local, rows_t, cols_of[d], out_d)
+                    parts.append(out_d.reshape(-1, 1))
                 send_counts = [len(mine) * L.k[d] * L.S for d in range(ws)]
                 recv_counts = [int((oi == s).sum()) * L.rows_padded for s in range(ws)]
-                v = _all_to_all_rows(torch.cat(parts) if len(mine) else d_local[:0, :1].reshape(-1, 1),
-                                     send_counts, recv_counts, group)
-                vrow_i = np.concatenate([pi[oi == s] for s in range(ws)])
-                if len(vrow_i) and L.rows_padded:
-                    ops.scatter(d_local, v.view(len(vrow_i), L.rows_padded), vrow_i)
+                v = _all_to_all_rows(torch.cat(parts), send_counts, recv_counts, group)
+                vrow_p = np.concatenate([np.flatnonzero(oi == s) for s in range(ws)])  # merge index of every row of v
+                if L.rows_padded:
+                    ops.scatter(d_local, v.view(n_pairs, L.rows_padded), vrow_p)
                 del v, parts
             ops.scan(d_local)
             nn_t, dm_t = ops.pack(n_pairs + n_act, dev)
             _all_reduce_sum(nn_t, group)
             _all_reduce_sum(dm_t, group)
             ops.unpack(nn_t, dm_t)
-            n_live, n_merges, n_pairs, n_act = ops.pairs(retry)
+            n_live, n_merges, n_pairs, n_act = ops.pairs(d_local, False)
             if n_pairs < 1:
+                # cached neighbours of tied distances can point in a cycle: list every live row and search again once
                 if retry:
                     raise ValueError("ward_linkage: distances are not finite")
                 retry = True
+                n_live, n_merges, n_pairs, n_act = ops.pairs(d_local, True)
                 pi = pj = np.zeros(0, dtype=np.int64)
-                continue
+                if n_pairs < 1:
+                    continue
             retry = False
             pi, pj = ops.round_pairs(n_pairs)
         Z, rounds = ops.finish(n)

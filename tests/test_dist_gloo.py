@@ -245,12 +245,17 @@ class NumpyWardSteps:
             Dr[:] = new
             self.nn[i], self.dmin[i] = best_c, best
 
-    def scatter(self, d_local, v, vrow_i):
+    def gather(self, d_local, rows_t, slots_t, out):
+        # in-place column layout: the column of a cluster is its slot
+        out.copy_(d_local[rows_t][:, slots_t.long()])
+
+    def scatter(self, d_local, v, vrow_p):
         D, V = d_local.numpy(), v.numpy()
+        vrow_i = np.asarray([self.last[p][0] for p in vrow_p])  # slot of the merge every row of v belongs to
         for lr in range(self.L.rows_padded):
             c = int(self.L.supers_of[self.L.rank][lr // self.L.S]) * self.L.S + lr % self.L.S
             if c < self.n and self.cstate[c] == -1:
-                D[lr, np.asarray(vrow_i)] = V[:, lr]
+                D[lr, vrow_i] = V[:, lr]
 
     def scan(self, d_local):
         D = d_local.numpy()
@@ -279,7 +284,7 @@ class NumpyWardSteps:
         self.nn[rows] = nn.numpy()
         self.dmin[rows] = dm.numpy()
 
-    def pairs(self, all_active):
+    def pairs(self, d_local, all_active):
         self.size_old[:] = self.size_new
         self.cstate[:] = np.where(self.alive, -1, -2)
         live = np.flatnonzero(self.alive)

@@ -740,6 +740,27 @@ def test_distance_row_blocks_and_single_process_sharded_driver():
     np.testing.assert_array_equal(Z, cnv.tl.ward_linkage(X))
 
 
+@pytest.mark.parametrize("n,d", [(300, 20), (2500, 64), (6000, 48)])
+def test_ward_column_layouts_agree(n, d, monkeypatch):
+    """Spare-column ("strip") layout with its in-place compaction against the in-place layout: the same entries
+    are computed by the same arithmetic, so on data without tied distances the linkage is identical bit for bit.
+    Also the row stride n (no spare columns) through the default entry point."""
+    import torch
+    from infercnvpy_amd import _engine
+
+    X = _blobs(n, d, 9, seed=n + 1)
+    xd = torch.from_numpy(X).cuda()
+    Zs, rs = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd))  # default allocation: n / 2 spare columns
+    monkeypatch.setenv("ICV_WARD_IN_PLACE", "1")
+    Zi, ri = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd))
+    monkeypatch.delenv("ICV_WARD_IN_PLACE")
+    d2 = torch.empty((n, (n + 3) // 4 * 4), dtype=torch.float32, device="cuda")[:, :n]
+    Zn, rn = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, out=d2))
+    assert rs == ri == rn
+    np.testing.assert_array_equal(Zs, Zi)
+    np.testing.assert_array_equal(Zn, Zi)
+
+
 # --------------------------------------------------------------------------- #
 # randomized sweep over geometries / dtypes / formats / reference kinds, and the multi-slab driver
 # --------------------------------------------------------------------------- #
