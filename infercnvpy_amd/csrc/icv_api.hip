@@ -1335,13 +1335,13 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     w->mdesc = (int4*)take(arr * 4);  // n x 16 bytes: one packed descriptor per merge
     w->mpos = (int4*)take(arr * 4);
     w->pos.slot_pos = (int*)take(arr);
-    w->pos.oldpos = (int*)take(arr);
+    take(arr);
     w->qmask = (unsigned char*)take(parr);
     w->pos.pos_slot = (int*)take(parr);
     w->pos.palive = (unsigned char*)take(parr);
     w->pos.pstate = (int*)take(parr);
     w->pos.psize = (int*)take(parr);
-    w->pos.pnew = (int*)take(parr);
+    take(parr);
     w->pos.newpos = (int*)take(parr);
     w->counts = (icv::WardStripCounts*)take(256);
     if (sr_local) {
@@ -1382,13 +1382,16 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     return ICV_OK;
 }
 
-int ward_check_ld(const icv_ward_s* w, int64_t ld) {
-    return ld == w->ld ? ICV_OK : fail(ICV_ERR_INVALID, "ward: the row stride differs from the one given to icv_ward_create");
+int ward_check_ld(const icv_ward_s* w, int64_t ld, const void* D = nullptr) {
+    if (ld != w->ld) return fail(ICV_ERR_INVALID, "ward: the row stride differs from the one given to icv_ward_create");
+    if (w->strip && D && (reinterpret_cast<uintptr_t>(D) & 15))
+        return fail(ICV_ERR_INVALID, "ward: a matrix with spare columns must be 16-byte aligned");
+    return ICV_OK;
 }
 
 int ward_merge(icv_ward_s* w, float* D, int64_t ld, const float* stage, int64_t ld_stage, const int32_t* h_pslot,
                bool scatter, hipStream_t st) {
-    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (int rc = ward_check_ld(w, ld, D)) return rc;
     if (w->h.n_pairs < 1) return ICV_OK;
     const int mb = w->merged_begin();
     if (h_pslot) HIP_TRY(hipMemcpyAsync(w->pslot, h_pslot, (size_t)w->h.n_pairs * 4, hipMemcpyHostToDevice, st));
@@ -1398,10 +1401,10 @@ int ward_merge(icv_ward_s* w, float* D, int64_t ld, const float* stage, int64_t 
     if (w->strip) {
         if (w->dense(D, ld, w->h.width_prev) && stage_ok)
             hipLaunchKernelGGL(icv::k_ward_merge_s<true>, grid, block, 0, st, D, ld, w->h.width_prev, w->live, w->h.n_live,
-                               w->cstate, V, w->mpos + mb, w->pos, w->pair_d, w->size_new, w->map, w->nn, w->dmin);
+                               w->cstate, V, w->mpos + mb, w->h.n_pairs, w->pos, w->map, w->nn, w->dmin);
         else
             hipLaunchKernelGGL(icv::k_ward_merge_s<false>, grid, block, 0, st, D, ld, w->h.width_prev, w->live, w->h.n_live,
-                               w->cstate, V, w->mpos + mb, w->pos, w->pair_d, w->size_new, w->map, w->nn, w->dmin);
+                               w->cstate, V, w->mpos + mb, w->h.n_pairs, w->pos, w->map, w->nn, w->dmin);
         if (scatter && w->h.n_unmerged > 0) {  // one GPU: the strip update straight from the new rows
             const dim3 g2((unsigned)((w->h.n_pairs + 63) / 64), (unsigned)((w->h.n_unmerged + 63) / 64));
             hipLaunchKernelGGL(icv::k_ward_push, g2, block, 0, st, D, ld, w->h.width_prev, w->mdesc + mb, w->h.n_pairs,
@@ -1419,7 +1422,7 @@ int ward_merge(icv_ward_s* w, float* D, int64_t ld, const float* stage, int64_t 
 }
 
 int ward_scan(icv_ward_s* w, const float* D, int64_t ld, hipStream_t st) {
-    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (int rc = ward_check_ld(w, ld, D)) return rc;
     if (w->h.n_act < 1) return ICV_OK;
     const dim3 grid((unsigned)w->h.n_act), block(256);
     if (w->strip) {
@@ -1455,7 +1458,7 @@ int ward_read_counts(icv_ward_s* w, hipStream_t st) {
 
 // in-place compaction of the alive columns of the alive local rows (strip layout)
 int ward_compact(icv_ward_s* w, float* D, int64_t ld, hipStream_t st) {
-    if (int rc = ward_check_ld(w, ld)) return rc;
+    if (int rc = ward_check_ld(w, ld, D)) return rc;
     if (!w->strip) return ICV_OK;
     hipLaunchKernelGGL(icv::k_ward_compact_map, dim3(1), dim3(1024), 0, st, w->cap, w->pos, w->qmask, w->counts);
     if (w->h.n_live > 0 && w->map.n_local > 0)
@@ -1482,9 +1485,14 @@ int ward_pairs(icv_ward_s* w, float* D, int64_t ld, bool all_active, hipStream_t
     if (w->h.width > 2 * w->h.n_live && w->h.width > 4096)
         if (int rc = ward_compact(w, D, ld, st)) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(icv::k_ward_pairs_s, dim3(1), dim3(1024), 0, st, (int)w->n, w->cap, w->live, w->cstate, w->qmask,
+        const int span = std::max<int>((int)w->n, w->cap);
+        hipLaunchKernelGGL(icv::k_ward_prep_s, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, (int)w->n, w->cstate,
+                           w->size_old, w->size_new, w->alive, w->pos, w->counts);
+        hipLaunchKernelGGL(icv::k_ward_pairs_s, dim3(1), dim3(1024), 0, st, (int)w->n, w->cap, w->live, w->cstate,
                            w->mdesc, w->mpos, w->pair_d, w->size_old, w->size_new, w->alive, w->nn, w->dmin, w->log_i,
                            w->log_j, w->log_d, w->log_size, w->act, w->ulist, all_active ? 1 : 0, w->pos, w->counts);
+        hipLaunchKernelGGL(icv::k_ward_qmask_s, dim3((unsigned)(((w->cap + 3) / 4 + 255) / 256)), dim3(256), 0, st, w->cap,
+                           w->pos.palive, w->qmask);
         HIP_TRY(hipGetLastError());
         const int width_before = w->h.width;
         if (int rc = ward_read_counts(w, st)) return rc;

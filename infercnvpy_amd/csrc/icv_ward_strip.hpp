@@ -26,8 +26,6 @@ struct WardPos {
     unsigned char* palive;  // [cap] the position holds the column of an alive cluster
     int* pstate;            // [cap] view of the merge kernel: -2 dead, -1 alive and unchanged, >= 0 position of the absorbed partner
     int* psize;             // [cap] size before the round's merges of the cluster at the position
-    int* pnew;              // [cap] new position of a column whose cluster merged (kept slot)
-    int* oldpos;            // [n]   position a slot had before it merged in the last round
     int* newpos;            // [cap] compaction map (-1: dead)
 };
 
@@ -37,12 +35,11 @@ struct WardPos {
 template <bool DENSE>
 __global__ void __launch_bounds__(256) k_ward_merge_s(float* D, int64_t ld, int width_prev, const int* live, int n_live,
                                                       const int* cstate, const WardPairView V, const int4* mpos,
-                                                      const WardPos P, const float* pair_d, const int* size_new,
-                                                      const WardMap M, int* nn, float* dmin) {
+                                                      int n_pairs, const WardPos P, const WardMap M, int* nn,
+                                                      float* dmin) {
     const int4 m = V.mdesc[blockIdx.x];
     const int r = m.x;
     if (!M.mine(r)) return;
-    const int own_q = mpos[blockIdx.x].x;
     float* Dr = D + M.lrow(r) * ld;
     const int ps = V.pslot ? V.pslot[blockIdx.x] : -1;
     const float* Dj = ps >= 0 ? V.stage + (int64_t)ps * V.ld_stage : D + M.lrow(m.y) * ld;
@@ -60,32 +57,13 @@ __global__ void __launch_bounds__(256) k_ward_merge_s(float* D, int64_t ld, int 
             if (best_c < 0 || cc < best_c) best_c = cc;
         }
     };
-    // returns true if `out` (the in-place value at position q) changed
+    // columns whose cluster did not merge: in place (returns true if `out` changed)
     auto elem = [&](int q, int st, float a, float b, int sz, float& out) {
-        if (st == -2 || q == own_q) return false;
-        if (st == -1) {
-            const float v = ward_lw(a, b, pdr, so_r, so_j, sz);
-            out = v;
-            cand(v, q, -1);
-            return true;
-        }
-        // the column's cluster c merged in the same round (absorbed the cluster at position st): one canonical
-        // order, lower slot first, so that row c evaluates bit for bit the same value for its column r
-        const int ql = st, c = P.pos_slot[q], szl = P.psize[ql];
-        float v;
-        if (r < c) {
-            const float xk = ward_lw(a, b, pdr, so_r, so_j, sz);
-            const float xl = ward_lw(Dr[ql], Dj[ql], pdr, so_r, so_j, szl);
-            v = ward_lw(xk, xl, pair_d[c], sz, szl, sn_r);
-        } else {
-            const float ui = ward_lw(a, Dr[ql], pair_d[c], sz, szl, so_r);
-            const float uj = ward_lw(b, Dj[ql], pair_d[c], sz, szl, so_j);
-            v = ward_lw(ui, uj, pdr, so_r, so_j, size_new[c]);
-        }
-        const int qn = P.pnew[q];
-        Dr[qn] = v;
-        cand(v, qn, c);
-        return false;
+        if (st != -1) return false;  // dead, or merged in this round (second loop)
+        const float v = ward_lw(a, b, pdr, so_r, so_j, sz);
+        out = v;
+        cand(v, q, -1);
+        return true;
     };
     if (DENSE) {
         const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
@@ -110,11 +88,35 @@ __global__ void __launch_bounds__(256) k_ward_merge_s(float* D, int64_t ld, int 
     } else {
         for (int idx = threadIdx.x; idx < n_live; idx += 256) {
             const int c = live[idx];
-            if (c == r) continue;
-            const int q = cstate[c] >= 0 ? P.oldpos[c] : P.slot_pos[c];
+            if (c == r || cstate[c] != -1) continue;
+            const int q = P.slot_pos[c];
             float o = Dr[q];
-            if (elem(q, P.pstate[q], o, Dj[q], P.psize[q], o)) Dr[q] = o;
+            if (elem(q, -1, o, Dj[q], P.psize[q], o)) Dr[q] = o;
         }
+    }
+    // clusters that merged in the same round, from the round's merge list (old positions of both parts -> the new
+    // position, consecutive over the list): one canonical order, lower slot first, so that row c evaluates bit for
+    // bit the same value for its column r.  The first loop leaves these old positions untouched.
+    for (int p = threadIdx.x; p < n_pairs; p += 256) {
+        const int4 mc = V.mdesc[p];
+        const int c = mc.x;
+        if (c == r) continue;
+        const int4 mq = mpos[p];
+        const int q = mq.x, ql = mq.y, sz = mc.z, szl = mc.w;
+        const float pdc = V.mdist[p];
+        const float a = Dr[q], b = Dj[q], al = Dr[ql], bl = Dj[ql];
+        float v;
+        if (r < c) {
+            const float xk = ward_lw(a, b, pdr, so_r, so_j, sz);
+            const float xl = ward_lw(al, bl, pdr, so_r, so_j, szl);
+            v = ward_lw(xk, xl, pdc, sz, szl, sn_r);
+        } else {
+            const float ui = ward_lw(a, al, pdc, sz, szl, so_r);
+            const float uj = ward_lw(b, bl, pdc, sz, szl, so_j);
+            v = ward_lw(ui, uj, pdr, so_r, so_j, sz + szl);
+        }
+        Dr[mq.z] = v;
+        cand(v, mq.z, c);
     }
     ward_argmin_publish(best, best_c, r, nn, dmin);
 }
@@ -228,40 +230,81 @@ __global__ void __launch_bounds__(256) k_ward_scan_s(const float* D, int64_t ld,
     ward_argmin_publish(best, best_c, r, nn, dmin);
 }
 
-// Single workgroup (1024 threads): k_ward_pairs plus the column bookkeeping.  Nothing is committed (and
-// need_compact is set) if the round's new columns do not fit the spare region.
-__global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live, int* cstate, unsigned char* qmask,
-                                                       int4* mdesc, int4* mpos, float* pair_d, int* size_old,
-                                                       int* size_new, unsigned char* alive, const int* nn,
-                                                       const float* dmin, int* log_i, int* log_j, float* log_d,
-                                                       int* log_size, int* act, int* ulist, int all_active,
-                                                       const WardPos P, WardStripCounts* counts) {
-    __shared__ int s_scan[16];
-    __shared__ int s_base;
-    const int t = threadIdx.x;
+// Start of a round's bookkeeping, wide: sizes and states by slot, merge-kernel view by position.
+__global__ void __launch_bounds__(256) k_ward_prep_s(int n, int* cstate, int* size_old, const int* size_new,
+                                                     const unsigned char* alive, const WardPos P,
+                                                     const WardStripCounts* counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        size_old[i] = size_new[i];
+        cstate[i] = alive[i] ? -1 : -2;
+    }
+    if (i < counts->width) {
+        const int a = P.palive[i];
+        P.pstate[i] = a ? -1 : -2;
+        P.psize[i] = a ? size_new[P.pos_slot[i]] : 0;  // sizes before this round's merges
+    }
+}
+// bit i of qmask[q]: position 4q + i holds an alive column (after the round's merges)
+__global__ void __launch_bounds__(256) k_ward_qmask_s(int cap, const unsigned char* palive, unsigned char* qmask) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= (cap + 3) / 4) return;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * q + i < cap && palive[4 * q + i]) m |= 1u << i;
+    qmask[q] = (unsigned char)m;
+}
+
+// Single workgroup (1024 threads), after k_ward_prep_s: the reciprocal pairs of the round in slot order, their new
+// columns, the lists for the next round (rows to search again, rows that did not merge, live rows).  Nothing is
+// committed (and need_compact is set) if the round's new columns do not fit the spare region.
+__global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live, int* cstate, int4* mdesc, int4* mpos,
+                                                       float* pair_d, const int* size_old, int* size_new,
+                                                       unsigned char* alive, const int* nn, const float* dmin,
+                                                       int* log_i, int* log_j, float* log_d, int* log_size, int* act,
+                                                       int* ulist, int all_active, const WardPos P,
+                                                       WardStripCounts* counts) {
+    __shared__ int s_cnt[3][16];
+    __shared__ int s_base[3];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int n_live = counts->n_live;
     const int m0 = counts->n_merges;
     const int W = counts->width;
-    if (t == 0) s_base = 0;
+    if (t < 3) s_base[t] = 0;
     __syncthreads();
-    auto block_scan = [&](int flag) {
-        const unsigned long long b = __ballot(flag != 0);
-        const int lane = t & 63, wv = t >> 6;
-        const int within = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) s_scan[wv] = __popcll(b);
+    // exclusive prefixes of up to three 0/1 flags over the workgroup + running bases (ballot / popcount inside the
+    // wavefront, the 16 wavefront totals through LDS)
+    auto scan3 = [&](int f0, int f1, int f2, int& e0, int& e1, int& e2) {
+        const unsigned long long b0 = __ballot(f0 != 0), b1 = __ballot(f1 != 0), b2 = __ballot(f2 != 0);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (lane == 0) {
+            s_cnt[0][wv] = __popcll(b0);
+            s_cnt[1][wv] = __popcll(b1);
+            s_cnt[2][wv] = __popcll(b2);
+        }
         __syncthreads();
-        int before = 0, total = 0;
+        int bf0 = 0, bf1 = 0, bf2 = 0, t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
-            const int c = s_scan[w];
-            before += w < wv ? c : 0;
-            total += c;
+            const int c0 = s_cnt[0][w], c1 = s_cnt[1][w], c2 = s_cnt[2][w];
+            bf0 += w < wv ? c0 : 0;
+            bf1 += w < wv ? c1 : 0;
+            bf2 += w < wv ? c2 : 0;
+            t0 += c0;
+            t1 += c1;
+            t2 += c2;
         }
-        const int excl = s_base + before + within;
+        e0 = s_base[0] + bf0 + __popcll(b0 & lt);
+        e1 = s_base[1] + bf1 + __popcll(b1 & lt);
+        e2 = s_base[2] + bf2 + __popcll(b2 & lt);
         __syncthreads();
-        if (t == 0) s_base += total;
+        if (t == 0) {
+            s_base[0] += t0;
+            s_base[1] += t1;
+            s_base[2] += t2;
+        }
         __syncthreads();
-        return excl;
     };
     auto is_pair_at = [&](int idx, int& r, int& c) {
         r = -1;
@@ -273,11 +316,17 @@ __global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live
     };
 
     // pass 1: how many pairs?
-    for (int base = 0; base < n_live; base += 1024) {
+    int local = 0;
+    for (int idx = t; idx < n_live; idx += 1024) {
         int r, c;
-        block_scan(is_pair_at(base + t, r, c));
+        local += is_pair_at(idx, r, c);
     }
-    const int n_pairs = s_base;
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+    if (lane == 0) s_cnt[0][wv] = local;
+    __syncthreads();
+    int n_pairs = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) n_pairs += s_cnt[0][w];
     __syncthreads();
     if (W + n_pairs > cap) {
         if (t == 0) {
@@ -286,24 +335,14 @@ __global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live
         }
         return;
     }
-    if (t == 0) s_base = 0;
-    for (int c = t; c < n; c += 1024) {
-        size_old[c] = size_new[c];
-        cstate[c] = alive[c] ? -1 : -2;
-    }
-    __syncthreads();
-    for (int q = t; q < W; q += 1024) {
-        const int a = P.palive[q];
-        P.pstate[q] = a ? -1 : -2;
-        P.psize[q] = a ? size_old[P.pos_slot[q]] : 0;
-    }
-    __syncthreads();
     // pass 2: commit in slot order
+    int e0, e1, e2;
     for (int base = 0; base < n_live; base += 1024) {
         int r, c;
         const int ip = is_pair_at(base + t, r, c);
-        const int p = block_scan(ip);
+        scan3(ip, 0, 0, e0, e1, e2);
         if (ip) {
+            const int p = e0;
             const int sz = size_old[r] + size_old[c];
             const int qi = P.slot_pos[r], qj = P.slot_pos[c], qn = W + p;
             log_i[m0 + p] = r;
@@ -319,8 +358,6 @@ __global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live
             alive[c] = 0;
             P.pstate[qi] = qj;
             P.pstate[qj] = -2;
-            P.pnew[qi] = qn;
-            P.oldpos[r] = qi;
             P.slot_pos[r] = qn;
             P.pos_slot[qn] = r;
             P.palive[qi] = 0;
@@ -329,70 +366,35 @@ __global__ void __launch_bounds__(1024) k_ward_pairs_s(int n, int cap, int* live
         }
     }
     __syncthreads();
-    const int W2 = W + n_pairs;
-    for (int q = t; q < (cap + 3) / 4; q += 1024) {  // bit i: position 4q + i holds an alive column
-        unsigned m = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (4 * q + i < W2 && P.palive[4 * q + i]) m |= 1u << i;
-        qmask[q] = (unsigned char)m;
-    }
+    if (t < 3) s_base[t] = 0;
     __syncthreads();
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    // rows to search again
+    // pass 3: rows to search again | alive rows that did not merge | live-list compaction (in place: writes never
+    // pass the chunk being read)
     for (int base = 0; base < n_live; base += 1024) {
         const int idx = base + t;
-        int r = -1, a = 0;
+        int r = -1, fa = 0, fu = 0, fk = 0;
         if (idx < n_live) {
             r = live[idx];
-            a = cstate[r] == -1 && (all_active || cstate[nn[r]] != -1);
+            const int cs = cstate[r];
+            fu = cs == -1;
+            fa = fu && (all_active || cstate[nn[r]] != -1);
+            fk = alive[r];
         }
-        const int p = block_scan(a);
-        if (a) act[p] = r;
-    }
-    __syncthreads();
-    const int n_act = s_base;
-    __syncthreads();
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    // alive rows that did not merge (targets of the strip update)
-    for (int base = 0; base < n_live; base += 1024) {
-        const int idx = base + t;
-        int r = -1, a = 0;
-        if (idx < n_live) {
-            r = live[idx];
-            a = cstate[r] == -1;
-        }
-        const int p = block_scan(a);
-        if (a) ulist[p] = r;
-    }
-    __syncthreads();
-    const int n_u = s_base;
-    __syncthreads();
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    // live-list compaction in place
-    for (int base = 0; base < n_live; base += 1024) {
-        const int idx = base + t;
-        int r = -1, keep = 0;
-        if (idx < n_live) {
-            r = live[idx];
-            keep = alive[r];
-        }
-        const int p = block_scan(keep);
-        if (keep) live[p] = r;
+        scan3(fa, fu, fk, e0, e1, e2);
+        if (fa) act[e0] = r;
+        if (fu) ulist[e1] = r;
+        if (fk) live[e2] = r;
     }
     __syncthreads();
     if (t == 0) {
-        counts->n_live = s_base;
+        counts->n_live = s_base[2];
         counts->n_merges = m0 + n_pairs;
         counts->n_pairs = n_pairs;
-        counts->n_act = n_act;
+        counts->n_act = s_base[0];
         counts->width_prev = W;
-        counts->width = W2;
+        counts->width = W + n_pairs;
         counts->need_compact = 0;
-        counts->n_unmerged = n_u;
+        counts->n_unmerged = s_base[1];
     }
 }
 
@@ -410,12 +412,10 @@ __global__ void __launch_bounds__(256) k_ward_init_s(int n, int cap, const WardP
         P.palive[q] = q < n ? 1 : 0;
         P.pstate[q] = q < n ? -1 : -2;
         P.psize[q] = q < n ? 1 : 0;
-        P.pnew[q] = 0;
         P.newpos[q] = -1;
     }
     if (q < n) {
         P.slot_pos[q] = q;
-        P.oldpos[q] = q;
         ulist[q] = q;
     }
     if (q == 0) {
@@ -485,26 +485,40 @@ __global__ void __launch_bounds__(1024) k_ward_compact_map(int cap, const WardPo
     }
 }
 
-// Compaction, part 2: one workgroup per alive row (live[blockIdx.x]), in place, 1024 positions per step: all reads
-// of a step precede its writes, and a write never passes the positions still to be read (newpos[q] <= q).
+// Compaction, part 2: one workgroup per alive row (live[blockIdx.x]), in place, 4096 positions per step (16-byte
+// loads of the row and of the map): all reads of a step precede its writes, and a write never passes the positions
+// still to be read (newpos[q] <= q).  newpos is only valid below width_old.
 __global__ void __launch_bounds__(256) k_ward_compact_rows(float* D, int64_t ld, int width_old, const int* live,
                                                            const int* newpos, const WardMap M) {
     const int r = live[blockIdx.x];
     if (!M.mine(r)) return;
     float* Dr = D + M.lrow(r) * ld;
-    for (int base = 0; base < width_old; base += 1024) {
-        float v[4];
-        int np[4];
+    const float4* Dr4 = reinterpret_cast<const float4*>(Dr);
+    const int4* np4 = reinterpret_cast<const int4*>(newpos);
+    for (int base = 0; base < width_old; base += 4096) {
+        float4 v[4];
+        int4 np[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int q = base + k * 256 + threadIdx.x;
-            np[k] = q < width_old ? newpos[q] : -1;
-            v[k] = np[k] >= 0 ? Dr[q] : 0.0f;
+            const int q = base + 4 * (k * 256 + threadIdx.x);
+            np[k] = make_int4(-1, -1, -1, -1);
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < width_old) {  // ld and the map are padded to multiples of 4: the vector loads stay inside
+                np[k] = np4[q >> 2];
+                v[k] = Dr4[q >> 2];
+                if (q + 1 >= width_old) np[k].y = -1;
+                if (q + 2 >= width_old) np[k].z = -1;
+                if (q + 3 >= width_old) np[k].w = -1;
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (np[k] >= 0) Dr[np[k]] = v[k];
+        for (int k = 0; k < 4; ++k) {
+            if (np[k].x >= 0) Dr[np[k].x] = v[k].x;
+            if (np[k].y >= 0) Dr[np[k].y] = v[k].y;
+            if (np[k].z >= 0) Dr[np[k].z] = v[k].z;
+            if (np[k].w >= 0) Dr[np[k].w] = v[k].w;
+        }
     }
 }
 

@@ -67,6 +67,7 @@ def main():
             rec["scipy_ward_s"] = round(t2 - t1, 3)
         print(json.dumps(rec), flush=True)
         del d2, x
+        torch.cuda.empty_cache()  # the library allocates its temporaries with hipMalloc, outside torch's cache
 
 
 if __name__ == "__main__":

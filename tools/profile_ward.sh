@@ -19,6 +19,7 @@ def sel(prefix):
     v.sort()
     return v
 scan, merge, pairs = sel("k_ward_scan"), sel("k_ward_merge"), sel("k_ward_pairs")
+push, compact = sel("k_ward_push"), sel("k_ward_compact")
 with open("gpurun_out/ward_prof/rounds.txt", "w") as o:
     o.write("round: rows searched, us | rows merged, us | pairs kernel us\n")
     for i, (_, us, g) in enumerate(scan):
@@ -26,7 +27,9 @@ with open("gpurun_out/ward_prof/rounds.txt", "w") as o:
         pk = pairs[i][1] if i < len(pairs) else 0.0
         o.write(f"round {i:3d} scan {g:7d} {us:9.1f} | merge {m[2]:6d} {m[1]:9.1f} | pairs {pk:7.1f}\n")
     o.write(f"total scan {sum(u for _, u, _ in scan) / 1e3:.1f} ms, merge {sum(u for _, u, _ in merge) / 1e3:.1f} ms, "
-            f"pairs {sum(u for _, u, _ in pairs) / 1e3:.1f} ms over {len(scan)} rounds\n")
+            f"pairs {sum(u for _, u, _ in pairs) / 1e3:.1f} ms, strip push {sum(u for _, u, _ in push) / 1e3:.1f} ms "
+            f"({len(push)} launches), compaction {sum(u for _, u, _ in compact) / 1e3:.1f} ms ({len(compact)} launches) "
+            f"over {len(scan)} rounds\n")
 print(open("gpurun_out/ward_prof/rounds.txt").read()[:6000])
 s = glob.glob("gpurun_out/ward_prof/**/ward_kernel_stats.csv", recursive=True)[0]
 print(open(s).read()[:1500])
