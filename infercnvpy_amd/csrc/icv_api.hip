@@ -1309,7 +1309,8 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
     const size_t parr = ((size_t)w->cap * 4 + 255) / 256 * 256;  // arrays indexed by column position
     const size_t map_bytes = sr_local ? ((size_t)n_super * 8 + 255) / 256 * 256 : 0;
-    HIP_TRY(hipMalloc((void**)&w->buf, arr * 28 + parr * 7 + 512 + map_bytes));
+    // 16 slot-indexed arrays + 2 x 4 (merge descriptors) + slot_pos; 6 position-indexed arrays; counters; storage map
+    HIP_TRY(hipMalloc((void**)&w->buf, arr * 25 + parr * 6 + 512 + map_bytes));
     char* b = w->buf;
     auto take = [&](size_t bytes) {
         char* p = b;
@@ -1335,13 +1336,11 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     w->mdesc = (int4*)take(arr * 4);  // n x 16 bytes: one packed descriptor per merge
     w->mpos = (int4*)take(arr * 4);
     w->pos.slot_pos = (int*)take(arr);
-    take(arr);
     w->qmask = (unsigned char*)take(parr);
     w->pos.pos_slot = (int*)take(parr);
     w->pos.palive = (unsigned char*)take(parr);
     w->pos.pstate = (int*)take(parr);
     w->pos.psize = (int*)take(parr);
-    take(parr);
     w->pos.newpos = (int*)take(parr);
     w->counts = (icv::WardStripCounts*)take(256);
     if (sr_local) {
