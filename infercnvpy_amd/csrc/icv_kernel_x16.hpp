@@ -101,6 +101,9 @@ __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_sca
 #ifndef ICV_X_LFIRST
 #define ICV_X_LFIRST 0  // 1: odd wavefronts run L before W in phase B (LDS-write-bound next to float64-bound work)
 #endif
+#ifndef ICV_X_ROW_AUX
+#define ICV_X_ROW_AUX 2  // cache policy of the row loads: nt (the row is read once, by one CU): -3 % kernel time in alternating runs
+#endif
 #ifndef ICV_X_ADDR
 #define ICV_X_ADDR 1  // 1: LDS byte addresses of the scatter resident (20 VGPRs) instead of the packed table (10)
 #endif
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
 #pragma unroll
-        for (int u = 0; u < XU; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, 0);
+        for (int u = 0; u < XU; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);
     }
     unsigned two = 2u;
     asm volatile("" : "+v"(two));  // a VGPR operand for the SDWA shifts
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             }
 #endif
 #ifndef ICV_X_EXP_NOLOAD
-            xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, 0);  // out of range: zeros, no traffic
+            xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);  // out of range: zeros, no traffic
 #else
             asm volatile("" : "+v"(xq[u]));
 #endif
@@ -338,7 +341,13 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             float* orow = P.out + (cell - 3 * (int64_t)gridDim.x) * P.ldo;
             const float4 q = *reinterpret_cast<const float4*>(stage + 4 * ts);
             if (4 * ts + 4 <= W) {
-                *reinterpret_cast<float4*>(orow + 4 * ts) = q;
+                {
+                    // non-temporal: x_res is written once and never read by this kernel; measured -2 % kernel time in
+                    // alternating runs against a plain store (the stores cost clock)
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t qq = {q.x, q.y, q.z, q.w};
+                    __builtin_nontemporal_store(qq, reinterpret_cast<f32x4_t*>(orow + 4 * ts));
+                }
             } else {
                 orow[4 * ts] = q.x;
                 if (4 * ts + 1 < W) orow[4 * ts + 1] = q.y;
