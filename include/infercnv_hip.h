@@ -255,7 +255,8 @@ int icv_pairwise_sqeuclidean_tiles(const float *x, int64_t n, int32_t d, int64_t
  * (ld >= n + (n + 1) / 2, ld % 4 == 0) a merged cluster keeps its row but moves to a NEW column: the clusters
  * merged in a round take consecutive columns of the spare region, so that the update of every other row is one
  * contiguous strip instead of one 4-byte write per 128-byte line; the alive columns are compacted in place when
- * the region is full.  Smaller strides use the columns in place.  Results are identical either way, bit for bit.
+ * the region is full (such a matrix must be 16-byte aligned).  Smaller strides use the columns in place.  Results
+ * are identical either way, bit for bit.
  *
  * Step-wise Ward rounds on a row-sharded matrix.  Every rank creates the same state (the bookkeeping is replicated
  * and deterministic); h_sr_local[g] = local super-row index of global super-row g on THIS rank (0 .. k-1) or -1
