@@ -315,7 +315,7 @@ def main():
         kernel_name = "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    # HBM bytes from the PMC counters are collected by tools/gpu_profile.sh (separate rocprofv3 --pmc passes) for
+    # HBM bytes from the PMC counters are collected by tools/r02_round_end.sh (separate rocprofv3 --pmc passes) for
     # the default workload and committed; they scale with the cells of a launch.  Other workloads: no counter data.
     if os.path.exists(pmc_path) and x16:
         try:
