@@ -221,7 +221,7 @@ class WardLayout:
     pairing a long row with a short one gives every rank the same number of tiles to compute (to within one row
     of super-tiles) and the same number of matrix rows to hold."""
 
-    def __init__(self, n: int, world_size: int, rank: int, super_rows: int = SUPER):
+    def __init__(self, n: int, world_size: int, rank: int, super_rows: int = SUPER, spare: bool = True):
         # super_rows: 1024 for the HIP kernels (ICV_SUPER_ROWS); the CPU tests of the exchanges use small ones
         assert super_rows >= 8 and super_rows & (super_rows - 1) == 0
         self.n, self.world, self.rank = int(n), int(world_size), int(rank)
@@ -240,9 +240,10 @@ class WardLayout:
             self.supers_of.append(mine)
         self.k = [len(v) for v in self.supers_of]  # super-rows per rank
         self.sr_local = np.where(self.owner == self.rank, self.local_index, -1).astype(np.int32)
-        # row stride: n / 2 spare columns (the Ward rounds then write their column updates as dense strips,
-        # include/infercnv_hip.h), a multiple of 4 floats (vector loads)
-        self.ld = (self.n + (self.n + 1) // 2 + 3) // 4 * 4
+        # row stride: a multiple of 4 floats (vector loads) and, when `spare`, n / 2 spare columns (the Ward rounds
+        # then write their column updates as dense strips, include/infercnv_hip.h).  Every rank must use the same
+        # stride: the column layout is part of the replicated bookkeeping.
+        self.ld = ((self.n + (self.n + 1) // 2 if spare else self.n) + 3) // 4 * 4
         self.rows_padded = self.k[self.rank] * self.S
         # first row of every rank's block in the mirror buffer (all ranks' local rows, concatenated)
         self.dest_row0 = np.concatenate([[0], np.cumsum([k * self.S for k in self.k])]).astype(np.int64)
@@ -496,7 +497,23 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
         Z, rounds = _engine.ward_linkage(d2)
         return (Z, rounds) if return_rounds else Z
     rank, ws = dist.get_rank(group), dist.get_world_size(group)
-    L = WardLayout(n, ws, rank, super_rows)
+    # spare columns for the Ward rounds only if the distance phase (local rows + mirror buffer + received blocks)
+    # still fits on EVERY rank: one all-reduce(MIN) of the local verdict
+    L = WardLayout(n, ws, rank, super_rows, spare=True)
+    fits = 1
+    if x_all.is_cuda:
+        free_b, _ = torch.cuda.mem_get_info()
+        need = 4 * (L.rows_padded * L.ld + 2 * int(L.dest_row0[-1]) * L.rows_padded) + (2 << 30)
+        fits = 1 if need < free_b else 0
+    flag = torch.tensor([fits], dtype=torch.int32, device=x_all.device)
+    if _host_staged(flag, group):
+        h = flag.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+        flag.copy_(h)
+    else:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        L = WardLayout(n, ws, rank, super_rows, spare=False)
     ops = (steps or HipWardSteps)(n, L)
     dev = x_all.device
     try:

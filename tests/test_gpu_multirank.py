@@ -114,7 +114,9 @@ def test_two_ranks_match_single_gpu():
         np.testing.assert_array_equal(results[r][3], Z1)
 
 
-def _ward_one_gpu_worker(rank, world, port, n, d, q):
+def _ward_one_gpu_worker(rank, world, port, n, d, in_place, q):
+    if in_place:
+        os.environ["ICV_WARD_IN_PLACE"] = "1"  # the column layout without spare columns, on every rank
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -142,10 +144,12 @@ def _ward_points(n, d):
     return (rng.standard_normal((n, d)) * 0.4 + rng.standard_normal((7, d))[rng.randint(0, 7, n)]).astype(np.float32)
 
 
-@pytest.mark.parametrize("world,n,d", [(2, 2500, 64), (3, 5300, 40), (2, 700, 16)])
-def test_sharded_ward_two_processes_one_gpu(world, n, d):
+@pytest.mark.parametrize("world,n,d,in_place", [(2, 2500, 64, False), (3, 5300, 40, False), (2, 700, 16, False),
+                                                  (2, 2500, 64, True)])
+def test_sharded_ward_two_processes_one_gpu(world, n, d, in_place):
     """Sharded tiles + sharded rounds equal the one-GPU linkage bit for bit (n = 700: one super-row, the second
-    rank holds nothing; n = 5300: six super-rows over three ranks, the last one partial)."""
+    rank holds nothing; n = 5300: six super-rows over three ranks, the last one partial; in_place: the step kernels
+    of the layout without spare columns)."""
     import torch.multiprocessing as mp
 
     from infercnvpy_amd.tl import ward_linkage
@@ -153,7 +157,7 @@ def test_sharded_ward_two_processes_one_gpu(world, n, d):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ward_one_gpu_worker, args=(r, world, port, n, d, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ward_one_gpu_worker, args=(r, world, port, n, d, in_place, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
