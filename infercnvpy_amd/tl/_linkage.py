@@ -18,7 +18,9 @@ from .. import _engine
 def ward_linkage(X, *, return_rounds: bool = False):
     """Ward linkage (scipy format, ``(n - 1) x 4`` float64) of the rows of ``X`` (dense or sparse host matrix).
 
-    Needs ``4 n^2`` bytes of HBM for the distance matrix (200 000 cells: 160 GB of the 288 GB).
+    The distance matrix lives in HBM: ``6 n^2`` bytes with the spare columns the Ward rounds like (200 000 cells:
+    240 GB of the 288 GB; Ward 0.53 s), ``4 n^2`` without them when memory is short (160 GB; Ward 0.97 s).  For
+    more cells than one GPU holds: ``infercnvpy_amd.dist.ward_linkage_sharded``.
     """
     torch = _engine._torch()
     if sp.issparse(X):
