@@ -185,7 +185,9 @@ def _free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    # default: 300 steps = 1 s of timed GPU work (a 20-step region is 65 ms: too short for an outside sampler to see,
+    # and short enough to sit inside the boost window of the clocks)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cells", type=int, default=None, help="total cells (default: 100 000 at N=1, 1 000 000 at N>1)")
     ap.add_argument("--window", type=int, default=100)
