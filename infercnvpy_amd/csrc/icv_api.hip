@@ -1481,8 +1481,16 @@ int ward_pairs(icv_ward_s* w, float* D, int64_t ld, bool all_active, hipStream_t
         ++w->rounds;
         return ward_read_counts(w, st);
     }
-    if (w->h.width > 2 * w->h.n_live && w->h.width > 4096)
-        if (int rc = ward_compact(w, D, ld, st)) return rc;
+    {
+        // developer knob: compaction threshold (positions per alive column), default 2
+        static const double thr = [] {
+            const char* e = std::getenv("ICV_WARD_COMPACT_X");
+            const double v = e ? std::atof(e) : 2.0;
+            return v >= 1.05 ? v : 2.0;
+        }();
+        if ((double)w->h.width > thr * (double)w->h.n_live && w->h.width > 4096)
+            if (int rc = ward_compact(w, D, ld, st)) return rc;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int span = std::max<int>((int)w->n, w->cap);
         hipLaunchKernelGGL(icv::k_ward_prep_s, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st, (int)w->n, w->cstate,
