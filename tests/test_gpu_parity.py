@@ -761,6 +761,25 @@ def test_ward_column_layouts_agree(n, d, monkeypatch):
     np.testing.assert_array_equal(Zn, Zi)
 
 
+def test_ward_linkage_properties_at_20000_cells():
+    """Size-independent properties where scipy would take minutes: a valid scipy linkage (monotone heights, sizes,
+    every cluster id used once), the root holds all cells, and two runs agree bit for bit (deterministic rounds,
+    compactions included)."""
+    import infercnvpy_amd as cnv
+    from scipy.cluster.hierarchy import is_valid_linkage
+
+    n = 20000
+    X = _blobs(n, 48, 25, seed=77)
+    Z, rounds = cnv.tl.ward_linkage(X, return_rounds=True)
+    assert Z.shape == (n - 1, 4) and is_valid_linkage(Z)
+    assert np.all(np.diff(Z[:, 2]) >= 0) and Z[-1, 3] == n
+    ids = np.concatenate([Z[:, 0], Z[:, 1]]).astype(np.int64)
+    assert np.array_equal(np.sort(ids), np.arange(2 * n - 2))
+    assert 10 < rounds < 200
+    Z2 = cnv.tl.ward_linkage(X)
+    np.testing.assert_array_equal(Z, Z2)
+
+
 # --------------------------------------------------------------------------- #
 # randomized sweep over geometries / dtypes / formats / reference kinds, and the multi-slab driver
 # --------------------------------------------------------------------------- #
