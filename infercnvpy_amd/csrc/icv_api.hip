@@ -70,6 +70,7 @@ struct icv_plan_s {
     int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
     uint32_t* d_x16_wdesc = nullptr;
+    int32_t *d_w_srel = nullptr, *d_blk_g0 = nullptr;  // k_smooth_ws prefix-sum form
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
     // Gene sets whose padded row does not fit LDS (float32: > ~40 000 genes, float64: > ~20 000): the
@@ -151,6 +152,8 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
+    HIP_TRY(up(p.w_srel.data(), p.w_srel.size() * 4, (void**)&pl->d_w_srel));
+    HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;  // >= Gp + 1: the trash slot reads 0
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
     pl->device = dev;
@@ -269,6 +272,8 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.pad_idx = pl->d_pad;
     K.w_pack = pl->d_wpack;
     K.x16_wdesc = pl->d_x16_wdesc;
+    K.w_srel = pl->d_w_srel;
+    K.blk_g0 = pl->d_blk_g0;
     K.x16_half = p.x16_half;
     K.n_pad = (int32_t)p.pad_idx.size();
     K.pyr_den = p.pyr_den;
@@ -364,7 +369,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, false> : icv::k_smooth_ws<U, 8, 4, 0, 0, false>;
         } else {
             if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
-            else if (p.B == 5 && p.window == 250) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
+            else if (p.B == 5 && p.window == 250 && p.ws_prefix) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
             // zero row + prepared entries {LDS position, centred and clipped value}
             const int nz = (int)pl->zrow_elems;
@@ -674,6 +679,8 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_x16_wdesc);
+        (void)hipFree(pl->d_w_srel);
+        (void)hipFree(pl->d_blk_g0);
         (void)hipFree(pl->d_zrow);
     }
     delete pl;

@@ -393,20 +393,39 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
         # default (k_smooth_x16 where the geometry admits it, else k_smooth_ws), k_smooth_ws forced,
         # prepared-entry CSR, generic CSR
-        for env, mat in (([], dm), (["ICV_NO_X16"], dm), ([], dm_csr), (["ICV_FORCE_GENERIC"], dm_csr)):
+        # long windows (more than 10 blocks) on prepared CSR input: k_smooth_ws forms the windows from prefix sums of
+        # the block sums -- another float64 evaluation order, equal to the canonical one to ~1e-12 (float32 x_res:
+        # last-bit differences in a few entries per 100 000)
+        pfx = window == 250 and step == 10
+        for env, mat, exact in (([], dm, True), (["ICV_NO_X16"], dm, True), ([], dm_csr, not pfx),
+                                (["ICV_FORCE_GENERIC"], dm_csr, True)):
+            def same(a, b, what):
+                a, b = torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)
+                if exact:
+                    assert torch.equal(a, b), (env, what)
+                else:
+                    torch.testing.assert_close(a.double(), b.double(), rtol=0, atol=2.5e-7 if what == "out" else 1e-11)
+                    if what == "out":
+                        assert (a != b).double().mean().item() < 1e-3, env
+
+            tol = 1e-12 if exact else 1e-9
             fast = run(plan, mat, ref, env)
-            for a, b in ((fast.out, gen.out), (fast.cell_median, gen.cell_median)):
-                assert torch.equal(torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)), env
+            same(fast.out, gen.out, "out")
+            same(fast.cell_median, gen.cell_median, "median")
             for a, b in ((fast.cell_stats, gen.cell_stats), (fast.thr, gen.thr)):
-                torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12, equal_nan=True)
+                torch.testing.assert_close(a, b, rtol=tol, atol=tol, equal_nan=True)
             assert torch.isnan(fast.out[6]).all() and not torch.isnan(fast.out[:6]).any()
             assert (fast.out[5] == 0).all()
             # without per-cell moments the thresholds come from per-chunk partial sums (formed inside
             # k_smooth_x16 where it runs): same thresholds to rounding, same output
             lean = run(plan, mat, ref, env, stats=False)
             assert lean.cell_stats is None
-            torch.testing.assert_close(lean.thr, gen.thr, rtol=1e-12, atol=1e-12, equal_nan=True)
-            assert torch.equal(torch.nan_to_num(lean.out, nan=123.0), torch.nan_to_num(gen.out, nan=123.0)), env
+            torch.testing.assert_close(lean.thr, gen.thr, rtol=tol, atol=tol, equal_nan=True)
+            d = torch.nan_to_num(lean.out, nan=123.0) != torch.nan_to_num(gen.out, nan=123.0)
+            if exact:
+                assert not d.any(), env
+            else:  # thresholded: an entry within ~1e-12 of the threshold may fall on the other side
+                assert d.double().mean().item() < 1e-3, env
 
 
 @pytest.mark.parametrize("fmt", ["dense", "csr"])
