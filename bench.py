@@ -312,7 +312,8 @@ def main():
     elif args.format == "dense" and args.window == 250 and args.step == 10:
         kernel_name = "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
     elif args.format == "csr":
-        kernel_name = "k_smooth_ws<..., CSR> after k_csr_prepare (prepared-entry CSR variant for this window)"
+        kernel_name = ("k_smooth_ws<..., CSR> after k_csr_prepare (prepared entries; window 250 / step 10: windows from "
+                       "prefix sums of the block sums)")
     else:
         kernel_name = "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
     traffic = None
