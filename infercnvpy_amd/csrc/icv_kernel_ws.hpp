@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     sc->psq[tl >> 6] = y1;
                 }
             }
+            ICV_PHASE(6)
             __syncthreads();  // B3a: wavefront totals published
             if (more) {
                 const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
@@ -618,6 +619,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
                     }
                 }
             }
+            ICV_PHASE(7)
             __syncthreads();  // B3b: prefix sums complete
             asm volatile("" : "+v"(tl));
         }
@@ -811,7 +813,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
     }
 #ifdef ICV_WS_PROFILE
     if (P.dbg && t == 64)
-        for (int i = 0; i < 6; ++i) atomicAdd(P.dbg + i, tacc[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(P.dbg + i, tacc[i]);
 #endif
 #undef ICV_PHASE
 }
