@@ -19,6 +19,7 @@
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
 #include "icv_kernel_x16.hpp"
+#include "icv_kernel_sd.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -320,6 +321,16 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
             return ICV_OK;
         }
         (void)hipFree(d);
+        if (lds == icv::kSdLds) {  // k_smooth_sd (-DICV_SD_PROFILE): work of phase 0..4, each followed by its barrier wait
+            std::fprintf(stderr, "[icv sd profile] grid=%lld rows=%lld cycles per cell (thread 64):", (long long)grid,
+                         (long long)K.n_rows);
+            // ph1 = locate + entries, ph2 = gather + scan, ph4 = stores + windows + moments
+            const char* nm[14] = {"ph0", "A", "entries", "B1", "scan", "B2", "ph3", "B3", "moments", "B4",
+                                  "locate", "gather", "stores", "windows"};
+            for (int i = 0; i < 14; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)h[i] / (double)K.n_rows);
+            std::fprintf(stderr, "\n");
+            return ICV_OK;
+        }
         const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
                                 "M1 pivot search"};
         double tot = 0;
@@ -348,6 +359,23 @@ bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K
            ((p.B == 10 && p.window == 100 && p.x16_fine == 4096) || (p.B == 5 && p.window == 250 && p.x16_fine == 1024));
 }
 
+// CSR input with long windows: fraction bits of the fixed-point bins of k_smooth_sd, or -1 when the kernel does not
+// apply.  A bin holds at most B entries: |S0| <= B * 2 cap * 2^k and |S1| <= B (B - 1) / 2 * 2 cap * 2^k must stay
+// below 2^62; fewer than 46 fraction bits (a clip value beyond ~1e3) would no longer be negligible next to the
+// float64 rounding of the windows.
+int sd_fraction_bits(const icv::Plan& p, double cap) {
+    if (!(p.window % 2 == 0 && p.B > 1 && p.window / p.B > 10 && p.NB <= 4096 && p.W <= 4 * icv::NT)) return -1;
+    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the dense-row CSR kernel (k_smooth_ws)
+    const double per_bin = (double)p.B * (double)(p.B > 3 ? p.B - 1 : 2) * cap + 1.0;
+    int e = 0;
+    (void)std::frexp(per_bin, &e);  // per_bin < 2^e
+    int k = 62 - e;
+    // one entry: |d| * 2^k <= 2 cap * 2^k must stay below 2^51 (the kernel rounds with the 1.5 * 2^52 addition)
+    (void)std::frexp(2.0 * cap + 1.0, &e);
+    if (k > 51 - e) k = 51 - e;
+    return k >= 46 ? k : -1;
+}
+
 // float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
 // kernel_done (optional): recorded right after the smoothing kernel itself, before the moment finish / hand-back
 // launches, so that profiling reports the dominant kernel's own duration
@@ -358,8 +386,9 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     void (*kern)(const icv::KParams) = nullptr;
     constexpr int U = icv::kFastUMax;
     K.scratch_off = p.fast_scratch_off;
-    AsyncBuf ws_guard;  // prepared CSR entries: released on every exit path
+    AsyncBuf ws_guard, base_guard;  // prepared CSR entries, zero-row window sums: released on every exit path
     void* ws_buf = nullptr;
+    int lds = p.fast_lds;
     if (!p.ws_ok) return -1;  // caller falls back to the generic kernel
     {
         const bool u10 = (p.B == 10 && p.window == 100);
@@ -368,25 +397,43 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             else if (p.B == 5 && p.window == 250) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, false>;
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, false> : icv::k_smooth_ws<U, 8, 4, 0, 0, false>;
         } else {
-            if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
-            else if (p.B == 5 && p.window == 250 && p.ws_prefix) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
-            else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
-            // zero row + prepared entries {LDS position, centred and clipped value}
+            const int sd_k = sd_fraction_bits(p, K.cap);
             const int nz = (int)pl->zrow_elems;
             hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
                                static_cast<float*>(pl->d_zrow), nz);
             const int64_t n = csr_end - csr_begin;
-            HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));
-            ws_buf = ws_guard.p;
-            float* cv = static_cast<float*>(ws_buf);
-            uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
-            K.cvals = cv - csr_begin;  // indexed by the absolute entry number
-            K.pos16 = ps - csr_begin;
-            if (n > 0) {
-                int64_t g = (n + 255) / 256;
-                if (g > 8192) g = 8192;
-                hipLaunchKernelGGL(icv::k_csr_prepare, dim3((unsigned)g), dim3(256), 0, st, K, csr_begin, csr_end,
-                                   const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
+            int64_t g = (n + 255) / 256;
+            if (g > 8192) g = 8192;
+            if (sd_k >= 0) {
+                // long windows: the stored entries as they are, differences to the zero row in block bins (k_smooth_sd)
+                kern = icv::k_smooth_sd<4>;
+                lds = icv::kSdLds;
+                HIP_TRY(ws_guard.alloc((size_t)K.n_cols * 16, st));  // per-column table
+                HIP_TRY(base_guard.alloc((size_t)p.W * sizeof(double), st));
+                ws_buf = ws_guard.p;
+                K.sd_tab = ws_buf;
+                K.sd_base = base_guard.as<double>();
+                K.sd_scale = std::ldexp(1.0, sd_k);
+                K.sd_qinv = std::ldexp(1.0, -sd_k);
+                K.sd_window = p.window;
+                hipLaunchKernelGGL(icv::k_sd_table, dim3((unsigned)((K.n_cols + 255) / 256)), dim3(256), 0, st, K,
+                                   static_cast<icv::u32x4*>(ws_buf));
+                hipLaunchKernelGGL(icv::k_sd_base, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, st, K,
+                                   static_cast<const float*>(pl->d_zrow), base_guard.as<double>());
+            } else {
+                if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
+                else if (p.B == 5 && p.window == 250 && p.ws_prefix) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
+                else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
+                // prepared entries {LDS position, centred and clipped value} on top of the zero row
+                HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));
+                ws_buf = ws_guard.p;
+                float* cv = static_cast<float*>(ws_buf);
+                uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
+                K.cvals = cv - csr_begin;  // indexed by the absolute entry number
+                K.pos16 = ps - csr_begin;
+                if (n > 0)
+                    hipLaunchKernelGGL(icv::k_csr_prepare, dim3((unsigned)g), dim3(256), 0, st, K, csr_begin, csr_end,
+                                       const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
             }
         }
         K.hist_off = p.ws_hist_off;
@@ -410,7 +457,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         K.row_list = pl->d_row_list;
         K.row_count = pl->d_row_count;
     }
-    int per_cu = icv::kLdsLimit / p.fast_lds;
+    int per_cu = icv::kLdsLimit / lds;
     if (per_cu > 4) per_cu = 4;
     if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
         const int v = std::atoi(e);
@@ -448,7 +495,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             hipLaunchKernelGGL(icv::k_stats_finish_n, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
                                K.cell_part, K.n_rows, icv::XWAVE, K.cell_stats);
     } else {
-        rc = run_kernel(kern, grid, p.fast_lds, K, st);
+        rc = run_kernel(kern, grid, lds, K, st);
         if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
         if (rc) return rc;
         // per-wavefront partial moments -> cell_stats (cells handed back are overwritten by k_smooth below)

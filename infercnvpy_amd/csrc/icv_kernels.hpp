@@ -93,6 +93,12 @@ struct KParams {
     // gene offset of its first gene inside its chromosome
     const int32_t* w_srel;
     const int32_t* blk_g0;
+    // k_smooth_sd (CSR, long windows): per input column {block | offset inside the block << 16, ref_lo, ref_hi,
+    // clip(0 - ref)} (k_sd_table); per window the sum of the zero row (k_sd_base); fixed-point scale of the bins
+    const void* sd_tab;
+    const double* sd_base;
+    double sd_scale, sd_qinv;  // 2^k and 2^-k
+    int32_t sd_window, _pad5;
 };
 
 struct Scratch {
