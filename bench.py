@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -311,9 +312,12 @@ def main():
         kernel_name = "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10)"
     elif args.format == "dense" and args.window == 250 and args.step == 10:
         kernel_name = "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
+    elif (args.format == "csr" and args.window % 2 == 0
+          and args.window // math.gcd(args.step, args.window // 2) > 10):  # long windows (icv_api.hip: sd_fraction_bits)
+        kernel_name = ("k_sd_table + k_sd_base + k_smooth_sd (CSR, long windows: stored entries only, differences to "
+                       "the zero row in fixed-point block bins)")
     elif args.format == "csr":
-        kernel_name = ("k_smooth_ws<..., CSR> after k_csr_prepare (prepared entries; window 250 / step 10: windows from "
-                       "prefix sums of the block sums)")
+        kernel_name = "k_csr_prepare + k_smooth_ws<..., CSR> (prepared entries on a zero row in LDS)"
     else:
         kernel_name = "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
     traffic = None

@@ -365,7 +365,7 @@ bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K
 // float64 rounding of the windows.
 int sd_fraction_bits(const icv::Plan& p, double cap) {
     if (!(p.window % 2 == 0 && p.B > 1 && p.window / p.B > 10 && p.NB <= 4096 && p.W <= 4 * icv::NT)) return -1;
-    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the dense-row CSR kernel (k_smooth_ws)
+    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the CSR kernel that builds the row in LDS (k_smooth_ws)
     const double per_bin = (double)p.B * (double)(p.B > 3 ? p.B - 1 : 2) * cap + 1.0;
     int e = 0;
     (void)std::frexp(per_bin, &e);  // per_bin < 2^e
@@ -422,7 +422,6 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
                                    static_cast<const float*>(pl->d_zrow), base_guard.as<double>());
             } else {
                 if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
-                else if (p.B == 5 && p.window == 250 && p.ws_prefix) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, true>;
                 else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
                 // prepared entries {LDS position, centred and clipped value} on top of the zero row
                 HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));

@@ -4,35 +4,61 @@
 // are the same for every cell.  A stored entry changes one gene from z[g] to v = clip(x - ref[g]); windows are linear
 // in the gene values, so   window(cell) = (base + sum over the stored entries of weight * (v - z[g])) / denominator.
 // The kernel never builds the 20 000-gene row: it reads a cell's stored entries {column, value} as they are, fetches
-// the column's table entry {block | offset inside the block, reference, z} (k_sd_table: 16 bytes per gene, L2
-// resident) and adds the differences d = v - z[g] into per-block bins {S0 = sum d, S1 = sum j d} (j: gene offset inside the block),
-// the bins are turned into prefix sums over the blocks and every window is read off three of them, exactly as in the
-// prefix form of k_smooth_ws.
+// the column's table entry {LDS slot of its block | offset inside the block, reference, z} (k_sd_table: 16 bytes per
+// gene, L2 resident) and adds the differences d = v - z[g] into per-block bins {S0 = sum d, S1 = sum j d} (j: gene
+// offset inside the block).  The bins become prefix sums over the blocks, and a pyramid window is a linear
+// combination of three of them (see phase 4); a flat window a difference of two.
 //
-// The bins are 64-bit fixed point (d * 2^k, k from the clip value: icv_api.hip), added with LDS integer atomics:
-// integer addition is associative, so the result does not depend on the order of the entries in the row nor on the
-// order in which the atomics land (bit-reproducible), and the quantisation (2^-k <= 2^-46 per entry, 2^-56 at the
-// default clip of 3) is far below the float64 rounding of the prefix differences.  Windows agree with the canonical
-// evaluation order of k_smooth to ~1e-12 (same bound as the prefix form of k_smooth_ws).
+// The bins are 64-bit fixed point (d * 2^k, k from the clip value: sd_fraction_bits in icv_api.hip), added with LDS
+// integer atomics: integer addition is associative, so the result depends neither on the order of the entries in the
+// row nor on the order in which the atomics land (bit-reproducible), and the quantisation (2^-k <= 2^-46 per entry,
+// 2^-48 at the default clip of 3) is far below the float64 rounding of the prefix differences.  Windows agree with the
+// canonical evaluation order of k_smooth to ~1e-12.
 //
 // Per cell and workgroup (512 threads, two workgroups per CU), the median of cell k-1 shares the barriers of cell k:
-//   phase 0   histogram of k-1: 8 bins per thread, wavefront prefix sums      | bins of k zeroed
+//   phase 0   histogram of k-1: 8 bins per thread, wavefront prefix sums      | bins of k zeroed; table entries of the
+//                                                                               columns of k requested
 //   barrier A
 //   phase 1   middle bins of k-1 located, histogram cleared                   | entries of k added to the bins
-//   barrier B1                                                                 | entries of k+1 prefetched
+//   barrier B1
 //   phase 2   windows of k-1 in the middle bins gathered (<= 64)              | bins -> float64 prefix sums per wavefront
 //   barrier B2
 //   phase 3   candidates ranked exactly -> median of k-1                      | sums of the wavefronts before each one;
-//             {column, value} of k+1 requested (their table entries: phase 0 of the next iteration)
+//             window tables and {column, value} of k+1 requested
 //   barrier B3
 //   phase 4   x_res, moments of k-1 stored                                    | windows of k, histogram of k
 //   barrier B4
+// The kernel is bound by VALU issue (16 wavefronts per CU: LDS holds two workgroups), so work is skipped by branches
+// wherever a wavefront has none -- a branch-free window path and a version with four barriers and tail arrays instead
+// of the wavefront offsets both executed more instructions and were slower (10.3 and 10.5 ms against 8.8).
 // A NaN among the stored values of a cell (never on real data) and a cell with more than 64 windows in its median
 // bins are handed back to the generic k_smooth (row_list), like k_smooth_ws does.
 #pragma once
 #include "icv_kernel_ws.hpp"
 
 namespace icv {
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_shift0(double v) {  // lanes without a source receive 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sums over the 64 lanes in float64, fixed order (row shifts 1, 2, 4, 8, then the row totals)
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    v += dpp_shift0<0x111, 0xf>(v);
+    v += dpp_shift0<0x112, 0xf>(v);
+    v += dpp_shift0<0x114, 0xf>(v);
+    v += dpp_shift0<0x118, 0xf>(v);
+    v += dpp_shift0<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_shift0<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// The bins {S0,S1} of block b, and then the prefix sums up to b, live at slot b >> 3 of plane b & 7 (8 planes of 512
+// 16-byte pairs, plane stride 513 pairs): the eight accesses of a thread that owns blocks 8t .. 8t+7 (one plane,
+// consecutive slots over the lanes) are conflict-free
+constexpr int kWsPlane = 513;
+__device__ __forceinline__ int ws_pidx(int b) { return (b & 7) * kWsPlane + (b >> 3); }
 
 constexpr int kSdPF = 4;  // stored entries prefetched per thread (rows with <= 2048 entries; longer rows fetch the
                           // rest inside phase 1)
@@ -56,7 +82,7 @@ struct ScratchD {
 };
 static_assert(sizeof(ScratchD) <= 1536, "ScratchD must fit the scratch region");
 
-// per input column: {block | gene offset inside the block << 16 (all ones: masked column), ref_lo, ref_hi,
+// per input column: {LDS slot of the block's bins | gene offset inside the block << 16 (all ones: masked column), ref_lo, ref_hi,
 // z = clip(0 - ref)} -- everything phase 1 needs to turn a stored value into its difference to the zero row
 __global__ void __launch_bounds__(256) k_sd_table(const KParams P, u32x4* tab) {
     const int g = blockIdx.x * 256 + threadIdx.x;
@@ -66,8 +92,8 @@ __global__ void __launch_bounds__(256) k_sd_table(const KParams P, u32x4* tab) {
     const int pos = P.dst[g];
     u32x4 e = {0xffffffffu, 0u, 0u, 0u};
     if (pos >= 0) {
-        const int blk = pos / P.B;
-        e.x = (uint32_t)blk | ((uint32_t)(pos - blk * P.B) << 16);
+        const int blk = pos / P.B;  // its bins: 64-bit words 2 ws_pidx(blk), + 1
+        e.x = (uint32_t)(2 * ws_pidx(blk)) | ((uint32_t)(pos - blk * P.B) << 16);
         e.y = __float_as_uint(lo[g]);
         e.z = __float_as_uint(hi[g]);
         e.w = __float_as_uint(centre_clip<float>(0.0f, lo[g], hi[g], (float)P.cap, P.bounded, P.trunc));
@@ -289,7 +315,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
                     } else {
                         // round to nearest integer, |d * scale| < 2^51: the low mantissa bits of d * scale + 1.5 * 2^52
                         const long long q = __double_as_longlong(d * scale + 6755399441055744.0) - 0x4338000000000000ll;
-                        const int slot = 2 * ws_pidx((int)(e.x & 0xffffu));
+                        const int slot = (int)(e.x & 0xffffu);
                         atomicAdd(SQ + slot, (unsigned long long)q);
                         atomicAdd(SQ + slot + 1, (unsigned long long)(q * (long long)(e.x >> 16)));
                     }
@@ -346,8 +372,8 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
                 const int4 v = reinterpret_cast<const int4*>(SP)[k * kWsPlane + tl];
                 const long long a = (long long)(((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x);
                 const long long b = (long long)(((unsigned long long)(unsigned)v.w << 32) | (unsigned)v.z);
-                s0[k] = (double)a * qinv;
-                s1[k] = fma((double)g0v[k], s0[k], (double)b * qinv);
+                s0[k] = (double)a;  // in units of 2^-k: the windows apply the scale (a power of two: exact)
+                s1[k] = fma((double)g0v[k], s0[k], (double)b);
                 t0 = t0 + s0[k];
                 t1 = t1 + s1[k];
             }
@@ -402,9 +428,10 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
             a0 = u0;
             c0 = (int)(cnt < 0x7fffffff ? cnt : 0x7fffffff);
         }
-        if (have_prev && sc->mode == 0) {
+        const int n_cand = sc->ncand;
+        if (have_prev && sc->mode == 0 && (tl >> 6) * 8 < n_cand) {  // (a wavefront ranks candidates 8 w .. 8 w + 7)
             // exact float64 ranks of the <= 64 gathered candidates (see k_smooth_ws)
-            const int n = sc->ncand < 64 ? sc->ncand : 64;
+            const int n = n_cand < 64 ? n_cand : 64;
             const int below = sc->below;
             const int ci = tl >> 3, part = tl & 7;
             const double mine_raw = sc->cand[ci];
@@ -472,78 +499,30 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
                 return make_double2(v.x + o.x, v.y + o.y);
             };
             int lnan = 0;
-            // Wavefronts whose windows are all full pyramid windows (every one in the benchmark geometry) take a path
-            // without per-window branches, two windows at a time (their twelve LDS reads in flight together); a
-            // thread's missing last window repeats its first one and is discarded.
-            bool all_full = true;
 #pragma unroll
             for (int i = 0; i < MAXW; ++i) {
-                if (i > 0) w_pack[i] = (tl + i * NT < W) ? w_pack[i] : w_pack[0];
-                if (i > 0) w_sr[i] = (tl + i * NT < W) ? w_sr[i] : w_sr[0];
-                if (i > 0) wbase[i] = (tl + i * NT < W) ? wbase[i] : wbase[0];
-                all_full &= (w_pack[i] >> 16) == win;
-            }
-            if (__builtin_amdgcn_ballot_w64(!all_full) == 0) {
-                static_assert(MAXW % 2 == 0, "windows are taken in pairs");
-#pragma unroll
-                for (int g = 0; g < MAXW; g += 2) {
-                    double2 pb[2], pm[2], pe[2], ob[2], om[2], oe[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int bs = w_pack[g + u] & 0xffff;
-                        const int ib = bs > 0 ? bs - 1 : 0, im = bs + hbw - 1, ie = bs + nbw - 1;
-                        pb[u] = SP[ws_pidx(ib)];
-                        ob[u] = sc->poff[ib >> 9];
-                        pm[u] = SP[ws_pidx(im)];
-                        om[u] = sc->poff[im >> 9];
-                        pe[u] = SP[ws_pidx(ie)];
-                        oe[u] = sc->poff[ie >> 9];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int i = g + u;
-                        const bool first = (w_pack[i] & 0xffff) == 0;  // no block before the window
-                        const double b0 = first ? 0.0 : pb[u].x + ob[u].x, b1 = first ? 0.0 : pb[u].y + ob[u].y;
-                        const double m0 = pm[u].x + om[u].x, m1 = pm[u].y + om[u].y;
-                        const double e0 = pe[u].x + oe[u].x, e1 = pe[u].y + oe[u].y;
+                const int j = tl + i * NT;
+                wv[i] = 0.0;
+                if (j < W) {
+                    const int wp = w_pack[i];
+                    const int ln = wp >> 16, bs = wp & 0xffff;
+                    const double2 pb = bs == 0 ? make_double2(0.0, 0.0) : prefix_at(bs - 1);
+                    double v;
+                    if (ln > 0) {
+                        const double2 pm = prefix_at(bs + hbw - 1), pe = prefix_at(bs + nbw - 1);
                         const double sg = (double)w_sr[i];
-                        const double a = (m1 - b1) - (sg - 1.0) * (m0 - b0);
-                        const double d = (sg + (double)win) * (e0 - m0) - (e1 - m1);
-                        const double v = finish_window(wbase[i] + (a + d), win, pyr_den, pyr_rcp, 1.0);
-                        const bool valid = tl + i * NT < W;
-                        wv[i] = valid ? v : 0.0;
-                        lnan |= valid & (v != v);
-                        const int hb = hist_bin(v, inv_bound);
-                        wbin[i >> 1] = (i & 1) ? (wbin[i >> 1] | ((unsigned)hb << 16)) : (unsigned)hb;
-                        if (valid) atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));
+                        const double a = (pm.y - pb.y) - (sg - 1.0) * (pm.x - pb.x);
+                        const double d = (sg + (double)win) * (pe.x - pm.x) - (pe.y - pm.y);
+                        v = finish_window(wbase[i] + (a + d) * qinv, ln, pyr_den, pyr_rcp, 1.0);
+                    } else {  // flat: ln = -(padded genes of the chromosome)
+                        const double pe = prefix_at(bs + (-ln) / B - 1).x;
+                        v = (wbase[i] + (pe - pb.x) * qinv) / P.w_denom[j];
                     }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i) {
-                    const int j = tl + i * NT;
-                    wv[i] = 0.0;
-                    if (j < W) {
-                        const int wp = w_pack[i];
-                        const int ln = wp >> 16, bs = wp & 0xffff;
-                        const double2 pb = bs == 0 ? make_double2(0.0, 0.0) : prefix_at(bs - 1);
-                        double v;
-                        if (ln > 0) {
-                            const double2 pm = prefix_at(bs + hbw - 1), pe = prefix_at(bs + nbw - 1);
-                            const double sg = (double)w_sr[i];
-                            const double a = (pm.y - pb.y) - (sg - 1.0) * (pm.x - pb.x);
-                            const double d = (sg + (double)win) * (pe.x - pm.x) - (pe.y - pm.y);
-                            v = finish_window(wbase[i] + (a + d), ln, pyr_den, pyr_rcp, 1.0);
-                        } else {  // flat: ln = -(padded genes of the chromosome)
-                            const double pe = prefix_at(bs + (-ln) / B - 1).x;
-                            v = (wbase[i] + (pe - pb.x)) / P.w_denom[j];
-                        }
-                        wv[i] = v;
-                        lnan |= (v != v);
-                        const int hb = hist_bin(v, inv_bound);
-                        wbin[i >> 1] = (i & 1) ? (wbin[i >> 1] | ((unsigned)hb << 16)) : (unsigned)hb;
-                        atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));  // 16-bit bins, two per word
-                    }
+                    wv[i] = v;
+                    lnan |= (v != v);
+                    const int hb = hist_bin(v, inv_bound);
+                    wbin[i >> 1] = (i & 1) ? (wbin[i >> 1] | ((unsigned)hb << 16)) : (unsigned)hb;
+                    atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));  // 16-bit bins, two per word
                 }
             }
             if (lnan) sc->nanflag = 1;  // benign race: every writer stores 1

@@ -89,29 +89,6 @@ __device__ __forceinline__ int hist_bin(double v, float inv_bound) {
 // the L phase writes the pre-centred zero row (clip(0 - ref), held in registers for the whole kernel)
 // over the LDS row and scatters the cell's entries on top; the next cell's first PF entries per
 // thread are prefetched like the dense row.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_shift0(double v) {  // lanes without a source receive 0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// inclusive prefix sums over the 64 lanes in float64, fixed order (row shifts 1, 2, 4, 8, then the row totals)
-__device__ __forceinline__ double wave_scan_f64(double v) {
-    v += dpp_shift0<0x111, 0xf>(v);
-    v += dpp_shift0<0x112, 0xf>(v);
-    v += dpp_shift0<0x114, 0xf>(v);
-    v += dpp_shift0<0x118, 0xf>(v);
-    v += dpp_shift0<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
-    v += dpp_shift0<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
-// long windows (more than 10 blocks): {S0,T1} of block b and then their prefix sums live at slot b >> 3 of plane
-// b & 7 (8 planes of 512 pairs, plane stride 513 pairs): the writes of the S phase (consecutive blocks over the
-// lanes: eight planes, same slot) and the eight accesses of a thread that owns blocks 8t .. 8t+7 (one plane,
-// consecutive slots over the lanes) are both conflict-free
-constexpr int kWsPlane = 513;
-__device__ __forceinline__ int ws_pidx(int b) { return (b & 7) * kWsPlane + (b >> 3); }
-
 constexpr int kCsrPF = 4;  // prepared entries prefetched per thread (rows with <= 2048 entries; longer rows
                            // fetch the rest inside the L phase)
 
@@ -138,10 +115,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
     // window descriptors (start block | length << 16): re-read from L2 in every L phase, ahead of the
     // row prefetch; as loop-carried registers they end up in scratch
     const __amdgpu_buffer_rsrc_t wp_rs = make_rsrc(P.w_pack, (unsigned)W * 4u);
-    // long windows: windows from prefix sums of the block sums (see the W phase)
-    constexpr bool PFX = CSR && BT > 0 && NBW > 10;  // (the dense long-window variant keeps the canonical form: registers)
-    const __amdgpu_buffer_rsrc_t sr_rs = make_rsrc(P.w_srel, (unsigned)W * 4u);
-    const __amdgpu_buffer_rsrc_t g0_rs = make_rsrc(P.blk_g0, (unsigned)NB * 4u);
     const double pyr_den = P.pyr_den, pyr_rcp = P.pyr_rcp;
     const float* xbase = static_cast<const float*>(P.values);
     // cells of this workgroup: blockIdx.x, +gridDim.x, ...; plus one pipeline-drain iteration
@@ -317,7 +290,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         }
         ICV_PHASE(0)
         int w_pack[MAXW];
-        int w_sr[PFX ? MAXW : 1], g0v[PFX ? MAXB : 1];  // PFX: window gene offsets, first-gene offsets of this thread's blocks
         if (ICV_PL != ICV_PA) __builtin_amdgcn_s_setprio(ICV_PL);
         if (more) {
           if constexpr (CSR) {
@@ -332,14 +304,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #pragma unroll
             for (int i = 0; i < MAXW; ++i)
                 w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-            if constexpr (PFX) {
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i)
-                    w_sr[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(sr_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-#pragma unroll
-                for (int i = 0; i < MAXB; ++i)
-                    g0v[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(g0_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-            }
             // (the CSR variants have the registers for five zero-row vectors in flight: two L2 round trips per cell
             // instead of five)
             constexpr int UHC = (UMAX % 5 == 0) ? 5 : UH;
@@ -376,14 +340,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #pragma unroll
             for (int i = 0; i < MAXW; ++i)  // out-of-range windows read 0 (buffer bounds check)
                 w_pack[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(wp_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-            if constexpr (PFX) {
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i)
-                    w_sr[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(sr_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-#pragma unroll
-                for (int i = 0; i < MAXB; ++i)
-                    g0v[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(g0_rs, (unsigned)tl * 4u, i * NT * 4, 0);
-            }
             for (int i = tl; i < P.n_pad; i += NT) row[P.pad_idx[i]] = 0.0f;
 #define ICV_SCATTER4(X, LO, HI, D, BND)                                                                          \
     {                                                                                                            \
@@ -535,12 +491,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
 #pragma unroll
             for (int i = 0; i < MAXB; ++i) {
                 const int b = tl + i * NT;
-                if constexpr (PFX) {  // {S0, T1 = sum of g v} (g: gene offset inside the chromosome), plane layout
-                    if (b < NB)
-                        reinterpret_cast<double2*>(S01)[ws_pidx(b)] = make_double2(s0[i], fma((double)g0v[i], s0[i], s1[i]));
-                } else {
-                    if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
-                }
+                if (b < NB) *reinterpret_cast<double2*>(S01 + 2 * b) = make_double2(s0[i], s1[i]);
             }
         }
         if (have_prev && sc->mode == 0) {
@@ -574,55 +525,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
         __syncthreads();  // B3: {S0,S1} ready, histogram cleared, median of the previous cell published
         ICV_PHASE(4)
         asm volatile("" : "+v"(tl));
-        if constexpr (PFX) {
-            // ---- inclusive prefix sums of {S0, T1} over ALL blocks, in place (a window is a difference of prefix
-            // sums inside one chromosome; T1 uses gene offsets relative to the chromosome, so |P1| stays ~1e8 and
-            // a difference is good to ~1e-8: 1e-12 on a window mean).  Thread t owns blocks 8t .. 8t+7.
-            double2* SP = reinterpret_cast<double2*>(S01);
-            double ex0 = 0.0, ex1 = 0.0;
-            if (more) {
-                // pass 1: the thread's total (the eight pairs are read again in pass 2: registers are short here)
-                double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (8 * tl + k < NB) {
-                        const double2 v = SP[k * kWsPlane + tl];
-                        t0 = t0 + v.x;
-                        t1 = t1 + v.y;
-                    }
-                }
-                const double y0 = wave_scan_f64(t0), y1 = wave_scan_f64(t1);
-                ex0 = y0 - t0;  // exclusive: the lanes before this one
-                ex1 = y1 - t1;
-                if ((tl & 63) == 63) {
-                    sc->psum[tl >> 6] = y0;
-                    sc->psq[tl >> 6] = y1;
-                }
-            }
-            ICV_PHASE(6)
-            __syncthreads();  // B3a: wavefront totals published
-            if (more) {
-                const int wv_id = __builtin_amdgcn_readfirstlane(tl >> 6);
-                double r0 = ex0, r1 = ex1;
-                for (int w = 0; w < wv_id; ++w) {  // uniform: broadcast reads, at most 7
-                    r0 = r0 + sc->psum[w];
-                    r1 = r1 + sc->psq[w];
-                }
-                // pass 2: running sums over the thread's blocks, written back in place
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (8 * tl + k < NB) {
-                        const double2 v = SP[k * kWsPlane + tl];
-                        r0 = r0 + v.x;
-                        r1 = r1 + v.y;
-                        SP[k * kWsPlane + tl] = make_double2(r0, r1);
-                    }
-                }
-            }
-            ICV_PHASE(7)
-            __syncthreads();  // B3b: prefix sums complete
-            asm volatile("" : "+v"(tl));
-        }
         if (have_prev) {
             // x_res of the previous cell from the windows still in registers (a cell that was handed back gets
             // med = 0 here and is rewritten, with its median and moments, by k_smooth afterwards)
@@ -705,45 +607,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_ws(const KParams P) {
             }
         }
 #endif
-        if constexpr (PFX) {
-            if (more) {
-                // windows from the prefix sums: a pyramid window of n genes starting at gene s of its chromosome is
-                //   [P1(m1) - P1(b-) - (s - 1)(P0(m1) - P0(b-))] + [(s + n)(P0(m2) - P0(m1)) - (P1(m2) - P1(m1))]
-                // (b-: the block before the window, m1 / m2: last block of its first / second half) -- three LDS
-                // reads per window instead of NBW; a flat window is a difference of P0 over the gene count.
-                // Another float64 evaluation order than the canonical one (k_smooth): equal to ~1e-12.
-                const double2* SP = reinterpret_cast<const double2*>(S01);
-                int lnan = 0;
-#pragma unroll
-                for (int i = 0; i < MAXW; ++i) {
-                    const int j = tl + i * NT;
-                    wv[i] = 0.0;
-                    if (j < W) {
-                        const int wp = w_pack[i];
-                        const int ln = wp >> 16, bs = wp & 0xffff;
-                        const double2 pb = bs == 0 ? make_double2(0.0, 0.0) : SP[ws_pidx(bs - 1)];
-                        double v;
-                        if (ln == NBW * BT) {
-                            const double2 pm = SP[ws_pidx(bs + NBW / 2 - 1)], pe = SP[ws_pidx(bs + NBW - 1)];
-                            const double sg = (double)w_sr[i];
-                            const double a = (pm.y - pb.y) - (sg - 1.0) * (pm.x - pb.x);
-                            const double d = (sg + (double)(NBW * BT)) * (pe.x - pm.x) - (pe.y - pm.y);
-                            v = finish_window(a + d, ln, pyr_den, pyr_rcp, 1.0);
-                        } else {  // flat: ln = -(padded genes of the chromosome)
-                            const double pe = SP[ws_pidx(bs + (-ln) / BT - 1)].x;
-                            v = (pe - pb.x) / P.w_denom[j];
-                        }
-                        wv[i] = v;
-                        lnan |= (v != v);
-                        const int hb = hist_bin(v, inv_bound);
-                        wbin[i >> 1] = (i & 1) ? (wbin[i >> 1] | ((unsigned)hb << 16)) : (unsigned)hb;
-                        atomicAdd(&hist[hb >> 1], 1 << ((hb & 1) * 16));  // 16-bit bins, two per word
-                    }
-                }
-                if (lnan) sc->nanflag = 1;
-            }
-            w_done = true;
-        }
         if (more && !w_done) {
             int lnan = 0;
 #pragma unroll

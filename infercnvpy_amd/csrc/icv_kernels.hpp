@@ -89,8 +89,8 @@ struct KParams {
     // block count | gene count << 16
     const uint32_t* x16_wdesc;
     int32_t x16_half, _pad4;  // k_smooth_x16: slots of the even-block {S0,S1} array
-    // k_smooth_ws, long windows (prefix-sum form): per window the gene offset inside its chromosome, per block the
-    // gene offset of its first gene inside its chromosome
+    // k_smooth_sd: per window the gene offset inside its chromosome, per block the gene offset of its first gene
+    // inside its chromosome
     const int32_t* w_srel;
     const int32_t* blk_g0;
     // k_smooth_sd (CSR, long windows): per input column {block | offset inside the block << 16, ref_lo, ref_hi,

@@ -59,7 +59,6 @@ struct Plan {
     // ws path, long windows (prefix-sum form): gene offset of a window inside its chromosome; per block, the gene
     // offset of its first gene inside its chromosome
     std::vector<int32_t> w_srel, blk_g0;
-    bool ws_prefix = false;  // long windows (more than 10 blocks): k_smooth_ws forms windows from prefix sums
     std::vector<uint16_t> dst16;     // fast path: kFastUMax*kThreads*4 entries, Gp (trash slot) = masked
     double pyr_den = 1.0, pyr_rcp = 1.0;
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
@@ -249,10 +248,7 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
             p.w_pack[j] = (int32_t)((uint32_t)((p.w_start[j] / B) & 0xffff) | ((uint32_t)p.w_len[j] << 16));
         p.ws_win_off = 16 * p.NB;
         p.ws_hist_off = p.ws_win_off;  // the histogram follows {S0,S1} inside the (dead) row
-        // long windows: {S0,T1} / their prefix sums live in 8 planes of 512 slots (block b: plane b & 7, slot b >> 3)
-        // (plane stride 513 pairs: see icv_kernel_ws.hpp)
-        p.ws_prefix = window % 2 == 0 && window / B > 10 && p.NB <= 4096 && 16 * 8 * 513 + 4096 * 2 <= p.fast_scratch_off;
-        if (p.ws_prefix) p.ws_hist_off = 16 * 8 * 513;
+        // k_smooth_sd: per window the gene offset inside its chromosome, per block that of its first gene
         p.w_srel.assign(p.W, 0);
         p.blk_g0.assign((size_t)p.NB + 8, 0);
         for (int c = 0; c < n_chr; ++c) {

@@ -393,9 +393,9 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
         # default (k_smooth_x16 where the geometry admits it, else k_smooth_ws), k_smooth_ws forced,
         # prepared-entry CSR, generic CSR
-        # long windows (more than 10 blocks) on prepared CSR input: k_smooth_ws forms the windows from prefix sums of
-        # the block sums -- another float64 evaluation order, equal to the canonical one to ~1e-12 (float32 x_res:
-        # last-bit differences in a few entries per 100 000)
+        # long windows (more than 10 blocks) on CSR input: k_smooth_sd adds the stored entries' differences to the
+        # zero row into block bins and reads the windows off prefix sums -- another float64 evaluation order, equal
+        # to the canonical one to ~1e-12 (float32 x_res: last-bit differences in a few entries per 100 000)
         pfx = window == 250 and step == 10
         for env, mat, exact in (([], dm, True), (["ICV_NO_X16"], dm, True), ([], dm_csr, not pfx),
                                 (["ICV_FORCE_GENERIC"], dm_csr, True)):
@@ -426,6 +426,53 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
                 assert not d.any(), env
             else:  # thresholded: an entry within ~1e-12 of the threshold may fall on the other side
                 assert d.double().mean().item() < 1e-3, env
+
+
+def test_csr_long_windows_do_not_depend_on_entry_order():
+    """k_smooth_sd accumulates in fixed point: any order of a row's stored entries gives the same bits, and so do
+    repeated runs.  Geometries: the benchmark's (window 250 / step 10) and one with other block sizes, masked
+    columns and a chromosome shorter than the window (flat window)."""
+    import torch
+
+    from infercnvpy_amd import _engine
+    from infercnvpy_amd._plan import GenePlan
+
+    for genes, window, step, extra in ((cases.GENES_PER_CHROM_20K, 250, 10, (("chrX", 31), (None, 3))),
+                                       ([1500, 700, 333, 90], 120, 4, ((None, 5),))):
+        v = cases.synthetic_var(genes, extra=extra)
+        n_genes = len(v["names"]) - len(v["names"]) % 4
+        for key in ("chromosome", "start"):
+            v[key] = v[key][:n_genes]
+        plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=step)
+        Xh = cases.synthetic_expr(300, n_genes, seed=5)
+        Xh[Xh < np.quantile(Xh, 0.9)] = 0  # ~10 % stored
+        ref = torch.from_numpy(Xh[100:].mean(axis=0)).cuda()
+        csr = sp.csr_matrix(Xh)
+        rng = np.random.RandomState(0)
+        indices, data = csr.indices.copy(), csr.data.copy()
+        for r in range(csr.shape[0]):  # shuffle the entries inside every row
+            a, b = csr.indptr[r], csr.indptr[r + 1]
+            perm = rng.permutation(b - a)
+            indices[a:b], data[a:b] = indices[a:b][perm], data[a:b][perm]
+
+        def run(ix, dv):
+            dm = _engine.DeviceMatrix(indptr=torch.from_numpy(csr.indptr.astype(np.int64)).cuda(),
+                                      indices=torch.from_numpy(ix.astype(np.int32)).cuda(),
+                                      data=torch.from_numpy(dv.astype(np.float32)).cuda(), shape=csr.shape)
+            res = _engine.run_hot_path(plan, dm, ref, chunksize=100, cell_stats=True)
+            torch.cuda.synchronize()
+            return res
+
+        base, again, shuffled = run(csr.indices, csr.data), run(csr.indices, csr.data), run(indices, data)
+        for other in (again, shuffled):
+            assert torch.equal(base.out, other.out)
+            assert torch.equal(base.cell_median, other.cell_median)
+            assert torch.equal(base.cell_stats, other.cell_stats)
+        # and the values are those of the dense path
+        dense = _engine.run_hot_path(plan, _engine.DeviceMatrix(dense=torch.from_numpy(Xh).cuda()), ref, chunksize=100,
+                                     cell_stats=True)
+        torch.testing.assert_close(base.out.double(), dense.out.double(), rtol=0, atol=2.5e-7)
+        torch.testing.assert_close(base.cell_median, dense.cell_median, rtol=0, atol=1e-11)
 
 
 @pytest.mark.parametrize("fmt", ["dense", "csr"])
