@@ -770,7 +770,7 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nc = m->n_cols;
     if (m->format == ICV_CSR) {
-        // one wavefront per (slab, column tile): slabs sized so that every CU gets a few of them
+        // one 1024-thread workgroup per (slab, column tile), the whole LDS of a CU each: two slabs per CU
         int n_cu = 256;
         {
             int dev = 0;
@@ -778,7 +778,7 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
                 n_cu = prop.multiProcessorCount;
         }
-        int rows_per_slab = (int)((m->n_rows + (int64_t)n_cu * 4 - 1) / ((int64_t)n_cu * 4));
+        int rows_per_slab = (int)((m->n_rows + (int64_t)n_cu * 2 - 1) / ((int64_t)n_cu * 2));
         if (rows_per_slab < 64) rows_per_slab = 64;
         const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
         const int n_tiles = (nc + icv::kCsrTileCols - 1) / icv::kCsrTileCols;
@@ -786,11 +786,11 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         AsyncBuf partial_b;
         HIP_TRY(partial_b.alloc((size_t)n_slabs * nc * sizeof(double), st));
         double* partial = partial_b.as<double>();
-        dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(64);
-        void (*kf)(const float*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
-            icv::k_colsum_csr<float>;
-        void (*kd)(const double*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*) =
-            icv::k_colsum_csr<double>;
+        dim3 grid((unsigned)n_tiles, (unsigned)n_slabs), block(icv::kCsThreads);
+        typedef void (*kf_t)(const float*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*);
+        typedef void (*kd_t)(const double*, const int64_t*, const int32_t*, int64_t, int, const int32_t*, int, int, double*);
+        const kf_t kf = row_group ? (kf_t)icv::k_colsum_csr<float, true> : (kf_t)icv::k_colsum_csr<float, false>;
+        const kd_t kd = row_group ? (kd_t)icv::k_colsum_csr<double, true> : (kd_t)icv::k_colsum_csr<double, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         for (int g = 0; g < n_groups; ++g) {

@@ -1020,53 +1020,106 @@ __global__ void __launch_bounds__(1024) k_colsum_finish(const double* partial, i
     }
 }
 
-// CSR: ONE wavefront owns (row slab) x (tile of up to 20 000 columns = 160 000 B of float64 accumulators in LDS,
-// the whole LDS of a CU).  The rows of the slab are walked in order and every batch of 64 stored entries of a row
-// is added with one ds_add_f64: the columns of a row are distinct, the LDS executes the instructions of a
-// wavefront in order, so every column receives its addends in row order -- deterministic, unlike several
-// wavefronts adding into one tile.  The tile then goes to partial[slab][...] and k_colsum_finish adds the slabs
-// in a fixed order.  Loads of the next batches are issued before the adds of the current one.
+// CSR: one 1024-thread workgroup owns (row slab) x (tile of up to 20 000 columns = 160 000 B of float64 accumulators in
+// LDS, the whole LDS of a CU).  The rows of the slab are taken one at a time: all sixteen wavefronts add the stored
+// entries of the SAME row with ds_add_f64 (the columns of a row are distinct: no two adds meet), then a workgroup
+// barrier, then the next row -- every column receives its addends in row order, so the sums are deterministic, unlike
+// wavefronts adding different rows into one tile.  The tile then goes to partial[slab][...] and k_colsum_finish adds
+// the slabs in a fixed order.
+// What makes it fast is the software pipeline: the {column, value} pairs of the next kCsDepth rows are in flight while
+// a row is added (a row is ~11 KB, the HBM round trip several rows long), and the row offsets another kCsDepth rows
+// ahead of that.  All of these are unconditional loads (buffer loads with the row's length as range; a row that is
+// past the slab or belongs to another group has length 0), so the compiler's wait counts are exact.
 constexpr int kCsrTileCols = 20000;
-template <typename T>
-__global__ void __launch_bounds__(64) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
-                                                   int64_t n_rows, int n_cols, const int32_t* row_group, int group,
-                                                   int rows_per_slab, double* partial /* n_slabs x n_cols */) {
+constexpr int kCsDepth = 8;
+constexpr int kCsThreads = 1024;
+template <typename T, bool GROUPS>
+__global__ void __launch_bounds__(kCsThreads) k_colsum_csr(const T* vals, const int64_t* indptr, const int32_t* indices,
+                                                           int64_t n_rows, int n_cols, const int32_t* row_group, int group,
+                                                           int rows_per_slab, double* partial /* n_slabs x n_cols */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tile = reinterpret_cast<double*>(smem);
+    constexpr int D = kCsDepth, NT_ = kCsThreads;
     const int c0 = blockIdx.x * kCsrTileCols;
     const int nc = (n_cols - c0) < kCsrTileCols ? (n_cols - c0) : kCsrTileCols;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < nc; i += 64) tile[i] = 0.0;
+    const int t = threadIdx.x;
+    for (int i = t; i < nc; i += NT_) tile[i] = 0.0;
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
     int64_t r1 = r0 + rows_per_slab;
     if (r1 > n_rows) r1 = n_rows;
-    constexpr int U = 4;
-    for (int64_t row = r0; row < r1; ++row) {
-        if (row_group && row_group[row] != group) continue;
-        const int64_t e = indptr[row + 1];
-        for (int64_t k0 = indptr[row]; k0 < e; k0 += 64 * U) {
-            int c[U];
-            double v[U];
+    if (r0 >= r1) return;  // (uniform)
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));  // row offsets through vector loads: scalar loads share their counter with the LDS
+    int64_t ipa[D], ipb[D];  // slot s: offsets of the row whose entries are requested next ...
+    int ipg[D], ipv[D];      // ... its group, and whether it lies inside the slab
+    unsigned ei[D][2];       // slot s: entries in flight (lanes t and t + 1024 of the row) ...
+    T ev[D][2];
+    int64_t est[D];          // ... the row's first entry and its length (0: nothing to add)
+    int cnt[D];
+    const auto load_ip = [&](int s, int64_t row) {
+        const int64_t rr = row < r1 ? row : r1 - 1;
+        ipa[s] = indptr[rr + zoff];
+        ipb[s] = indptr[rr + 1 + zoff];
+        ipg[s] = GROUPS ? row_group[rr + zoff] : group;
+        ipv[s] = row < r1;
+    };
+    const auto uniform64 = [](int64_t v) {
+        return ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    const auto load_entries = [&](int s) {
+        const int64_t e0 = uniform64(ipa[s]), e1 = uniform64(ipb[s]);
+        const bool mine = ipv[s] && __builtin_amdgcn_readfirstlane(ipg[s]) == group;
+        const int64_t n = mine ? e1 - e0 : 0;
+        const unsigned npf = (unsigned)(n < 2 * NT_ ? n : 2 * NT_);
+        const __amdgpu_buffer_rsrc_t i_rs = make_rsrc(indices + e0, npf * 4u);
+        const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vals + e0, npf * (unsigned)sizeof(T));
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t k = k0 + u * 64 + lane;
-                c[u] = -1;
-                v[u] = 0.0;
-                if (k < e) {
-                    c[u] = indices[k] - c0;
-                    v[u] = (double)vals[k];
-                }
+        for (int u = 0; u < 2; ++u) {
+            ei[s][u] = __builtin_amdgcn_raw_buffer_load_b32(i_rs, (unsigned)t * 4u, u * NT_ * 4, 0);
+            if constexpr (sizeof(T) == 4) {
+                ev[s][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(v_rs, (unsigned)t * 4u, u * NT_ * 4, 0));
+            } else {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(v_rs, (unsigned)t * 8u, u * NT_ * 8, 0);
+                ev[s][u] = __hiloint2double((int)w.y, (int)w.x);
             }
+        }
+        est[s] = e0;
+        cnt[s] = (int)(n < 0x7fffffff ? n : 0x7fffffff);
+    };
+    const auto add = [&](int col, double v) {
+        const int c = col - c0;
+        if (c >= 0 && c < nc) __hip_atomic_fetch_add(tile + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const auto consume = [&](int s) {
+        const int n = cnt[s];
+        if (n > 0) {  // (uniform)
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (c[u] >= 0 && c[u] < nc)
-                    __hip_atomic_fetch_add(tile + c[u], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < 2; ++u)
+                if (t + u * NT_ < n) add((int)ei[s][u], (double)ev[s][u]);
+            for (int k = t + 2 * NT_; k < n; k += NT_) add(indices[est[s] + k], (double)vals[est[s] + k]);  // long rows
+            __syncthreads();  // the next row may meet the same columns
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_ip(s, r0 + s);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        load_entries(s);
+        load_ip(s, r0 + D + s);
+    }
+    for (int64_t r = r0; r < r1; r += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            consume(s);                  // row r + s
+            load_entries(s);             // row r + s + D (its offsets were requested D rows ago)
+            load_ip(s, r + s + 2 * D);
         }
     }
     __syncthreads();
     double* dst = partial + (int64_t)blockIdx.y * n_cols + c0;
-    for (int i = lane; i < nc; i += 64) dst[i] = tile[i];
+    for (int i = t; i < nc; i += NT_) dst[i] = tile[i];
 }
 
 // cnv_score: per-row sum |x| (tl/_scores.py:66), one wavefront per row, float64
