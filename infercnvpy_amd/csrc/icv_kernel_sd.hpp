@@ -36,6 +36,20 @@
 #pragma once
 #include "icv_kernel_ws.hpp"
 
+// Wave priority by phase (s_setprio): the SIMD's arbiter prefers the wavefronts of the workgroup that is in its
+// scan (phase 2) or window (phase 4) phase over the one that zeroes bins, waits for gathers or issues loads:
+// 8.40 -> 7.90 ms on config 4 (same box; priority 2 in phases 1, 2, 4: 8.09; in phases 0 and 3: 8.43; 3 instead of 2
+// in phases 2 and 4: 7.82, within the noise)
+#ifndef ICV_SD_P0
+#define ICV_SD_P0 0
+#define ICV_SD_P1 0
+#define ICV_SD_P2 2
+#define ICV_SD_P3 0
+#define ICV_SD_P4 2
+#endif
+#define ICV_SD_PRIO(p) \
+    if (ICV_SD_P0 | ICV_SD_P1 | ICV_SD_P2 | ICV_SD_P3 | ICV_SD_P4) __builtin_amdgcn_s_setprio(p);
+
 namespace icv {
 
 template <int CTRL, int ROWMASK>
@@ -206,6 +220,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         asm volatile("" : "+v"(tl));  // keep thread-derived values out of LICM (see k_smooth_fast)
 
         // ---------------- phase 0: histogram level 1 (previous cell); bins zeroed (this cell) -------------------
+        ICV_SD_PRIO(ICV_SD_P0)
         int4 hv = make_int4(0, 0, 0, 0);
         int htot = 0, hincl = 0, nanf = 0, hback = 0;
         if (have_prev) {
@@ -229,6 +244,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         ICV_SDP(1)
 
         // ---------------- phase 1: middle bins located (previous cell); entries added (this cell) ---------------
+        ICV_SD_PRIO(ICV_SD_P1)
         if (have_prev) {
             if (hback) {  // a stored NaN: the generic kernel recomputes the cell
                 if (tl == 0) {
@@ -336,6 +352,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         asm volatile("" : "+v"(tl));
 
         // ---------------- phase 2: candidates gathered (previous cell); block totals (this cell) ----------------
+        ICV_SD_PRIO(ICV_SD_P2)
         if (have_prev && sc->mode == 0) {
             const int b1 = sc->b1, b2 = sc->b2;
             const int n_in_bins = sc->c1 + (b2 != b1 ? sc->c2 : 0);
@@ -396,6 +413,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         asm volatile("" : "+v"(tl));
 
         // ---------------- phase 3: median (previous cell); sums of the wavefronts before (this cell) -------------
+        ICV_SD_PRIO(ICV_SD_P3)
         // Loads first: the tables of phase 4, then the entries of the next cell (needed two barriers later).  All of
         // them, and the x_res stores of phase 4, are unconditional buffer operations -- with an empty range where
         // there is nothing to do -- so that the compiler's counter bookkeeping stays exact and the waits in front of
@@ -473,6 +491,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         asm volatile("" : "+v"(tl));
 
         // ---------------- phase 4: x_res (previous cell); windows + histogram (this cell) -----------------------
+        ICV_SD_PRIO(ICV_SD_P4)
         double sum = 0.0, sq = 0.0;
         const double med = (k1 == k2) ? sc->ma : (sc->ma + sc->mb) / 2.0;
         {
