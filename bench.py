@@ -22,8 +22,17 @@ Prints ONE JSON line on rank 0: value = cells/s of the whole job (HBM-resident i
                  (events recorded by the library on the launch stream), against the 8 TB/s HBM peak
   cpu_baseline - the numpy oracle (a port of the reference algorithm, oracle/) on this box's host cores on a
                  bounded sample of the same workload (rank 0, N = 1 only)
-  e2e          - the public cnv.tl.infercnv(adata) from HOST memory to a host CSR X_cnv (PCIe-inclusive; rank 0,
-                 N = 1 only): dense 200 000 x 20 000 and the config-4 CSR, with the stage times.
+  e2e          - the public cnv.tl.infercnv(adata) from HOST memory to a host CSR X_cnv (PCIe-inclusive, rank 0).
+                 N = 1: dense 200 000 x 20 000 and the config-4 CSR.  N > 1: ONE call with devices=[0..N-1] (the
+                 multi-GPU path of the public API: row shards, one uploader + CSR drain per GPU), 100 000 dense
+                 cells per GPU, while the other ranks wait at a barrier with their HBM released.
+  extra        - (N = 1) the other BASELINE configurations, HBM resident, each with its own roofline: config 4 (CSR
+                 window 250), CSR window 100, config 3's 1 M cells on one GPU, the product-path variant of the step
+                 (thresholds as a keep-mask + device-side CSR pack instead of the in-place threshold), config 5
+                 (distances + Ward at 100 000 x 5 000).
+
+``--dry-run-one-gpu`` (never a measurement: prints "dry_run": true): all N ranks share cuda:0 and the collectives
+go through gloo -- exercises the launcher, the sharding and the N > 1 code paths on a one-GPU box.
 """
 from __future__ import annotations
 
@@ -41,8 +50,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # same guide: dense fp32 MFMA peak
 CHUNK = 5000
+CONFIG2_CELLS = 100_000
 CONFIG3_CELLS = 1_000_000
+G = 20000
 
 
 def synth_chunk(torch, n_rows, n_genes, seed):
@@ -106,29 +118,76 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=3):
+def _physical_cores():
+    """Physical cores of the box (distinct (package, core) pairs in /proc/cpuinfo); logical count if unknown."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def _cpu_pool_rate(workers, window, step, cells_per_worker, reps):
     from concurrent.futures import ProcessPoolExecutor
 
-    cores = os.cpu_count() or 1
-    tasks = [(100 + i, cells_per_worker, window, step, reps) for i in range(cores)]
+    tasks = [(100 + i, cells_per_worker, window, step, reps) for i in range(workers)]
     t0 = time.perf_counter()
-    with ProcessPoolExecutor(max_workers=cores) as pool:
+    with ProcessPoolExecutor(max_workers=workers) as pool:
         busy = list(pool.map(_cpu_worker, tasks))
     wall = time.perf_counter() - t0
-    n = cells_per_worker * cores * reps
+    n = cells_per_worker * workers * reps
     # all workers run concurrently: throughput = cells / the slowest worker's compute time
-    return {
-        "value": n / max(busy), "unit": "cells/s", "cores": cores, "kind": "port",
-        "sample": f"{cores} processes x {reps} x {cells_per_worker}-cell chunks ({n} cells x 20000 genes dense fp32, "
-                  f"window {window} step {step}), oracle chunk kernel (per-row np.convolve as the reference) on "
-                  f"worker-local data; slowest worker {max(busy):.1f} s compute, {wall:.1f} s wall incl. start-up",
+    return n / max(busy), n, max(busy), wall
+
+
+def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2):
+    logical = os.cpu_count() or 1
+    physical = min(_physical_cores(), logical)
+    rate_l, n_l, busy_l, wall_l = _cpu_pool_rate(logical, window, step, cells_per_worker, reps)
+    out = {
+        "value": rate_l, "unit": "cells/s", "cores": logical, "kind": "port",
+        "per_process_cells_per_s": rate_l / logical,
+        "sample": f"{logical} processes (one per logical CPU) x {reps} x {cells_per_worker}-cell chunks ({n_l} cells x "
+                  f"20000 genes dense fp32, window {window} step {step}), oracle chunk kernel (per-row np.convolve as "
+                  f"the reference) on worker-local data; slowest worker {busy_l:.1f} s compute, {wall_l:.1f} s wall "
+                  f"incl. start-up.  {rate_l / logical:.0f} cells/s per process against ~600-900 for one process alone "
+                  f"on an idle box: with every logical CPU busy the box is memory-bandwidth / SMT bound (each chunk "
+                  f"pass streams ~0.5 GB through numpy temporaries), so this is the whole-box rate, not cores x the "
+                  f"single-core rate",
     }
+    if physical < logical:
+        rate_p, n_p, busy_p, wall_p = _cpu_pool_rate(physical, window, step, cells_per_worker, reps)
+        out["physical_cores"] = {
+            "value": rate_p, "cores": physical, "per_process_cells_per_s": rate_p / physical,
+            "sample": f"{physical} processes (one per physical core), same chunks: {n_p} cells, slowest worker "
+                      f"{busy_p:.1f} s, {wall_p:.1f} s wall",
+        }
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------------
 # end to end through the public API, from host memory
 # ----------------------------------------------------------------------------------------------------------
-def e2e_legs(torch, window_dense=100, dense_cells=200_000, csr_cells=500_000):
+def _stage_seconds(tm):
+    out = {}
+    for k, x in tm.items():
+        if isinstance(x, (int, float)) and k not in ("kernel",):
+            out[k] = round(float(x), 4)
+    return out
+
+
+def _e2e_run(name, X, window, legs, devices=None, repeats=2):
+    import gc
+
     import numpy as np
     import pandas as pd
     import scipy.sparse as sp
@@ -139,40 +198,294 @@ def e2e_legs(torch, window_dense=100, dense_cells=200_000, csr_cells=500_000):
 
     v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
     var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    ref = np.asarray(X[:2000].mean(axis=0), dtype=np.float64).ravel().astype(np.float32)
+    best, ad = None, None
+    for _ in range(repeats):  # first call pays one-time costs (pinned staging buffers, plan tables, contexts)
+        ad = None  # a fresh AnnData per call: releasing the previous X_cnv (> 1 GB) is not part of the call
+        gc.collect()
+        ad = SimpleAnnData(X, var=var)
+        tm = {}
+        t0 = time.perf_counter()
+        cnv.tl.infercnv(ad, reference=ref, window_size=window, step=10, devices=devices, _timings=tm)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, tm)
+    dt, tm = best
+    in_bytes = X.data.nbytes + X.indices.nbytes + X.indptr.nbytes if sp.issparse(X) else X.nbytes
+    legs[name] = {
+        "cells": int(X.shape[0]), "seconds": dt, "cells_per_s": X.shape[0] / dt, "devices": tm.get("devices"),
+        # per-GPU upload rate of the slowest shard's helper thread, and what all links moved together per second
+        "h2d_GBps": in_bytes / max(len(tm.get("devices") or [0]), 1) / max(tm.get("h2d", dt), 1e-9) / 1e9,
+        "h2d_GBps_all_gpus": in_bytes / max(tm.get("h2d", dt), 1e-9) / 1e9,
+        "input_GB": in_bytes / 1e9,
+        "x_cnv_nnz": int(ad.obsm["X_cnv"].nnz), "stages_s": _stage_seconds(tm),
+    }
+    if "shards" in tm:
+        legs[name]["shards"] = tm["shards"]
+
+
+def e2e_legs(torch, window_dense=100, dense_cells=200_000, csr_cells=500_000):
+    import scipy.sparse as sp
+
     legs = {}
-
-    def run(name, X, window, **kw):
-        import gc
-
-        ref = np.asarray(X[:2000].mean(axis=0), dtype=np.float64).ravel().astype(np.float32)
-        best, ad = None, None
-        for _ in range(2):  # first call pays one-time costs (pinned staging buffers, plan tables)
-            ad = None  # a fresh AnnData per call: releasing the previous X_cnv (> 1 GB) is not part of the call
-            gc.collect()
-            ad = SimpleAnnData(X, var=var)
-            tm = {}
-            t0 = time.perf_counter()
-            cnv.tl.infercnv(ad, reference=ref, window_size=window, step=10, _timings=tm, **kw)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[0]:
-                best = (dt, tm)
-        dt, tm = best
-        in_bytes = X.data.nbytes + X.indices.nbytes + X.indptr.nbytes if sp.issparse(X) else X.nbytes
-        legs[name] = {
-            "cells": int(X.shape[0]), "seconds": dt, "cells_per_s": X.shape[0] / dt,
-            "h2d_GBps": in_bytes / max(tm.get("h2d", dt), 1e-9) / 1e9, "input_GB": in_bytes / 1e9,
-            "x_cnv_nnz": int(ad.obsm["X_cnv"].nnz), "stages_s": {k: round(float(x), 4) for k, x in tm.items()},
-        }
-
-    Xd = synth_rows(torch, 0, dense_cells, 20000).cpu().numpy()
-    run(f"dense fp32 {dense_cells} x 20000, window {window_dense}", Xd, window_dense)
+    Xd = synth_rows(torch, 0, dense_cells, G).cpu().numpy()
+    _e2e_run(f"dense fp32 {dense_cells} x 20000, window {window_dense}", Xd, window_dense, legs, devices=[0])
     del Xd
-    ip, ix, dv = synth_csr_on_device(torch, csr_cells, 20000, 0.07, seed=3)
-    Xs = sp.csr_matrix((dv.cpu().numpy(), ix.cpu().numpy(), ip.cpu().numpy()), shape=(csr_cells, 20000))
+    ip, ix, dv = synth_csr_on_device(torch, csr_cells, G, 0.07, seed=3)
+    Xs = sp.csr_matrix((dv.cpu().numpy(), ix.cpu().numpy(), ip.cpu().numpy()), shape=(csr_cells, G))
     del ip, ix, dv
     torch.cuda.empty_cache()
-    run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250 (BASELINE config 4)", Xs, 250)
+    _e2e_run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250 (BASELINE config 4)", Xs, 250, legs, devices=[0])
     return legs
+
+
+def e2e_multi_gpu(torch, devices, cells_per_gpu=100_000):
+    """ONE public call over all GPUs of the job (rank 0; the other ranks idle): weak-scaled dense input."""
+    import numpy as np
+
+    legs = {}
+    n = cells_per_gpu * len(devices)
+    Xd = np.empty((n, G), dtype=np.float32)
+    for r0 in range(0, n, 50_000):  # generated on this rank's GPU, 4 GB at a time
+        r1 = min(n, r0 + 50_000)
+        Xd[r0:r1] = synth_rows(torch, r0, r1, G).cpu().numpy()
+    torch.cuda.empty_cache()
+    _e2e_run(f"dense fp32 {n} x 20000, window 100, tl.infercnv(devices={list(devices)})", Xd, 100, legs,
+             devices=list(devices))
+    return legs
+
+
+# ----------------------------------------------------------------------------------------------------------
+# HBM-resident step: timing + roofline of the smoothing kernel
+# ----------------------------------------------------------------------------------------------------------
+def kernel_label(fmt, window, step):
+    if fmt == "dense" and window == 100 and step == 10:
+        return "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10)"
+    if fmt == "dense" and window == 250 and step == 10:
+        return "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
+    if fmt == "csr" and window % 2 == 0 and math.gcd(step, window // 2) > 1:
+        return ("k_sd_table + k_sd_base + k_smooth_sd (CSR fp32, block form: stored entries only, differences to the "
+                "zero row in fixed-point block bins, windows from prefix sums)")
+    if fmt == "csr":
+        return "k_smooth<CSR> (generic: one row in LDS)"
+    return "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
+
+
+def pmc_traffic(key, cells):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected
+    in separate rocprofv3 --pmc runs on a fixed number of cells, corrected per MI355X_MICROARCH.md), scaled to the
+    cells of this launch.  None for workloads without counter data."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    ent = rec.get("kernels", {}).get(key) if "kernels" in rec else None
+    if ent is None and key == "dense_w100" and "x16" in rec.get("kernel", ""):
+        ent = {"hbm_bytes_per_launch": rec.get("k_smooth_hbm_bytes_per_launch"), "cells": 100_000}
+    if not ent or not ent.get("hbm_bytes_per_launch"):
+        return None
+    return ent["hbm_bytes_per_launch"] * (cells / float(ent.get("cells", 100_000)))
+
+
+def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksize, steps, warmup, dist=None,
+             bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None):
+    """Time `steps` passes of the hot path over the resident rows of `dm`; returns (seconds, roofline dict)."""
+    n_total = n_local if n_total is None else n_total
+    W = plan.n_windows
+    out = _engine.alloc_out(n_local, W)
+    sums = torch.zeros((1, G), dtype=torch.float64, device="cuda")
+    fixed_ref = (_engine.column_sums(dm)[0] / n_local).float() if no_refmean else None
+
+    def one_step():
+        if fixed_ref is None:
+            sums.zero_()
+            _engine.column_sums(dm, None, 1, sums)
+            # the only collective of the path: [G] float64 sums + the row count, over RCCL / xGMI
+            ref = icd.reference_means(sums, [n_local], "float32", device_out=True)[0] if dist is not None \
+                else (sums[0] / n_local).float()
+        else:
+            ref = fixed_ref
+        # no host synchronisation inside a step: the library records HIP events around the smoothing kernel on
+        # the launch stream (icv_profile_begin) and the times are read after the timed region
+        return icd.run_shard(plan, dm, ref, global_row0=row0, n_obs_global=n_total, lfc_clip=3.0,
+                             dynamic_threshold=1.5, chunksize=chunksize, all_bounds=bounds, out=out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_step()
+    fence()
+    _engine.profile_begin(plan)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    smooth_ms = [r.smooth_ms for r in _engine.profile_collect(plan)]
+    assert len(smooth_ms) == steps
+    # SURVEY §8(d): dense 4*G + 4*W = 87 208 B/cell at window 100 / step 10; CSR 8*nnz_row + 8 + 4*W
+    bytes_per_cell = (4 * G + 4 * W) if fmt == "dense" else (8 * nnz_row + 8 + 4 * W)
+    avg = sum(smooth_ms) / max(len(smooth_ms), 1)
+    achieved = bytes_per_cell * n_local / (avg * 1e-3) / 1e9
+    roof = {
+        "kernel": kernel_label(fmt, window, step), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(traffic_key, n_local) if traffic_key else None,
+        "bytes_per_cell": bytes_per_cell, "kernel_ms": avg, "kernel_ms_min_max": [min(smooth_ms), max(smooth_ms)],
+        "cells_per_launch": n_local,
+    }
+    del out
+    return dt, roof
+
+
+def product_path_step(torch, _engine, plan, dm, n_local, chunksize, steps=5):
+    """The public path's variant of the step (reference :449-455 inside the chunk kernel): thresholds formed, x_res
+    left as it is, keep-mask + per-row counts (k_thr_mask), row offsets, indices / float64 values packed on the
+    device (k_csr_fill_masked).  Per-kernel milliseconds from events on the launch stream."""
+    import ctypes as C
+
+    from infercnvpy_amd import _lib
+
+    lib = _lib.load()
+    W = plan.n_windows
+    ref = (_engine.column_sums(dm)[0] / n_local).float()
+    out = _engine.alloc_out(n_local, W)
+    cap = None
+    ms = {"smooth_and_thresholds": [], "k_thr_mask": [], "row_offsets_cumsum": [], "k_csr_fill_masked": []}
+    nnz = 0
+    for it in range(steps + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        res = _engine.run_hot_path(plan, dm, ref, chunksize=chunksize, out=out, apply=False)
+        ev[1].record()
+        part = _engine.threshold_mask(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+        ev[2].record()
+        ip = torch.zeros(n_local + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(part.counts, 0, out=ip[1:])
+        ev[3].record()
+        if cap is None:  # sized once (a host round trip, outside the timed iterations)
+            nnz = int(ip[-1].item())
+            cap = (torch.empty(nnz, dtype=torch.int32, device="cuda"), torch.empty(nnz, dtype=torch.float64, device="cuda"))
+            continue
+        _lib.check(lib.icv_csr_fill_masked(_engine._ptr(part.out), n_local, W, part.out.stride(0), _engine._ptr(part.mask),
+                                           _engine._ptr(ip), _engine._ptr(cap[0]), _engine._ptr(cap[1]),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ev[4].record()
+        torch.cuda.synchronize()
+        for k, (a, b) in zip(ms, ((0, 1), (1, 2), (2, 3), (3, 4))):
+            ms[k].append(ev[a].elapsed_time(ev[b]))
+    avg = {k: sum(v) / len(v) for k, v in ms.items()}
+    total = sum(avg.values())
+    n_words = (W + 63) // 64
+    mask_bytes = (4 * W + 8 * n_words + 8) * n_local
+    fill_bytes = (4 * W + 8 * n_words + 8) * n_local + 12 * nnz
+    return {
+        "workload": f"dense fp32 {n_local} x {G}, window 100: icv_infercnv_run(NO_APPLY) + icv_threshold_mask + "
+                    f"row offsets + icv_csr_fill_masked (X_cnv as CSR float64 in HBM; reference _infercnv.py:449-455)",
+        "ms_per_step": total, "cells_per_s": n_local / (total * 1e-3), "kernel_ms": avg, "x_cnv_nnz": nnz,
+        "roofline_k_thr_mask": {"bound": "hbm", "achieved": mask_bytes / (avg["k_thr_mask"] * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": mask_bytes / (avg["k_thr_mask"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "bytes_per_launch": mask_bytes},
+        "roofline_k_csr_fill_masked": {"bound": "hbm", "achieved": fill_bytes / (avg["k_csr_fill_masked"] * 1e-3) / 1e9,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": fill_bytes / (avg["k_csr_fill_masked"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "bytes_per_launch": fill_bytes},
+        "note": "reference-mean pass excluded (shown in the main line); k_thr_mask reads x_res once, "
+                "k_csr_fill_masked reads it once more and writes 12 B per kept entry",
+    }
+
+
+def config5_leg(torch, _engine, n=100_000, d=5000, clusters=30):
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    centres = torch.randn((clusters, d), device="cuda", generator=gen) * 0.3
+    lab = torch.randint(0, clusters, (n,), device="cuda", generator=gen)
+    x = centres[lab] + 0.2 * torch.randn((n, d), device="cuda", generator=gen)
+    _engine.pairwise_sqeuclidean(x[:256].contiguous())  # warm-up
+    d2 = torch.empty((n, (n + (n + 1) // 2 + 3) // 4 * 4), dtype=torch.float32, device="cuda")[:, :n]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _engine.pairwise_sqeuclidean(x, out=d2)
+    torch.cuda.synchronize()
+    t_pd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _, rounds = _engine.ward_linkage(d2, spare=True)
+    t_w = time.perf_counter() - t0
+    tf = 1.0 * n * (n + 128) * d / t_pd / 1e12  # executed flops: tiles on / above the diagonal only
+    del d2, x
+    torch.cuda.empty_cache()
+    return {
+        "workload": f"BASELINE config 5 on one GPU at half size: X_cnv-like {n} x {d} fp32 -> squared Euclidean "
+                    f"distances (fp32 MFMA, upper-triangle tiles + mirrored copy) + Ward linkage",
+        "pdist_s": t_pd, "ward_s": t_w, "ward_rounds": rounds,
+        "roofline": {"kernel": "k_gram_mfma<DIST,SYM> (incl. centring, norms, allocation of its temporaries)",
+                     "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None},
+    }
+
+
+def extra_legs(torch, icd, _engine, GenePlan, cases, which):
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    extra = {}
+
+    def leg(name, fn):
+        if which and name not in which:
+            return
+        t0 = time.perf_counter()
+        try:
+            extra[name] = fn()
+            extra[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:  # one failing leg must not cost the main line
+            extra[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
+    def csr_leg(cells, window, label, traffic_key):
+        ip, ix, dv = synth_csr_on_device(torch, cells, G, 0.07, seed=3)
+        dm = _engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(cells, G))
+        plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
+        nnz_row = dv.numel() / cells
+        dt, roof = hbm_step(torch, icd, _engine, plan, dm, cells, "csr", window, 10, CHUNK, steps=5, warmup=2,
+                            nnz_row=nnz_row, traffic_key=traffic_key)
+        plan.close()
+        return {"workload": label, "ms_per_step": dt / 5 * 1e3, "cells_per_s": cells / (dt / 5), "steps": 5,
+                "nnz_per_cell": nnz_row, "roofline": roof}
+
+    leg("config4_csr_w250", lambda: csr_leg(
+        500_000, 250, "BASELINE config 4: CSR fp32 500000 x 20000, density 0.07, window 250, step 10, HBM resident, "
+                      "reference = all-cell mean (in the step)", "csr_w250"))
+    leg("csr_w100", lambda: csr_leg(
+        200_000, 100, "CSR fp32 200000 x 20000, density 0.07, window 100 (default arguments on 10x-style input), "
+                      "HBM resident, reference mean in the step", "csr_w100"))
+
+    def one_million():
+        X = synth_rows(torch, 0, CONFIG3_CELLS, G)
+        dm = _engine.DeviceMatrix(dense=X)
+        plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+        dt, roof = hbm_step(torch, icd, _engine, plan, dm, CONFIG3_CELLS, "dense", 100, 10, CHUNK, steps=3, warmup=1,
+                            traffic_key="dense_w100")
+        plan.close()
+        return {"workload": "BASELINE config 3's matrix on ONE GPU: dense fp32 1000000 x 20000 (80 GB resident), "
+                            "window 100 (the size north_star quotes its targets on)",
+                "ms_per_step": dt / 3 * 1e3, "cells_per_s": CONFIG3_CELLS / (dt / 3), "steps": 3, "roofline": roof}
+
+    leg("config3_cells_on_one_gpu", one_million)
+
+    def product():
+        X = synth_rows(torch, 0, CONFIG2_CELLS, G)
+        dm = _engine.DeviceMatrix(dense=X)
+        plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+        r = product_path_step(torch, _engine, plan, dm, CONFIG2_CELLS, CHUNK)
+        plan.close()
+        return r
+
+    leg("product_path_csr_pack", product)
+    leg("config5_100k", lambda: config5_leg(torch, _engine))
+    return extra
 
 
 def _free_port():
@@ -199,7 +512,11 @@ def main():
     ap.add_argument("--density", type=float, default=0.07)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--extra", default="", help="comma-separated subset of the extra legs (default: all)")
     ap.add_argument("--no-refmean", action="store_true", help="exclude the reference-mean pass from the step")
+    ap.add_argument("--dry-run-one-gpu", action="store_true",
+                    help="NOT a measurement: all ranks on cuda:0, collectives through gloo (prints \"dry_run\": true)")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -210,8 +527,9 @@ def main():
         import torch
 
         have = torch.cuda.device_count()
-        if have < args.gpus:
-            sys.exit(f"bench.py: --gpus {args.gpus} requested but this box has {have} visible GPU(s)")
+        if have < args.gpus and not args.dry_run_one_gpu:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but this box has {have} visible GPU(s) "
+                     f"(--dry-run-one-gpu exercises the N-rank code path on one GPU; it is not a measurement)")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -229,24 +547,31 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = bool(args.dry_run_one_gpu)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        if torch.cuda.device_count() <= local_rank:
-            sys.exit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()})")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            if torch.cuda.device_count() <= local_rank:
+                sys.exit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()})")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
     n_gpus = world
 
-    G = 20000
     v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
     plan = GenePlan(v["chromosome"], v["start"], window_size=args.window, step=args.step)
     W = plan.n_windows
-    n_total = args.cells if args.cells is not None else (100_000 if n_gpus == 1 else CONFIG3_CELLS)
+    default_total = CONFIG2_CELLS if n_gpus == 1 else CONFIG3_CELLS
+    n_total = args.cells if args.cells is not None else default_total
+    if dry and args.cells is None:
+        n_total = 20_000 * n_gpus  # small: every rank shares one GPU's HBM
     bounds = icd.shard_bounds(n_total, n_gpus, args.chunksize)
     row0, row1 = bounds[rank]
     n_local = row1 - row0
@@ -258,80 +583,35 @@ def main():
         ip, ix, dv = synth_csr_on_device(torch, n_local, G, args.density, seed=3 + rank)
         dm = _engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(n_local, G))
         nnz_row = dv.numel() / max(n_local, 1)
-    out = _engine.alloc_out(n_local, W)
-    sums = torch.zeros((1, G), dtype=torch.float64, device="cuda")
-    fixed_ref = None
-    if args.no_refmean:
-        fixed_ref = (_engine.column_sums(dm)[0] / n_local).float()
+        X = None
+    default_geometry = args.window == 100 and args.step == 10 and args.chunksize == CHUNK
+    traffic_key = None
+    if args.format == "dense" and default_geometry:
+        traffic_key = "dense_w100"
+    elif args.format == "csr" and args.step == 10 and args.window in (100, 250) and abs(args.density - 0.07) < 1e-9:
+        traffic_key = f"csr_w{args.window}"
 
-    def one_step():
-        if fixed_ref is None:
-            sums.zero_()
-            _engine.column_sums(dm, None, 1, sums)
-            # the only collective of the path: [G] float64 sums + the row count, over RCCL / xGMI
-            ref = icd.reference_means(sums, [n_local], "float32", device_out=True)[0] if dist is not None \
-                else (sums[0] / n_local).float()
-        else:
-            ref = fixed_ref
-        # no host synchronisation inside a step: the library records HIP events around the smoothing kernel on
-        # the launch stream (icv_profile_begin) and the times are read after the timed region
-        return icd.run_shard(plan, dm, ref, global_row0=row0, n_obs_global=n_total, lfc_clip=3.0,
-                             dynamic_threshold=1.5, chunksize=args.chunksize, all_bounds=bounds, out=out)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    _engine.profile_begin(plan)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    dt = time.perf_counter() - t0
-    smooth_ms = [r.smooth_ms for r in _engine.profile_collect(plan)]
-    assert len(smooth_ms) == args.steps
+    dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
+                        args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
+                        no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key)
+    host_group = None
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # a CPU-side group for waiting without a collective kernel spinning on the idle GPUs (the e2e leg below)
+        host_group = dist.new_group(backend="gloo")
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps)
 
-    # dense 4*G + 4*W = 87 208 B/cell at window 100 / step 10; CSR 8*nnz_row + 8 + 4*W
-    bytes_per_cell = (4 * G + 4 * W) if args.format == "dense" else (8 * nnz_row + 8 + 4 * W)
-    avg_smooth_ms = sum(smooth_ms) / max(len(smooth_ms), 1)
-    achieved = bytes_per_cell * n_local / (avg_smooth_ms * 1e-3) / 1e9
-    x16 = args.format == "dense" and args.window == 100 and args.step == 10
-    if x16:
-        kernel_name = "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10)"
-    elif args.format == "dense" and args.window == 250 and args.step == 10:
-        kernel_name = "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
-    elif (args.format == "csr" and args.window % 2 == 0
-          and args.window // math.gcd(args.step, args.window // 2) > 10):  # long windows (icv_api.hip: sd_fraction_bits)
-        kernel_name = ("k_sd_table + k_sd_base + k_smooth_sd (CSR, long windows: stored entries only, differences to "
-                       "the zero row in fixed-point block bins)")
-    elif args.format == "csr":
-        kernel_name = "k_csr_prepare + k_smooth_ws<..., CSR> (prepared entries on a zero row in LDS)"
+    if args.format == "dense" and default_geometry and n_total == default_total:
+        name = "BASELINE config 2: dense fp32" if n_gpus == 1 else "BASELINE config 3: dense fp32"
+    elif args.format == "csr" and args.window == 250 and args.step == 10 and n_total == 500_000 and n_gpus == 1:
+        name = f"BASELINE config 4: CSR fp32 density {args.density}"
     else:
-        kernel_name = "k_smooth_ws (variant for this window; generic k_smooth if the plan does not fit)"
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    # HBM bytes from the PMC counters are collected by tools/r02_round_end.sh (separate rocprofv3 --pmc passes) for
-    # the default workload and committed; they scale with the cells of a launch.  Other workloads: no counter data.
-    if os.path.exists(pmc_path) and x16:
-        try:
-            rec = json.load(open(pmc_path))
-            if "x16" in rec.get("kernel", ""):
-                traffic = rec.get("k_smooth_hbm_bytes_per_launch") * (n_local / 100_000.0)
-        except Exception:
-            traffic = None
-
+        name = ("custom (not a BASELINE configuration): " +
+                ("dense fp32" if args.format == "dense" else f"CSR fp32 density {args.density}"))
     result = {
         "metric": f"cells/sec through the tl.infercnv hot path (window={args.window}), input resident in HBM",
         "value": value,
@@ -341,14 +621,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if n_gpus > 1 else "weak",
+        # total work per N is fixed for N > 1 (config 3: 1 M cells); N = 1 runs config 2 (100 000 cells) as BASELINE
+        # asks, and the same 1 M cells on one GPU are the `extra.config3_cells_on_one_gpu` leg of the N = 1 line.
+        # The step is linear in cells, so cells/s are comparable across all N.
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",  # arithmetic type from the block sums on (np.convolve is float64); I/O is float32
         "data": "synthetic",
         "config": {
-            "workload": (("BASELINE config 2: dense fp32" if n_gpus == 1 else "BASELINE config 3: dense fp32")
-                         if args.format == "dense" else f"BASELINE config 4 style: CSR fp32 density {args.density}") +
-                        f" {n_total} cells x {G} genes (chr1..22, random var order), "
+            "workload": f"{name} {n_total} cells x {G} genes (chr1..22, random var order), "
                         f"window {args.window}, step {args.step}, chunksize {args.chunksize}, lfc_clip 3, "
                         f"dynamic_threshold 1.5, reference = all-cell mean"
                         + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)"),
@@ -356,42 +637,52 @@ def main():
             "cells_total": n_total,
             "cells_per_gpu": [b - a for a, b in bounds],
             "n_windows": W,
+            "scaling_note": "N = 1: BASELINE config 2 (100 000 cells); N > 1: config 3 (1 000 000 cells in total, "
+                            "sharded): fixed total work for N > 1",
             "parallelism": f"{n_gpus} rank(s) (torch.distributed world size "
                            f"{dist.get_world_size() if dist is not None else 1}, backend "
-                           f"{'nccl/RCCL' if dist is not None else 'none'}), row shards aligned to the chunks, one "
-                           f"all-reduce of the [G+1] float64 reference sums per step, no other collective",
+                           f"{('gloo, ALL RANKS ON cuda:0 (dry run)' if dry else 'nccl/RCCL') if dist is not None else 'none'}), "
+                           f"row shards aligned to the chunks, one all-reduce of the [G+1] float64 reference sums per "
+                           f"step, no other collective",
         },
-        "roofline": {
-            "kernel": kernel_name,
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "bytes_per_cell": bytes_per_cell,
-            "kernel_ms": avg_smooth_ms,
-            "kernel_ms_min_max": [min(smooth_ms), max(smooth_ms)],
-            "cells_per_launch": n_local,
-        },
+        "roofline": roof,
     }
-    if rank == 0 and n_gpus == 1:
+    if dry:
+        result["dry_run"] = True
+        result["dry_run_note"] = ("all ranks share ONE GPU and the collectives go through gloo and the host: code-path "
+                                  "exercise only, the numbers mean nothing")
+    del X, dm
+    torch.cuda.empty_cache()
+    if rank == 0 and n_gpus == 1 and args.format == "dense":
         if not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(window=args.window, step=args.step)
             except Exception as e:  # the GPU number must still be reported
                 result["cpu_baseline"] = {"error": repr(e)}
-        if not args.no_e2e and args.format == "dense":
-            del X, dm, out
-            torch.cuda.empty_cache()
+        if not args.no_e2e:
             try:
                 result["e2e"] = e2e_legs(torch)
             except Exception as e:
                 result["e2e"] = {"error": repr(e)}
+        if not args.no_extra and default_geometry and args.cells is None:
+            which = [w for w in args.extra.split(",") if w]
+            result["extra"] = extra_legs(torch, icd, _engine, GenePlan, cases, which)
+    if n_gpus > 1 and not args.no_e2e and args.format == "dense":
+        # the public API over all GPUs of the job, from host memory: rank 0 drives every GPU from one process while
+        # the other ranks have released their HBM and wait
+        torch.cuda.synchronize()
+        dist.barrier(group=host_group)
+        if rank == 0:
+            try:
+                devs = [0] * n_gpus if dry else list(range(n_gpus))
+                result["e2e"] = e2e_multi_gpu(torch, devs, cells_per_gpu=10_000 if dry else 100_000)
+            except Exception as e:
+                result["e2e"] = {"error": repr(e)}
+        dist.barrier(group=host_group)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 

@@ -96,8 +96,9 @@ typedef struct {
  * Concurrency: the tables of a plan are immutable after creation, but the plan also owns the per-call device
  * workspace of the compute entry points (moment partials, hand-back lists, CSR staging): ONE compute call at a
  * time per plan.  A second call entering while one is in its launch sequence fails with ICV_ERR_INVALID ("plan
- * busy") instead of racing; calls on different plans, and successive calls on one plan enqueued on the same
- * stream, are fine.
+ * busy") instead of racing.  Successive calls on one plan are ordered on the device: a call enqueued on another
+ * stream than the plan's previous call first waits (hipStreamWaitEvent) for that call's kernels, so the shared
+ * workspace is never used by two calls at once; calls on different plans are independent.
  */
 int icv_plan_create(int32_t n_cols_all, const int32_t *h_col_pos, int32_t n_chr,
                     const int32_t *h_chrom_offsets, int32_t window, int32_t step, icv_plan_t *out);
@@ -107,13 +108,26 @@ int icv_plan_get_info(icv_plan_t plan, icv_plan_info *h_info);
 int icv_plan_chr_pos(icv_plan_t plan, int32_t *h_chr_pos /* n_chr */);
 /* window table in sorted-gene coordinates: window j covers [start, start+len) */
 int icv_plan_window_table(icv_plan_t plan, int32_t *h_start /* W */, int32_t *h_len /* W */);
+/* Which smoothing kernel the plan's last compute call (icv_infercnv_smooth / _run / icv_gene_values) launched:
+ * diagnostics and tests ("this input really took the CSR stored-entries kernel"). */
+enum {
+    ICV_KERNEL_NONE = 0,
+    ICV_KERNEL_GENERIC = 1, /* k_smooth: any dtype / format / geometry that fits LDS                      */
+    ICV_KERNEL_WS = 2,      /* k_smooth_ws: dense float32, block form                                     */
+    ICV_KERNEL_WS_CSR = 3,  /* k_csr_prepare + k_smooth_ws: CSR float32, row rebuilt in LDS               */
+    ICV_KERNEL_X16 = 4,     /* k_smooth_x16: dense float32, window 100 or 250 / step 10                   */
+    ICV_KERNEL_SD = 5,      /* k_smooth_sd: CSR float32, block form, stored entries only (prefix sums)    */
+    ICV_KERNEL_SPLIT = 6    /* chromosome groups (row larger than LDS) + median on float64 windows in HBM */
+};
+int icv_plan_last_kernel(icv_plan_t plan, int32_t *h_kind);
 
 /* ---- reference profile (reference :385, :400) --------------------------------------------
  * Per-group column sums in float64.  h/d: `row_group` (device, n_rows int32; -1 = row not in
  * any group; NULL = every row in group 0).  `sums` (device, n_groups x n_cols float64) is
  * ACCUMULATED into, so shards / ranks can add up before the caller divides by the counts.
- * Dense and CSR sums are deterministic (fixed reduction order; CSR: one wavefront per row slab adds into LDS
- * accumulators in row order).
+ * Dense and CSR sums are deterministic (fixed reduction order; CSR: a 1024-thread workgroup per row slab adds ONE
+ * row at a time into float64 LDS accumulators, a barrier between rows, so every column receives its addends in
+ * row order; the slabs are then added in slab order).
  */
 int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, double *sums,
                void *stream);
@@ -228,12 +242,16 @@ int icv_corr_iqr(const float *x, int64_t n, int32_t k, int64_t ld, double *h_iqr
  * of temporary device memory.
  *
  * icv_ward_linkage: Ward linkage of the n points whose squared distances are in dist_sq (n x n float32 in
- * HBM, symmetric, row stride ld >= n; OVERWRITTEN, the spare columns of a larger stride included).  h_linkage is a HOST array of (n-1) x 4 doubles in scipy's linkage-matrix
+ * HBM, symmetric, row stride ld >= n; OVERWRITTEN).  spare_columns != 0: the caller also hands over columns
+ * [n, ld) of every row as scratch (see "Column layout" below; ld % 4 == 0 and ld >= n + (n + 1) / 2 required, else
+ * ICV_ERR_INVALID); 0: nothing outside the n x n block is touched, whatever the stride (dist_sq may be a column
+ * slice of a wider buffer).  h_linkage is a HOST array of (n-1) x 4 doubles in scipy's linkage-matrix
  * format (cluster ids, height, size; rows sorted by height).  Synchronous; *h_rounds (optional) returns
  * the number of reciprocal-nearest-neighbour rounds.  ICV_ERR_INVALID if a distance is NaN. */
 int icv_pairwise_sqeuclidean(const float *x, int64_t n, int32_t d, int64_t ld, int64_t row_begin, int64_t row_end,
                              float *out, int64_t ldo, void *stream);
-int icv_ward_linkage(float *dist_sq, int64_t n, int64_t ld, double *h_linkage, int32_t *h_rounds, void *stream);
+int icv_ward_linkage(float *dist_sq, int64_t n, int64_t ld, int32_t spare_columns, double *h_linkage,
+                     int32_t *h_rounds, void *stream);
 
 /* The same two steps for a distance matrix SHARDED by rows over several GPUs (one process per GPU; the exchanges
  * between the calls are the caller's: infercnvpy_amd/dist.py does them with torch.distributed over RCCL).
@@ -251,12 +269,13 @@ int icv_pairwise_sqeuclidean_tiles(const float *x, int64_t n, int32_t d, int64_t
                                    const int64_t *h_mir_off, float *dir, int64_t ld_dir, float *mir, int64_t ld_mir,
                                    void *stream);
 
-/* Column layout of the Ward rounds (both entry points).  When the row stride leaves at least n / 2 spare columns
- * (ld >= n + (n + 1) / 2, ld % 4 == 0) a merged cluster keeps its row but moves to a NEW column: the clusters
+/* Column layout of the Ward rounds (both entry points; chosen by the caller's spare_columns argument, never
+ * inferred from the stride).  With spare columns -- a row stride that leaves at least n / 2 of them
+ * (ld >= n + (n + 1) / 2, ld % 4 == 0) -- a merged cluster keeps its row but moves to a NEW column: the clusters
  * merged in a round take consecutive columns of the spare region, so that the update of every other row is one
  * contiguous strip instead of one 4-byte write per 128-byte line; the alive columns are compacted in place when
- * the region is full (such a matrix must be 16-byte aligned).  Smaller strides use the columns in place.  Results
- * are identical either way, bit for bit.
+ * the region is full (such a matrix must be 16-byte aligned).  Without spare columns the columns are updated in
+ * place.  Results are identical either way, bit for bit.
  *
  * Step-wise Ward rounds on a row-sharded matrix.  Every rank creates the same state (the bookkeeping is replicated
  * and deterministic); h_sr_local[g] = local super-row index of global super-row g on THIS rank (0 .. k-1) or -1
@@ -280,7 +299,7 @@ int icv_pairwise_sqeuclidean_tiles(const float *x, int64_t n, int32_t d, int64_t
  * state. */
 typedef struct icv_ward_s *icv_ward_t;
 int icv_ward_create(int64_t n, const int32_t *h_sr_local, int32_t n_super, int32_t super_shift, int64_t ld,
-                    icv_ward_t *out, void *stream);
+                    int32_t spare_columns, icv_ward_t *out, void *stream);
 void icv_ward_destroy(icv_ward_t w);
 int icv_ward_merge(icv_ward_t w, float *d_local, int64_t ld, const float *stage, int64_t ld_stage,
                    const int32_t *h_pslot, int32_t scatter, void *stream);

@@ -164,7 +164,9 @@ class SlabStream:
         self._landed = 0
         self._stream = torch.cuda.Stream()
         device = torch.cuda.current_device()  # the helper thread starts on device 0 otherwise
+        creator_stream = torch.cuda.current_stream()
         self._err = None
+        self._cancel = threading.Event()
         if sp.issparse(X):
             indptr64 = np.ascontiguousarray(X.indptr.astype(np.int64, copy=False))
             nnz = int(indptr64[-1])
@@ -190,8 +192,13 @@ class SlabStream:
         def work():
             try:
                 torch.cuda.set_device(device)
+                # the buffers were allocated on the creator's stream: whatever that stream still has queued on a
+                # recycled block (kernels of the previous slab) comes before the first copy into it
+                self._stream.wait_stream(creator_stream)
                 with torch.cuda.stream(self._stream):
                     for r0, r1 in self.bounds:
+                        if self._cancel.is_set():
+                            break
                         copy_piece(r0, r1)
                         ev = torch.cuda.Event()
                         ev.record(self._stream)
@@ -227,6 +234,22 @@ class SlabStream:
             yield self.bounds[k]
         if self._thread.is_alive():
             self._thread.join()
+
+    def close(self, cancel=False):
+        """Stop the uploader (``cancel``: skip the pieces it has not started) and drop the slab's device buffers."""
+        if cancel:
+            self._cancel.set()
+        if self._thread.is_alive():
+            self._thread.join()
+        if self.dm is not None:
+            # kernels of the consumer's stream may still read the slab: the caching allocator must not hand the
+            # blocks (allocated on the creator's stream) to anyone before those kernels have run
+            torch = _torch()
+            cur = torch.cuda.current_stream()
+            for t in self.dm._keep:
+                t.record_stream(cur)
+                t.record_stream(self._stream)
+        self.dm = None
 
 
 class PackedRows:
@@ -270,6 +293,8 @@ class CsrDrain:
         self._q = queue.Queue()
         self._stream = torch.cuda.Stream()
         self._err = None
+        self._cancel = threading.Event()
+        self._finished = False
         self.indptr_h = np.zeros(self.n_rows + 1, dtype=np.int64)
         self.indices_h = np.empty(0, dtype=np.int32)
         self.data_h = np.empty(0, dtype=np.float64)
@@ -301,6 +326,9 @@ class CsrDrain:
                         item = self._q.get()
                         if item is None:
                             return
+                        if self._cancel.is_set():  # a failed call: drop what is queued, keep draining to the sentinel
+                            del item
+                            continue
                         part, ev = item
                         t0 = time.perf_counter()
                         self._stream.wait_event(ev)
@@ -327,6 +355,12 @@ class CsrDrain:
                         self.busy_seconds += time.perf_counter() - t0
             except BaseException as e:  # surfaced in finish()
                 self._err = e
+                while True:  # keep consuming (and releasing) submitted parts until the sentinel arrives
+                    try:
+                        if self._q.get(timeout=60) is None:
+                            return
+                    except queue.Empty:
+                        return
 
         self._thread = threading.Thread(target=work, daemon=True)
         self._thread.start()
@@ -339,14 +373,28 @@ class CsrDrain:
         ev.record(torch.cuda.current_stream())
         self._q.put((part, ev))
 
-    def finish(self):
+    def finish(self, arrays=False):
+        """Wait for the queued pieces; the scipy CSR matrix of all rows, or with ``arrays=True`` its
+        ``(indptr, indices, data)`` (the caller concatenates several drains)."""
+        self._finished = True
         self._q.put(None)
         self._thread.join()
         if self._err is not None:
             raise self._err
         assert self.rows_done == self.n_rows, (self.rows_done, self.n_rows)
+        if arrays:
+            return self.indptr_h, self.indices_h[: self.nnz], self.data_h[: self.nnz]
         return sp.csr_matrix((self.data_h[: self.nnz], self.indices_h[: self.nnz], self.indptr_h),
                              shape=(self.n_rows, self.n_cols))
+
+    def close(self):
+        """Idempotent shutdown for error paths: drop queued pieces (their device buffers), stop the thread."""
+        if not self._finished:
+            self._finished = True
+            self._cancel.set()
+            self._q.put(None)
+        if self._thread.is_alive():
+            self._thread.join()
 
 
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,
@@ -452,23 +500,33 @@ def corr_iqr(x):
     return float(out.value)
 
 
-def pairwise_sqeuclidean(x, out=None, rows=None):
+def spare_stride(n):
+    """Row stride (floats) of an n x n distance matrix with the n / 2 spare columns the Ward rounds can use."""
+    return (n + (n + 1) // 2 + 3) // 4 * 4
+
+
+def has_spare_columns(dist_sq):
+    n = dist_sq.shape[0]
+    return dist_sq.stride(0) % 4 == 0 and dist_sq.stride(0) >= n + (n + 1) // 2
+
+
+def pairwise_sqeuclidean(x, out=None, rows=None, spare=False):
     """float32 squared Euclidean distances between the rows of a device matrix: the full n x n matrix, or the
-    row block ``rows = (begin, end)`` against all n rows."""
+    row block ``rows = (begin, end)`` against all n rows.  ``spare=True`` (full matrix, no ``out``): allocate the
+    result with n / 2 spare columns per row when HBM allows (6 n^2 bytes instead of 4 n^2) -- for a matrix that goes
+    on to :func:`ward_linkage` (``spare=has_spare_columns(out)``), whose rounds then write their column updates as
+    dense strips."""
     torch = _torch()
     lib = _lib.load()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     n = x.shape[0]
     r0, r1 = (0, n) if rows is None else rows
     if out is None:
-        # row stride: a multiple of 16 bytes (vector loads in the Ward rounds) and, for the full matrix when HBM
-        # allows, n / 2 spare columns (the rounds then write their column updates as dense strips)
-        ld = (n + 3) // 4 * 4
-        if rows is None:
-            ld_spare = (n + (n + 1) // 2 + 3) // 4 * 4
+        ld = (n + 3) // 4 * 4  # a multiple of 16 bytes: vector loads in the Ward rounds
+        if rows is None and spare:
             free_b, _ = torch.cuda.mem_get_info()
-            if 4 * n * ld_spare + 4 * n * (x.shape[1] + 16) + (1 << 30) < free_b:
-                ld = ld_spare
+            if 4 * n * spare_stride(n) + 4 * n * (x.shape[1] + 16) + (1 << 30) < free_b:
+                ld = spare_stride(n)
         out = torch.empty((r1 - r0, ld), dtype=torch.float32, device=x.device)[:, :n]
     assert out.shape[0] >= r1 - r0 and out.shape[1] >= n and out.stride(1) == 1
     _lib.check(lib.icv_pairwise_sqeuclidean(_ptr(x), n, x.shape[1], x.stride(0), r0, r1, _ptr(out), out.stride(0),
@@ -476,8 +534,10 @@ def pairwise_sqeuclidean(x, out=None, rows=None):
     return out
 
 
-def ward_linkage(dist_sq):
-    """scipy-format Ward linkage matrix from a device n x n squared-distance matrix (overwritten)."""
+def ward_linkage(dist_sq, spare=False):
+    """scipy-format Ward linkage matrix from a device n x n squared-distance matrix (overwritten).  ``spare=True``:
+    the columns [n, stride) of every row are the rounds' to use as well (a matrix allocated with
+    :func:`spare_stride`); False: nothing outside the n x n block is written, whatever the stride."""
     torch = _torch()
     lib = _lib.load()
     assert dist_sq.is_cuda and dist_sq.dtype == torch.float32 and dist_sq.dim() == 2 and dist_sq.stride(1) == 1
@@ -485,8 +545,8 @@ def ward_linkage(dist_sq):
     assert dist_sq.shape[1] == n
     Z = np.empty((max(n - 1, 0), 4), dtype=np.float64)
     rounds = C.c_int32(0)
-    _lib.check(lib.icv_ward_linkage(_ptr(dist_sq), n, dist_sq.stride(0), Z.ctypes.data, C.byref(rounds),
-                                    _stream_ptr(torch)))
+    _lib.check(lib.icv_ward_linkage(_ptr(dist_sq), n, dist_sq.stride(0), 1 if spare else 0, Z.ctypes.data,
+                                    C.byref(rounds), _stream_ptr(torch)))
     return Z, int(rounds.value)
 
 

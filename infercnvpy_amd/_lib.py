@@ -20,10 +20,13 @@ ICV_DENSE, ICV_CSR = 0, 1
 ICV_FLAG_TRUNC_TO_INT = 1
 ICV_FLAG_ROUND_F32 = 2
 ICV_FLAG_NO_APPLY = 4
+(ICV_KERNEL_NONE, ICV_KERNEL_GENERIC, ICV_KERNEL_WS, ICV_KERNEL_WS_CSR, ICV_KERNEL_X16, ICV_KERNEL_SD,
+ ICV_KERNEL_SPLIT) = range(7)
 
 # every symbol include/infercnv_hip.h declares
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
+    "icv_plan_last_kernel",
     "icv_colsum", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_corr_iqr",
@@ -85,6 +88,7 @@ def load():
     lib.icv_plan_get_info.argtypes = [vp, P(PlanInfo)]
     lib.icv_plan_chr_pos.argtypes = [vp, vp]
     lib.icv_plan_window_table.argtypes = [vp, vp, vp]
+    lib.icv_plan_last_kernel.argtypes = [vp, P(i32)]
     lib.icv_colsum.argtypes = [P(Matrix), vp, i32, vp, vp]
     lib.icv_infercnv_smooth.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, vp]
     lib.icv_chunk_thresholds.argtypes = [vp, i64, i64, i64, i32, dbl, vp, vp]
@@ -100,9 +104,9 @@ def load():
     lib.icv_csr_fill_masked.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, vp]
     lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]
-    lib.icv_ward_linkage.argtypes = [vp, i64, i64, vp, P(i32), vp]
+    lib.icv_ward_linkage.argtypes = [vp, i64, i64, i32, vp, P(i32), vp]
     lib.icv_pairwise_sqeuclidean_tiles.argtypes = [vp, i64, i32, i64, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp]
-    lib.icv_ward_create.argtypes = [i64, vp, i32, i32, i64, P(vp), vp]
+    lib.icv_ward_create.argtypes = [i64, vp, i32, i32, i64, i32, P(vp), vp]
     lib.icv_ward_destroy.argtypes = [vp]
     lib.icv_ward_destroy.restype = None
     lib.icv_ward_merge.argtypes = [vp, vp, i64, vp, i64, vp, i32, vp]

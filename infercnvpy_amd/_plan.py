@@ -130,6 +130,12 @@ class GenePlan:
         _lib.check(_lib.load().icv_plan_window_table(self._handle, st.ctypes.data, ln.ctypes.data))
         return st, ln
 
+    def last_kernel(self) -> int:
+        """``_lib.ICV_KERNEL_*`` of the smoothing kernel the last compute call on this plan launched."""
+        kind = C.c_int32(0)
+        _lib.check(_lib.load().icv_plan_last_kernel(self._handle, C.byref(kind)))
+        return int(kind.value)
+
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
             _lib.load().icv_plan_destroy(self._handle)

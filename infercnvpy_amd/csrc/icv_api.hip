@@ -80,6 +80,12 @@ struct icv_plan_s {
     std::vector<icv_plan_s*> parts;
     std::vector<int> part_woff;  // first window of every group in the full window list
     int parts_elem = 0;          // element size the groups were sized for (0: not built)
+    int last_kernel = ICV_KERNEL_NONE;  // smoothing kernel of the last compute call (icv_plan_last_kernel)
+    // the per-call workspace above is shared by all calls on this plan: a call on another stream than the previous
+    // one first waits (on the device) for the previous call's work
+    hipEvent_t done_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
 };
 
 namespace {
@@ -88,11 +94,31 @@ namespace {
 struct PlanBusy {
     icv_plan_t pl;
     bool ok;
+    hipStream_t st = nullptr;
+    bool entered = false;
     explicit PlanBusy(icv_plan_t p) : pl(p), ok(false) {
         bool expected = false;
         ok = p && p->busy.compare_exchange_strong(expected, true);
     }
+    // Work of the previous call on this plan may still be in flight on ANOTHER stream and uses the same workspace
+    // (row list, partial moments, zero row): this call's stream waits for it.  Same stream: already ordered.
+    hipError_t enter(hipStream_t s) {
+        st = s;
+        entered = true;
+        if (!pl->done_ev) {
+            const hipError_t e = hipEventCreateWithFlags(&pl->done_ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        if (pl->has_last && pl->last_stream != s) return hipStreamWaitEvent(s, pl->done_ev, 0);
+        return hipSuccess;
+    }
     ~PlanBusy() {
+        if (ok && entered && pl->done_ev) {
+            if (hipEventRecord(pl->done_ev, st) == hipSuccess) {
+                pl->last_stream = st;
+                pl->has_last = true;
+            }
+        }
         if (ok) pl->busy.store(false);
     }
 };
@@ -100,6 +126,8 @@ struct PlanBusy {
     PlanBusy busy_guard_(pl);                                                                        \
     if (!busy_guard_.ok)                                                                             \
         return fail(ICV_ERR_INVALID, "plan busy: one compute call at a time per plan (see icv_plan_create)")
+// after ensure_device: order this call behind the plan's previous call if that ran on another stream
+#define PLAN_ENTER(stream_) HIP_TRY(busy_guard_.enter(static_cast<hipStream_t>(stream_)))
 
 // stream-ordered temporary: freed on every exit path (error paths leaked their buffers)
 struct AsyncBuf {
@@ -359,13 +387,15 @@ bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K
            ((p.B == 10 && p.window == 100 && p.x16_fine == 4096) || (p.B == 5 && p.window == 250 && p.x16_fine == 1024));
 }
 
-// CSR input with long windows: fraction bits of the fixed-point bins of k_smooth_sd, or -1 when the kernel does not
-// apply.  A bin holds at most B entries: |S0| <= B * 2 cap * 2^k and |S1| <= B (B - 1) / 2 * 2 cap * 2^k must stay
-// below 2^62; fewer than 46 fraction bits (a clip value beyond ~1e3) would no longer be negligible next to the
-// float64 rounding of the windows.
+// CSR float32 input in block form: fraction bits of the fixed-point bins of k_smooth_sd, or -1 when the kernel does
+// not apply (geometry: Plan::sd_ok).  A bin holds at most B entries: |S0| <= B * 2 cap * 2^k and
+// |S1| <= B (B - 1) / 2 * 2 cap * 2^k must stay below 2^62; fewer than 46 fraction bits (a clip value beyond ~1e3)
+// would no longer be negligible next to the float64 rounding of the windows.
 int sd_fraction_bits(const icv::Plan& p, double cap) {
-    if (!(p.window % 2 == 0 && p.B > 1 && p.window / p.B > 10 && p.NB <= 4096 && p.W <= 4 * icv::NT)) return -1;
-    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the CSR kernel that builds the row in LDS (k_smooth_ws)
+    if (!p.sd_ok) return -1;
+    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the CSR kernels that build the row in LDS
+    if (const char* e = std::getenv("ICV_SD_MIN_NBW"))  // developer knob: only windows of more than this many blocks
+        if (p.window / p.B <= std::atoi(e)) return -1;
     const double per_bin = (double)p.B * (double)(p.B > 3 ? p.B - 1 : 2) * cap + 1.0;
     int e = 0;
     (void)std::frexp(per_bin, &e);  // per_bin < 2^e
@@ -374,6 +404,93 @@ int sd_fraction_bits(const icv::Plan& p, double cap) {
     (void)std::frexp(2.0 * cap + 1.0, &e);
     if (k > 51 - e) k = 51 - e;
     return k >= 46 ? k : -1;
+}
+
+// plan-owned workspace of the kernels that hand cells back to the generic k_smooth: the list of those cells, its
+// counter (zeroed here) and the per-wavefront partial moments
+int hand_back_workspace(icv_plan_t pl, icv::KParams& K, hipStream_t st) {
+    if (pl->row_list_cap < K.n_rows) {
+        (void)hipFree(pl->d_row_list);
+        pl->d_row_list = nullptr;
+        pl->row_list_cap = 0;
+        HIP_TRY(hipMalloc((void**)&pl->d_row_list, (size_t)K.n_rows * sizeof(int64_t)));
+        pl->row_list_cap = K.n_rows;
+    }
+    if (pl->cell_part_cap < K.n_rows) {
+        (void)hipFree(pl->d_cell_part);
+        pl->d_cell_part = nullptr;
+        pl->cell_part_cap = 0;
+        // 16 wavefront partial pairs per cell (k_smooth_x16; k_smooth_ws / k_smooth_sd use the first 8)
+        HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 32 * sizeof(double)));
+        pl->cell_part_cap = K.n_rows;
+    }
+    K.cell_part = pl->d_cell_part;
+    if (!pl->d_row_count) HIP_TRY(hipMalloc((void**)&pl->d_row_count, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
+    K.row_list = pl->d_row_list;
+    K.row_count = pl->d_row_count;
+    return ICV_OK;
+}
+
+// cells a fast kernel handed back (more than 64 windows in the median bins, a stored NaN): the generic kernel
+// recomputes them (it reads the device-side count and exits at once when the list is empty)
+int launch_hand_back(icv_plan_t pl, const icv::KParams& K, hipStream_t st, bool csr) {
+    const icv::Plan& p = pl->p;
+    icv::KParams G = K;
+    G.win_off = p.lay32.win_off;
+    G.scratch_off = p.lay32.scratch_off;
+    G.dbg = nullptr;
+    const int need = (p.NB + icv::kThreads - 1) / icv::kThreads;
+    void (*gk)(const icv::KParams);
+    if (csr) gk = need <= 4 ? icv::k_smooth<float, true, 4> : icv::k_smooth<float, true, 8>;
+    else gk = need <= 4 ? icv::k_smooth<float, false, 4> : icv::k_smooth<float, false, 8>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                p.lay32.total));
+    int64_t g2 = pl->n_cu;
+    if (g2 > K.n_rows) g2 = K.n_rows;
+    hipLaunchKernelGGL(gk, dim3((unsigned)g2), dim3(icv::NT), p.lay32.total, st, G);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+// CSR float32 input, block form (Plan::sd_ok): k_smooth_sd touches the stored entries only -- their differences to
+// the zero row go into fixed-point block bins, windows come off prefix sums (icv_kernel_sd.hpp)
+int launch_smooth_sd(icv_plan_t pl, icv::KParams K, int sd_k, hipStream_t st, hipEvent_t kernel_done = nullptr) {
+    const icv::Plan& p = pl->p;
+    AsyncBuf tab_guard, base_guard;  // per-column table, zero-row window sums: released on every exit path
+    const int nz = (int)pl->zrow_elems;
+    hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
+                       static_cast<float*>(pl->d_zrow), nz);
+    HIP_TRY(tab_guard.alloc((size_t)K.n_cols * 16, st));
+    HIP_TRY(base_guard.alloc((size_t)p.W * sizeof(double), st));
+    K.sd_tab = tab_guard.p;
+    K.sd_base = base_guard.as<double>();
+    K.sd_scale = std::ldexp(1.0, sd_k);
+    K.sd_qinv = std::ldexp(1.0, -sd_k);
+    K.sd_window = p.window;
+    hipLaunchKernelGGL(icv::k_sd_table, dim3((unsigned)((K.n_cols + 255) / 256)), dim3(256), 0, st, K,
+                       tab_guard.as<icv::u32x4>());
+    hipLaunchKernelGGL(icv::k_sd_base, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, st, K,
+                       static_cast<const float*>(pl->d_zrow), base_guard.as<double>());
+    if (int rc = hand_back_workspace(pl, K, st)) return rc;
+    int per_cu = icv::kLdsLimit / icv::kSdLds;
+    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
+        const int v = std::atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    int64_t grid = (int64_t)pl->n_cu * per_cu;
+    if (grid > K.n_rows) grid = K.n_rows;
+    if (grid < 1) {
+        if (kernel_done) HIP_TRY(hipEventRecord(kernel_done, st));
+        return ICV_OK;
+    }
+    int rc = run_kernel(icv::k_smooth_sd<4>, grid, icv::kSdLds, K, st);
+    if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
+    if (rc) return rc;
+    hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
+                       K.n_rows, K.cell_stats);
+    pl->last_kernel = ICV_KERNEL_SD;
+    return launch_hand_back(pl, K, st, true);
 }
 
 // float32, blocked form, small enough geometry: register-prefetch kernels (dense or prepared CSR)
@@ -386,9 +503,9 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     void (*kern)(const icv::KParams) = nullptr;
     constexpr int U = icv::kFastUMax;
     K.scratch_off = p.fast_scratch_off;
-    AsyncBuf ws_guard, base_guard;  // prepared CSR entries, zero-row window sums: released on every exit path
+    AsyncBuf ws_guard;  // prepared CSR entries: released on every exit path
     void* ws_buf = nullptr;
-    int lds = p.fast_lds;
+    const int lds = p.fast_lds;
     if (!p.ws_ok) return -1;  // caller falls back to the generic kernel
     {
         const bool u10 = (p.B == 10 && p.window == 100);
@@ -397,64 +514,27 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             else if (p.B == 5 && p.window == 250) kern = icv::k_smooth_ws<U, 8, 4, 5, 50, false>;
             else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, false> : icv::k_smooth_ws<U, 8, 4, 0, 0, false>;
         } else {
-            const int sd_k = sd_fraction_bits(p, K.cap);
             const int nz = (int)pl->zrow_elems;
             hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
                                static_cast<float*>(pl->d_zrow), nz);
             const int64_t n = csr_end - csr_begin;
             int64_t g = (n + 255) / 256;
             if (g > 8192) g = 8192;
-            if (sd_k >= 0) {
-                // long windows: the stored entries as they are, differences to the zero row in block bins (k_smooth_sd)
-                kern = icv::k_smooth_sd<4>;
-                lds = icv::kSdLds;
-                HIP_TRY(ws_guard.alloc((size_t)K.n_cols * 16, st));  // per-column table
-                HIP_TRY(base_guard.alloc((size_t)p.W * sizeof(double), st));
-                ws_buf = ws_guard.p;
-                K.sd_tab = ws_buf;
-                K.sd_base = base_guard.as<double>();
-                K.sd_scale = std::ldexp(1.0, sd_k);
-                K.sd_qinv = std::ldexp(1.0, -sd_k);
-                K.sd_window = p.window;
-                hipLaunchKernelGGL(icv::k_sd_table, dim3((unsigned)((K.n_cols + 255) / 256)), dim3(256), 0, st, K,
-                                   static_cast<icv::u32x4*>(ws_buf));
-                hipLaunchKernelGGL(icv::k_sd_base, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, st, K,
-                                   static_cast<const float*>(pl->d_zrow), base_guard.as<double>());
-            } else {
-                if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
-                else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
-                // prepared entries {LDS position, centred and clipped value} on top of the zero row
-                HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));
-                ws_buf = ws_guard.p;
-                float* cv = static_cast<float*>(ws_buf);
-                uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
-                K.cvals = cv - csr_begin;  // indexed by the absolute entry number
-                K.pos16 = ps - csr_begin;
-                if (n > 0)
-                    hipLaunchKernelGGL(icv::k_csr_prepare, dim3((unsigned)g), dim3(256), 0, st, K, csr_begin, csr_end,
-                                       const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
-            }
+            if (need_b <= 4) kern = u10 ? icv::k_smooth_ws<U, 4, 4, 10, 10, true> : icv::k_smooth_ws<U, 4, 4, 0, 0, true>;
+            else kern = (p.B == 5) ? icv::k_smooth_ws<U, 8, 4, 5, 0, true> : icv::k_smooth_ws<U, 8, 4, 0, 0, true>;
+            // prepared entries {LDS position, centred and clipped value} on top of the zero row
+            HIP_TRY(ws_guard.alloc((size_t)(n > 0 ? n : 1) * 6, st));
+            ws_buf = ws_guard.p;
+            float* cv = static_cast<float*>(ws_buf);
+            uint16_t* ps = reinterpret_cast<uint16_t*>(cv + (n > 0 ? n : 1));
+            K.cvals = cv - csr_begin;  // indexed by the absolute entry number
+            K.pos16 = ps - csr_begin;
+            if (n > 0)
+                hipLaunchKernelGGL(icv::k_csr_prepare, dim3((unsigned)g), dim3(256), 0, st, K, csr_begin, csr_end,
+                                   const_cast<uint16_t*>(K.pos16), const_cast<float*>(K.cvals));
         }
         K.hist_off = p.ws_hist_off;
-        if (pl->row_list_cap < K.n_rows) {
-            (void)hipFree(pl->d_row_list);
-            pl->d_row_list = nullptr;
-            HIP_TRY(hipMalloc((void**)&pl->d_row_list, (size_t)K.n_rows * sizeof(int64_t)));
-            pl->row_list_cap = K.n_rows;
-        }
-        if (pl->cell_part_cap < K.n_rows) {
-            (void)hipFree(pl->d_cell_part);
-            pl->d_cell_part = nullptr;
-            pl->cell_part_cap = 0;
-            // 16 wavefront partial pairs per cell (k_smooth_x16; k_smooth_ws uses the first 8)
-            HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 32 * sizeof(double)));
-            pl->cell_part_cap = K.n_rows;
-        }
-        K.cell_part = pl->d_cell_part;
-        if (!pl->d_row_count) HIP_TRY(hipMalloc((void**)&pl->d_row_count, sizeof(int)));
-        HIP_TRY(hipMemsetAsync(pl->d_row_count, 0, sizeof(int), st));
-        K.row_list = pl->d_row_list;
-        K.row_count = pl->d_row_count;
+        if (int rc = hand_back_workspace(pl, K, st)) return rc;
     }
     int per_cu = icv::kLdsLimit / lds;
     if (per_cu > 4) per_cu = 4;
@@ -501,23 +581,8 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
                            K.cell_part, K.n_rows, K.cell_stats);
     }
-    // cells whose median bins held more than 64 windows: recompute them with the generic kernel
-    // (reads the device-side count; exits at once when the list is empty)
-    icv::KParams G = K;
-    G.win_off = p.lay32.win_off;
-    G.scratch_off = p.lay32.scratch_off;
-    G.dbg = nullptr;
-    const int need = (p.NB + icv::kThreads - 1) / icv::kThreads;
-    void (*gk)(const icv::KParams);
-    if (csr) gk = need <= 4 ? icv::k_smooth<float, true, 4> : icv::k_smooth<float, true, 8>;
-    else gk = need <= 4 ? icv::k_smooth<float, false, 4> : icv::k_smooth<float, false, 8>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                p.lay32.total));
-    int64_t g2 = pl->n_cu;
-    if (g2 > K.n_rows) g2 = K.n_rows;
-    hipLaunchKernelGGL(gk, dim3((unsigned)g2), dim3(icv::NT), p.lay32.total, st, G);
-    HIP_TRY(hipGetLastError());
-    return ICV_OK;
+    pl->last_kernel = xk ? ICV_KERNEL_X16 : (csr ? ICV_KERNEL_WS_CSR : ICV_KERNEL_WS);
+    return launch_hand_back(pl, K, st, csr);
 }
 
 template <typename T, bool CSR>
@@ -625,24 +690,33 @@ int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipS
 int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
                   hipStream_t st, hipEvent_t kernel_done = nullptr, bool* recorded = nullptr) {
     if (recorded) *recorded = false;
-    if (!lay.fits) return smooth_split(pl, m, K, st);
-    if (m->dtype == ICV_F32 && m->format == ICV_DENSE && pl->p.ws_ok && K.vec_ok && std::isfinite(K.cap) &&
-        !std::getenv("ICV_FORCE_GENERIC"))
-    {
+    if (!lay.fits) {
+        pl->last_kernel = ICV_KERNEL_SPLIT;
+        return smooth_split(pl, m, K, st);
+    }
+    const bool fast_allowed = m->dtype == ICV_F32 && std::isfinite(K.cap) && !std::getenv("ICV_FORCE_GENERIC");
+    if (fast_allowed && m->format == ICV_DENSE && pl->p.ws_ok && K.vec_ok) {
         const int rc = launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
         if (rc >= 0) {
             if (recorded) *recorded = kernel_done != nullptr;
             return rc;
         }
     }
-    if (m->dtype == ICV_F32 && m->format == ICV_CSR && pl->p.ws_ok && std::isfinite(K.cap) &&
-        m->csr_end > m->csr_begin && aligned16(K.ref_lo) && !std::getenv("ICV_FORCE_GENERIC")) {
-        const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
-        if (rc >= 0) {
+    if (fast_allowed && m->format == ICV_CSR && m->csr_end > m->csr_begin) {
+        const int sd_k = sd_fraction_bits(pl->p, K.cap);
+        if (sd_k >= 0) {
             if (recorded) *recorded = kernel_done != nullptr;
-            return rc;
+            return launch_smooth_sd(pl, K, sd_k, st, kernel_done);
+        }
+        if (pl->p.ws_ok && aligned16(K.ref_lo)) {
+            const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
+            if (rc >= 0) {
+                if (recorded) *recorded = kernel_done != nullptr;
+                return rc;
+            }
         }
     }
+    pl->last_kernel = ICV_KERNEL_GENERIC;
     if (m->dtype == ICV_F32)
         return m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, lay, st)
                                       : launch_smooth_t<float, true>(pl, K, lay, st);
@@ -728,6 +802,7 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_w_srel);
         (void)hipFree(pl->d_blk_g0);
         (void)hipFree(pl->d_zrow);
+        if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
     }
     delete pl;
 }
@@ -748,6 +823,12 @@ int icv_plan_get_info(icv_plan_t pl, icv_plan_info* info) {
     info->lds_bytes_f64 = p.lay64.total;
     int per_cu = p.lay32.fits ? icv::kLdsLimit / p.lay32.total : 0;
     info->workgroups_per_cu_f32 = per_cu > 4 ? 4 : per_cu;
+    return ICV_OK;
+}
+
+int icv_plan_last_kernel(icv_plan_t pl, int32_t* kind) {
+    if (!pl || !kind) return fail(ICV_ERR_INVALID, "null argument");
+    *kind = pl->last_kernel;
     return ICV_OK;
 }
 
@@ -834,6 +915,7 @@ int icv_infercnv_smooth(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, 
     PLAN_BUSY_GUARD(pl);
     if (!cell_median || !cell_stats) return fail(ICV_ERR_INVALID, "cell_median and cell_stats are required");
     if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
     icv::KParams K;
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
@@ -861,6 +943,7 @@ int icv_apply_threshold(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, 
     PLAN_BUSY_GUARD(pl);
     if (!cell_median || !thr || chunksize < 1) return fail(ICV_ERR_INVALID, "bad apply_threshold arguments");
     if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
     icv::KParams K;
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, const_cast<double*>(cell_median),
@@ -881,6 +964,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
         return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");
     if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     icv::KParams K;
     const icv::Layout* lay;
@@ -1003,6 +1087,7 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     if (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
         return fail(ICV_ERR_INVALID, "chunksize / row_phase invalid");
     if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
     const icv::Plan& p = pl->p;
     const int64_t n = m->n_rows;
     if (n < 1) return ICV_OK;
@@ -1023,6 +1108,7 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out32, W, cmed, cstat, K, lay))) return rc;
     K.win_out = win;
     K.win_ld = W;
+    pl->last_kernel = lay->fits ? ICV_KERNEL_GENERIC : ICV_KERNEL_SPLIT;
     if (!lay->fits)
         rc = split_windows(pl, m, K, win, st);
     else if (m->dtype == ICV_F32)
@@ -1065,6 +1151,7 @@ int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
     if (!cell_median || !mask || !row_nnz || (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize)))
         return fail(ICV_ERR_INVALID, "bad threshold_mask arguments");
     if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
     icv::KParams K;
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, const_cast<float*>(out), ldo,
@@ -1349,15 +1436,19 @@ struct icv_ward_s {
 };
 
 namespace {
-int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, int64_t ld, hipStream_t st,
-                icv_ward_s** out) {
+int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, int64_t ld, bool spare,
+                hipStream_t st, icv_ward_s** out) {
     if (n < 2 || n > 0x7fffffff / 2 || !out || ld < n) return fail(ICV_ERR_INVALID, "bad ward arguments");
+    if (spare && (ld % 4 != 0 || ld < n + (n + 1) / 2))
+        return fail(ICV_ERR_INVALID, "ward: spare columns need a row stride that is a multiple of 4 and >= n + (n + 1) / 2");
     if (sr_local && (n_super < 1 || super_shift < 2 || super_shift > 20 || ((int64_t)n_super << super_shift) < n))
         return fail(ICV_ERR_INVALID, "bad ward storage map");
     std::unique_ptr<icv_ward_s> w(new icv_ward_s);
     w->n = n;
     w->ld = ld;
-    w->strip = ld % 4 == 0 && ld >= n + (n + 1) / 2 && !std::getenv("ICV_WARD_IN_PLACE");
+    // the caller says whether columns [n, ld) of every row are the rounds' to use (never inferred from the stride: a
+    // column slice of a wider buffer has a large stride too); ICV_WARD_IN_PLACE: developer knob, the other layout
+    w->strip = spare && !std::getenv("ICV_WARD_IN_PLACE");
     w->cap = w->strip ? (int)std::min<int64_t>(ld, 2 * n) : (int)n;
     const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
     const size_t parr = ((size_t)w->cap * 4 + 255) / 256 * 256;  // arrays indexed by column position
@@ -1606,14 +1697,15 @@ int ward_finish(icv_ward_s* w, double* h_linkage) {
 
 extern "C" {
 
-int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, int32_t* h_rounds, void* stream) {
+int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, int32_t spare_columns, double* h_linkage,
+                     int32_t* h_rounds, void* stream) {
     if (!dist_sq || !h_linkage || n < 1 || ld < n || n > 0x7fffffff / 2)
         return fail(ICV_ERR_INVALID, "bad ward_linkage arguments");
     if (h_rounds) *h_rounds = 0;
     if (n == 1) return ICV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     icv_ward_s* raw = nullptr;
-    if (int rc = ward_create(n, nullptr, 0, 0, ld, st, &raw)) return rc;
+    if (int rc = ward_create(n, nullptr, 0, 0, ld, spare_columns != 0, st, &raw)) return rc;
     std::unique_ptr<icv_ward_s> w(raw);
     bool retry = false;
     while (w->h.n_live > 1) {
@@ -1638,8 +1730,9 @@ int icv_ward_linkage(float* dist_sq, int64_t n, int64_t ld, double* h_linkage, i
 }
 
 int icv_ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t super_shift, int64_t ld,
+                    int32_t spare_columns,
                     icv_ward_t* out, void* stream) {
-    return ward_create(n, sr_local, n_super, super_shift, ld, static_cast<hipStream_t>(stream), out);
+    return ward_create(n, sr_local, n_super, super_shift, ld, spare_columns != 0, static_cast<hipStream_t>(stream), out);
 }
 void icv_ward_destroy(icv_ward_t w) { delete w; }
 

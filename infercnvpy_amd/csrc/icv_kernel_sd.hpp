@@ -158,6 +158,13 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         sc->ma = 0.0;
         sc->mb = 0.0;
     }
+    if (t < NWAVE) {  // wavefronts whose blocks 512 w .. 512 w + 511 lie past the last block never publish totals
+        sc->psum[t] = 0.0;
+        sc->psq[t] = 0.0;
+    }
+    // this wavefront owns blocks at all (wavefront-uniform): geometries with few blocks (window 100: 2 000) skip the
+    // zeroing and the scan of the planes' unused tail
+    const bool wblk = ((t & ~63) * 8) < NB;
     // per-thread tables, re-read from L2 in every cell (as loop-carried registers they end up in scratch): window
     // descriptor, gene offset and zero-row sum of windows t, t + 512, ...; first-gene offsets of blocks 8 t .. 8 t + 7
     const __amdgpu_buffer_rsrc_t wp_rs = make_rsrc(P.w_pack, (unsigned)W * 4u);
@@ -235,7 +242,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
         const int64_t nxt = cell + gridDim.x;
 #pragma unroll
         for (int i = 0; i < kSdPF; ++i) etab[i] = __builtin_amdgcn_raw_buffer_load_b128(tab_rs, nidx[i] * 16u, 0, 0);
-        if (more) {
+        if (more && wblk) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) reinterpret_cast<int4*>(SP)[k * kWsPlane + tl] = make_int4(0, 0, 0, 0);
         }
@@ -377,7 +384,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_sd(const KParams P) {
             }
         }
         ICV_SDP(11)
-        if (more) {
+        if (more && wblk) {
             const int g0v[8] = {(int)g0a.x, (int)g0a.y, (int)g0a.z, (int)g0a.w, (int)g0b.x, (int)g0b.y, (int)g0b.z, (int)g0b.w};
             // {S0, T1 = sum of g d} of the thread's blocks 8 t .. 8 t + 7 (g: gene offset inside the chromosome); their
             // prefix sums over the blocks of this WAVEFRONT go back in place, the wavefront's total to the scratch:

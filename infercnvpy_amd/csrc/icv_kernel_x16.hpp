@@ -159,19 +159,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             if constexpr (REFRES) refv[u] = __builtin_amdgcn_raw_buffer_load_b128(ref_rs, voff, u * XT * 16, 0);
             const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, (unsigned)t * 8u, u * XT * 8, 0);
 #if ICV_X_ADDR
-#ifdef ICV_X_EXP_LINSCAT  // timing experiment (wrong results): conflict-free scatter addresses
-            laddr[u][0] = ((unsigned)(u * 4 + 0) * 1000u + (unsigned)t) * 4u;
-            laddr[u][1] = ((unsigned)(u * 4 + 1) * 1000u + (unsigned)t) * 4u;
-            laddr[u][2] = ((unsigned)(u * 4 + 2) * 1000u + (unsigned)t) * 4u;
-            laddr[u][3] = ((unsigned)(u * 4 + 3) * 1000u + (unsigned)t) * 4u;
-            if (t >= 1000) laddr[u][0] = laddr[u][1] = laddr[u][2] = laddr[u][3] = 80000u;
-            (void)d;
-#else
             laddr[u][0] = (d.x & 0xffffu) * 4u;
             laddr[u][1] = (d.x >> 16) * 4u;
             laddr[u][2] = (d.y & 0xffffu) * 4u;
             laddr[u][3] = (d.y >> 16) * 4u;
-#endif
 #else
             dtab[u] = d;
 #endif
@@ -220,17 +211,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     // centre, clip and scatter the row in xq, re-requesting every vector for cell `c_next` as it is consumed
     auto l_phase = [&](int64_t c_next) __attribute__((always_inline)) {
         const bool more = c_next < P.n_rows;
-#ifdef ICV_X_EXP_NOLOAD  // timing experiment (wrong results): no HBM row traffic, the first row is reused
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase, 0u);
-        (void)more;
-        (void)xr;
-#else
-#ifdef ICV_X_EXP_L2ROW  // timing experiment (wrong results): every cell re-reads the workgroup's first row (L2 hits)
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, more ? row_bytes : 0u);
-#else
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (more ? c_next : 0) * P.ld, more ? row_bytes : 0u);
-#endif
-#endif
         u32x4 rloc[REFRES ? 1 : XU];
         if constexpr (!REFRES) {
 #pragma unroll
@@ -270,11 +251,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 if (y3 != y3) row[dy >> 16] = y3;
             }
 #endif
-#ifndef ICV_X_EXP_NOLOAD
             xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);  // out of range: zeros, no traffic
-#else
-            asm volatile("" : "+v"(xq[u]));
-#endif
         }
     };
 
@@ -332,11 +309,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 
         // =============================== phase A ================================================
         const int ts = tl - XT / 2;  // wavefronts 8..15 (wavefronts 0, 1 carry the median chains of this phase)
-#ifdef ICV_X_EXP_NOSTORE
-        if (st16 && it >= 3 && ts >= 0 && 4 * ts < W && P.dbg) {
-#else
         if (st16 && it >= 3 && ts >= 0 && 4 * ts < W) {
-#endif
             // ---- x_res of cell it-3, staged in LDS by phase B of the previous iteration: one 16-byte store ----
             float* orow = P.out + (cell - 3 * (int64_t)gridDim.x) * P.ldo;
             const float4 q = *reinterpret_cast<const float4*>(stage + 4 * ts);
@@ -675,16 +648,13 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             wbA = (unsigned)(w0 ? h0 : 0xffff) | ((unsigned)(w1 ? h1 : 0xffff) << 16);
             unsigned* fz = hist + p0 * XFINE;
             unsigned* cz = coarse + p0 * (XREP * XCOARSE) + (tl & (XREP - 1));
-#ifndef ICV_X_EXP_NOATOM  // timing experiment (wrong medians): 1 = no coarse atomics, 2 = no atomics at all
-#define ICV_X_EXP_NOATOM 0
-#endif
             if (w0) {
-                if (ICV_X_EXP_NOATOM < 2) atomicAdd(fz + h0, 1u);
-                if (ICV_X_EXP_NOATOM < 1) atomicAdd(cz + (h0 >> 6) * XREP, 1u);
+                atomicAdd(fz + h0, 1u);
+                atomicAdd(cz + (h0 >> 6) * XREP, 1u);
             }
             if (w1) {
-                if (ICV_X_EXP_NOATOM < 2) atomicAdd(fz + h1, 1u);
-                if (ICV_X_EXP_NOATOM < 1) atomicAdd(cz + (h1 >> 6) * XREP, 1u);
+                atomicAdd(fz + h1, 1u);
+                atomicAdd(cz + (h1 >> 6) * XREP, 1u);
             }
             const double vs = w1 ? v0 + v1 : v0;  // NaN in either window (|window| is bounded: no inf - inf)
             if (w0 && vs != vs) sc->nanflag[p0] = 1;  // benign race: every writer stores 1

@@ -723,9 +723,19 @@ __global__ void __launch_bounds__(256) k_chunk_thr_part(const double* chunk_part
 
 // ---------------------------------------------------------------------------------------
 // step 5b: zero |x| < thr, decided in float64 (reference :451).  The stored float32 value
-// decides except when it ties with float32(thr): then the window is recomputed from the input
-// with the canonical evaluation order above (bit-identical to k_smooth) and compared in float64.
+// decides except when it lies within one float32 ulp of float32(thr): then the window is recomputed
+// from the input with the canonical evaluation order above (bit-identical to k_smooth) and compared
+// in float64.  The one-ulp band makes the decision independent of the smoothing kernel that wrote
+// x_res: k_smooth_sd sums its windows in another float64 order (equal to ~1e-12), so its float32
+// value can differ from the canonical one in the last bit.
 // ---------------------------------------------------------------------------------------
+// |y| against the float32 threshold: -1 below, +1 above, 0 float32 cannot decide (a NaN threshold or value: +1)
+__device__ __forceinline__ int thr_compare(float a, float thf) {
+    if (!(thf == thf) || !(a == a)) return 1;
+    const int d = __float_as_int(a) - __float_as_int(thf);  // both non-negative: the bit patterns are ordered
+    return d < -1 ? -1 : (d > 1 ? 1 : 0);
+}
+
 // clipped, centred value of padded position pp of one cell, re-read from the input matrix
 template <typename T, bool CSR>
 __device__ double value_at(const KParams& P, int64_t cell, int pp) {
@@ -783,9 +793,11 @@ __global__ void __launch_bounds__(256) k_apply_thr(const KParams P, const double
     __syncthreads();
     // returns the value to store for window j (0 below the threshold); ties are queued / resolved exactly
     auto decide = [&](int j, float y) -> float {
+        if (y == 0.0f) return y;  // zero either way
         const float a = fabsf(y);
-        if (a < thf) return 0.0f;
-        if (a == thf) {
+        const int cmp = thr_compare(a, thf);
+        if (cmp < 0) return 0.0f;
+        if (cmp == 0) {
             // float32 cannot decide: queue the window for an exact float64 recomputation
             const int idx = atomicAdd(&tie_n, 1);
             if (idx < 32) {
@@ -877,8 +889,9 @@ __global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double*
             const float a = fabsf(y);
             keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
             if (has_thr) {
-                if (a < thf) keep = false;
-                else if (a == thf) {  // float32 cannot decide: exact float64 recomputation below
+                const int cmp = thr_compare(a, thf);
+                if (cmp < 0) keep = false;
+                else if (cmp == 0 && keep) {  // float32 cannot decide: exact float64 recomputation below
                     const int idx = atomicAdd(&tie_n, 1);
                     if (idx < 32) {
                         tie_j[idx] = j;

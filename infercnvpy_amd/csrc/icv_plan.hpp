@@ -63,6 +63,7 @@ struct Plan {
     double pyr_den = 1.0, pyr_rcp = 1.0;
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
     bool ws_ok = false;              // ... and the wave-specialised k_smooth_ws
+    bool sd_ok = false;              // geometry admits k_smooth_sd (CSR float32 input: stored entries only)
     int fast_lds = 0, fast_scratch_off = 0, ws_win_off = 0, ws_hist_off = 0;
     // k_smooth_sp (one 1024-thread workgroup per CU): row | {S0,S1} | histogram | scratch, nothing aliased
     bool sp_ok = false;
@@ -233,22 +234,16 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
                                   : (double)((window + 1) / 2) * (double)((window + 1) / 2);
     p.pyr_rcp = 1.0 / p.pyr_den;
 
-    // fast path: float32 dense, blocked form, row + tables fit the register/LDS budget
-    p.fast_ok = false;
-    if (B > 1 && n_cols_all % 4 == 0 && n_cols_all <= kFastUMax * kThreads * 4 && p.Gp < 65535 &&
-        window <= 32767 && p.Gp <= 32767 * 1) {
-        int data = round_up((p.Gp + 1) * 4, 16);  // + trash slot for masked columns
-        if (16 * p.NB > data) data = 16 * p.NB;
-        p.fast_scratch_off = round_up(data, 16);
-        p.fast_lds = p.fast_scratch_off + kFastScratchBytes;
-        p.fast_ok = p.fast_lds <= kLdsLimit;
-        p.dst16.assign((size_t)kWsUMax * (kThreads - 64) * 4, (uint16_t)p.Gp);  // >= kFastUMax*kThreads*4
+    // packed window table {start block (16 bits) | length << 16} of the ws / sd kernels; k_smooth_sd: per window the
+    // gene offset inside its chromosome, per block that of its first gene.  Needs every length to fit 16 signed bits.
+    p.sd_ok = false;
+    bool pack_ok = B > 1 && window <= 32767 && p.NB <= 65535;
+    for (int c = 0; c < n_chr && pack_ok; ++c) pack_ok = p.pad_off[c + 1] - p.pad_off[c] <= 32767;
+    p.w_pack.clear(); p.w_srel.clear(); p.blk_g0.clear();
+    if (pack_ok) {
         p.w_pack.resize(p.W);
         for (int j = 0; j < p.W; ++j)
             p.w_pack[j] = (int32_t)((uint32_t)((p.w_start[j] / B) & 0xffff) | ((uint32_t)p.w_len[j] << 16));
-        p.ws_win_off = 16 * p.NB;
-        p.ws_hist_off = p.ws_win_off;  // the histogram follows {S0,S1} inside the (dead) row
-        // k_smooth_sd: per window the gene offset inside its chromosome, per block that of its first gene
         p.w_srel.assign(p.W, 0);
         p.blk_g0.assign((size_t)p.NB + 8, 0);
         for (int c = 0; c < n_chr; ++c) {
@@ -256,6 +251,23 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
             for (int q = 0; q < wc; ++q) p.w_srel[w0 + q] = p.w_start[w0 + q] - p.pad_off[c];
             for (int b = p.pad_off[c] / B; b < p.pad_off[c + 1] / B; ++b) p.blk_g0[b] = b * B - p.pad_off[c];
         }
+        // k_smooth_sd: block bins in 8 planes of 512 slots, four windows per thread of a 512-thread workgroup; the
+        // cells it hands back go to the generic kernel (one row in LDS)
+        p.sd_ok = window % 2 == 0 && p.NB <= 8 * kThreads && p.W <= 4 * kThreads && p.lay32.fits;
+    }
+
+    // fast path: float32 dense, blocked form, row + tables fit the register/LDS budget
+    p.fast_ok = false;
+    if (pack_ok && n_cols_all % 4 == 0 && n_cols_all <= kFastUMax * kThreads * 4 && p.Gp < 65535 &&
+        window <= 32767 && p.Gp <= 32767 * 1) {
+        int data = round_up((p.Gp + 1) * 4, 16);  // + trash slot for masked columns
+        if (16 * p.NB > data) data = 16 * p.NB;
+        p.fast_scratch_off = round_up(data, 16);
+        p.fast_lds = p.fast_scratch_off + kFastScratchBytes;
+        p.fast_ok = p.fast_lds <= kLdsLimit;
+        p.dst16.assign((size_t)kWsUMax * (kThreads - 64) * 4, (uint16_t)p.Gp);  // >= kFastUMax*kThreads*4
+        p.ws_win_off = 16 * p.NB;
+        p.ws_hist_off = p.ws_win_off;  // the histogram follows {S0,S1} inside the (dead) row
         p.ws_ok = p.fast_ok && p.ws_hist_off + 4096 * 2 <= p.fast_scratch_off && p.W < 65536 && p.NB <= kThreads * 8 &&
                   p.W <= kThreads * 4;
         for (int g = 0; g < n_cols_all; ++g)

@@ -62,10 +62,16 @@ def shard_bounds(n_obs: int, world_size: int, chunksize: int, align: bool = True
 
 
 def all_reduce_sum_(tensor, group=None):
-    """In-place sum over ranks (no-op for a single process)."""
+    """In-place sum over ranks (no-op for a single process).  Device tensors travel through RCCL with the ``nccl``
+    backend; with any other backend (``gloo``: the CPU tests, and several ranks sharing one GPU) through the host."""
     dist = _dist()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+        if tensor.is_cuda and dist.get_backend(group) != "nccl":
+            h = tensor.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            tensor.copy_(h)
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return tensor
 
 
@@ -361,8 +367,9 @@ class HipWardSteps:
         h = C.c_void_p()
         sr = np.ascontiguousarray(layout.sr_local, dtype=np.int32)
         assert layout.S == SUPER, "the HIP kernels own rows in super-rows of ICV_SUPER_ROWS"
+        spare = layout.ld % 4 == 0 and layout.ld >= n + (n + 1) // 2  # WardLayout(spare=True)
         _lib.check(self.lib.icv_ward_create(int(n), sr.ctypes.data, int(layout.n_super), SUPER_SHIFT, int(layout.ld),
-                                            C.byref(h), self._st()))
+                                            1 if spare else 0, C.byref(h), self._st()))
         self.handle = h
 
     def _st(self):
@@ -493,8 +500,8 @@ def ward_linkage_sharded(x_local, *, group=None, steps=None, return_rounds=False
     if len(bounds) == 1:
         from . import _engine
 
-        d2 = _engine.pairwise_sqeuclidean(x_all)
-        Z, rounds = _engine.ward_linkage(d2)
+        d2 = _engine.pairwise_sqeuclidean(x_all, spare=True)
+        Z, rounds = _engine.ward_linkage(d2, spare=_engine.has_spare_columns(d2))
         return (Z, rounds) if return_rounds else Z
     rank, ws = dist.get_rank(group), dist.get_world_size(group)
     # spare columns for the Ward rounds only if the distance phase (local rows + mirror buffer + received blocks)

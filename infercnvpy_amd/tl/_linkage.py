@@ -33,9 +33,9 @@ def ward_linkage(X, *, return_rounds: bool = False):
     if X.shape[0] < 2:
         raise ValueError("at least two cells are needed for a linkage")
     xd = torch.from_numpy(X).cuda()
-    d2 = _engine.pairwise_sqeuclidean(xd)
+    d2 = _engine.pairwise_sqeuclidean(xd, spare=True)
     del xd
-    Z, rounds = _engine.ward_linkage(d2)
+    Z, rounds = _engine.ward_linkage(d2, spare=_engine.has_spare_columns(d2))
     return (Z, rounds) if return_rounds else Z
 
 

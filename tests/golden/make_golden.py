@@ -67,6 +67,8 @@ def make_adata(X, var, obs_labels=None):
 
 
 def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="dense"):
+    if ONLY is not None and not name.startswith(ONLY):
+        return
     Xin = X
     if fmt == "csr":
         Xin = sp.csr_matrix(X)
@@ -144,11 +146,18 @@ def ith_cases(scores):
     print("ith_scores:", {g: (gex[g], cna[g]) for g in keys})
 
 
+ONLY = None  # --only PREFIX[,PREFIX...]: write just the cases whose name starts with one of the prefixes
+
+
 def main():
+    global ONLY
     ref, scores = load_reference()
     if "--only-ith" in sys.argv:
         return ith_cases(scores)
-    ith_cases(scores)
+    if "--only" in sys.argv:
+        ONLY = tuple(sys.argv[sys.argv.index("--only") + 1].split(","))
+    else:
+        ith_cases(scores)
 
     extra = (("chrX", 30), ("chrY", 6), ("chrM", 8), ("GL000218.1", 9), (None, 5))
     var_m = cases.synthetic_var([230, 110, 101, 100, 99, 57, 140],
@@ -211,6 +220,29 @@ def main():
     run_case(ref, "w250_s10_csr", Xw, var_w, dict(reference=refw, window_size=250, step=10), fmt="csr")
     run_case(ref, "w250_s5", Xw, var_w, dict(reference=refw, window_size=250, step=5))
 
+    # CSR input in block form = the stored-entries kernel (k_smooth_sd): bounded references (:424-432), other clip
+    # values (its fixed-point scale), other block sizes; columns without a chromosome / on chrX, a chromosome with
+    # fewer genes than the window (flat window, :227-236), one with exactly `window` genes
+    var_s = cases.synthetic_var([600, 260, 251, 250, 249, 90], seed_start=12, seed_perm=13,
+                                extra=(("chrX", 31), ("chrM", 3), (None, 4)))
+    Xs = cases.synthetic_expr(40, len(var_s["names"]), seed=9)
+    refs = Xs.mean(axis=0, dtype=np.float64).astype(np.float32)
+    labs = np.array(["nA"] * 9 + ["nB"] * 8 + ["t"] * 23)[np.random.RandomState(5).permutation(40)]
+    w250 = dict(window_size=250, step=10)
+    run_case(ref, "w250_s10_csr_r2", Xs, var_s, dict(reference_key="group", reference_cat=["nA", "nB"], **w250),
+             obs_labels=labs, fmt="csr")
+    refs2 = np.vstack([Xs[labs == "nA"].mean(axis=0, dtype=np.float64),
+                       Xs[labs == "nB"].mean(axis=0, dtype=np.float64)]).astype(np.float32)
+    run_case(ref, "w250_s10_csr_r2given", Xs, var_s, dict(reference=refs2, **w250), fmt="csr")
+    run_case(ref, "w250_s10_csr_clip05", Xs, var_s, dict(reference=refs, lfc_clip=0.5, **w250), fmt="csr")
+    run_case(ref, "w250_s10_csr_clip10", Xs, var_s, dict(reference=refs, lfc_clip=10, **w250), fmt="csr")
+    run_case(ref, "w120_s4_csr", Xs, var_s, dict(reference=refs, window_size=120, step=4, chunksize=16), fmt="csr")
+    run_case(ref, "w100_s2_csr", Xs, var_s, dict(reference=refs, window_size=100, step=2), fmt="csr")
+    run_case(ref, "w100_s10_csr_x", Xs, var_s, dict(reference=refs, window_size=100, step=10), fmt="csr")
+    run_case(ref, "w100_s10_csc_r2", Xs, var_s, dict(reference_key="group", reference_cat=["nB", "nA"],
+                                                      window_size=100, step=10, dynamic_threshold=1.0),
+             obs_labels=labs, fmt="csc")
+
     # GTF-ordered input (identity gather) and a dense, no-zeros matrix
     var_o = cases.synthetic_var([230, 110, 101, 100, 99, 57, 140],
                                 names=["chr1", "chr2", "chr3", "chr4", "chr5", "chr6", "chr10"], permute=False)
@@ -242,7 +274,7 @@ def main():
              fmt="csr")
 
     # reference means in isolation (dense / CSR, float32): _get_reference
-    for fmt in ("dense", "csr"):
+    for fmt in ("dense", "csr") if ONLY is None else ():
         Xin = sp.csr_matrix(Xf) if fmt == "csr" else Xf
         ad = make_adata(Xin, var_m, labels)
         r_all = np.asarray(ref._get_reference(ad, None, None, None, None))

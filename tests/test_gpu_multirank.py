@@ -7,7 +7,11 @@ single-GPU run bit for bit; the sharded Ward linkage must equal ``tl.ward_linkag
 
 ``test_sharded_ward_two_processes_one_gpu`` runs the sharded distance tiles and Ward rounds (the HIP step kernels
 behind ``icv_pairwise_sqeuclidean_tiles`` / ``icv_ward_*``) with two processes on ONE GPU: the collectives go
-through gloo and host copies there, everything else is the code path of the multi-GPU job."""
+through gloo and host copies there, everything else is the code path of the multi-GPU job.
+``test_hot_path_ranks_on_one_gpu`` does the same for the headline path (BASELINE config 3: ``icv_colsum`` ->
+``dist.reference_means`` -> ``dist.run_shard``), so that the sharded code runs under a process group on every
+box, and ``test_public_api_shards_*`` run the multi-GPU ``tl.infercnv`` (``devices=``) with several shards on one
+GPU (and on two GPUs where the box has them)."""
 import os
 import socket
 
@@ -169,3 +173,262 @@ def test_sharded_ward_two_processes_one_gpu(world, n, d, in_place):
     for r in range(world):
         assert results[r][3] == rounds1
         np.testing.assert_array_equal(results[r][2], Z1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the hot path under a process group with every rank on cuda:0 (collectives: gloo through the host)
+# ----------------------------------------------------------------------------------------------------------------------
+_HP_GENES = [700, 320, 150, 100, 60]
+_HP_N, _HP_CS = 2300, 500
+
+
+def _hp_inputs(fmt):
+    import scipy.sparse as sp
+
+    v = cases.synthetic_var(_HP_GENES, extra=(("chrX", 40), (None, 6)))
+    n_genes = len(v["names"]) - len(v["names"]) % 4
+    for key in ("chromosome", "start"):
+        v[key] = v[key][:n_genes]
+    X = cases.synthetic_expr(_HP_N, n_genes, seed=51)
+    if fmt == "csr":
+        X[X < np.quantile(X, 0.9)] = 0
+        X = sp.csr_matrix(X)
+    labels = np.array(["n1", "n2", "t"])[np.random.RandomState(9).randint(0, 3, _HP_N)]
+    return v, X, labels
+
+
+def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window):
+    """One rank's share: column sums -> all-reduced means -> run_shard.  Returns (r0, r1, out, thr, ref)."""
+    import torch
+
+    bounds = icd.shard_bounds(_HP_N, world, _HP_CS, align=align)
+    r0, r1 = bounds[rank]
+    dm = _engine.to_device_matrix(X[r0:r1], torch.float32)
+    ll = labels[r0:r1]
+    if cats is None:
+        sums = _engine.column_sums(dm) if r1 > r0 else torch.zeros((1, X.shape[1]), dtype=torch.float64, device="cuda")
+        counts = [r1 - r0]
+    else:
+        grp = np.full(r1 - r0, -1, dtype=np.int32)
+        for gi, c in enumerate(cats):
+            grp[ll == c] = gi
+        sums = _engine.column_sums(dm, grp, len(cats)) if r1 > r0 else \
+            torch.zeros((len(cats), X.shape[1]), dtype=torch.float64, device="cuda")
+        counts = [int((ll == c).sum()) for c in cats]
+    ref = icd.reference_means(sums, counts, "float32", device_out=True).contiguous()
+    ref_lo = ref[0].contiguous() if cats is None else ref.min(dim=0).values.contiguous()
+    ref_hi = None if cats is None else ref.max(dim=0).values.contiguous()
+    # with and without the partition: both ways every rank must take the same branch
+    outs = {}
+    for ab in (bounds, None):
+        res = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=_HP_N, chunksize=_HP_CS, all_bounds=ab)
+        torch.cuda.synchronize()
+        outs[ab is None] = (res.out.cpu().numpy(), None if res.thr is None else res.thr.cpu().numpy())
+    return r0, r1, outs, ref.cpu().numpy()
+
+
+def _hp_worker(rank, world, port, fmt, window, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infercnvpy_amd import _engine, dist as icd
+        from infercnvpy_amd._plan import GenePlan
+
+        v, X, labels = _hp_inputs(fmt)
+        plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
+        out = {}
+        for align in (True, False):
+            for cats in (None, ["n1", "n2"]):
+                out[(align, cats is None)] = _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window)
+        q.put((rank, "ok", out))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fmt,window", [(2, "dense", 100), (3, "dense", 100), (2, "csr", 100), (3, "csr", 250)])
+def test_hot_path_ranks_on_one_gpu(world, fmt, window):
+    """BASELINE config 3's code path (row shards, ONE all-reduce of the reference sums, chunk-aligned and unaligned
+    thresholds) with 2-3 ranks sharing cuda:0: the concatenated shards equal the single-process run bit for bit
+    whenever the all-reduced means equal the single-process means (they are rounded from float64 sums added in
+    another order), and every rank sees the same means."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from infercnvpy_amd import _engine
+    from infercnvpy_amd._plan import GenePlan
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hp_worker, args=(r, world, port, fmt, window, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"
+
+    v, X, labels = _hp_inputs(fmt)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
+    dm = _engine.to_device_matrix(X, torch.float32)
+    for (align, allmean), _ in results[0][2].items():
+        if allmean:
+            ref = (_engine.column_sums(dm) / _HP_N).float()
+            ref_lo, ref_hi = ref[0].contiguous(), None
+        else:
+            grp = np.full(_HP_N, -1, dtype=np.int32)
+            for gi, c in enumerate(["n1", "n2"]):
+                grp[labels == c] = gi
+            cnt = torch.tensor([(labels == "n1").sum(), (labels == "n2").sum()], dtype=torch.float64, device="cuda")
+            ref = (_engine.column_sums(dm, grp, 2) / cnt[:, None]).float()
+            ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
+        whole = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, chunksize=_HP_CS)
+        w_out, w_thr = whole.out.cpu().numpy(), whole.thr.cpu().numpy()
+        parts = [results[r][2][(align, allmean)] for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == _HP_N
+        for a, b in zip(parts[:-1], parts[1:]):
+            assert a[1] == b[0]
+            np.testing.assert_array_equal(a[3], b[3])  # all ranks hold the same means
+        np.testing.assert_allclose(parts[0][3], ref.cpu().numpy(), rtol=1e-6, atol=1e-12)
+        same_ref = np.array_equal(parts[0][3], ref.cpu().numpy())
+        for no_bounds in (False, True):
+            got = np.vstack([p[2][no_bounds][0] for p in parts])
+            if same_ref and (align or fmt == "dense" or window == 100):
+                assert np.array_equal(got, w_out), (align, allmean, no_bounds)
+            elif same_ref:
+                # unaligned shards of the long-window CSR kernel: thresholds from all-reduced per-cell moments
+                # (another summation order than the per-chunk partials): ties at 1e-12 may flip
+                assert np.mean((got == 0) != (w_out == 0)) < 1e-5
+                np.testing.assert_allclose(got[(got != 0) & (w_out != 0)], w_out[(got != 0) & (w_out != 0)], atol=1e-6)
+            else:  # a mean differs in its last bit: values agree to rounding, the zero pattern up to threshold ties
+                assert np.mean((got == 0) != (w_out == 0)) < 1e-4
+            # thresholds of the chunks a rank holds
+            for p in parts:
+                thr = p[2][no_bounds][1]
+                k0 = p[0] // _HP_CS
+                if p[1] > p[0]:
+                    np.testing.assert_allclose(thr, w_thr[k0:k0 + len(thr)], rtol=1e-6 if not same_ref else 1e-11)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-GPU tl.infercnv: several row shards inside one call
+# ----------------------------------------------------------------------------------------------------------------------
+def _api_inputs(fmt, n_obs=1150):
+    import pandas as pd
+    import scipy.sparse as sp
+
+    v = cases.synthetic_var(_HP_GENES, extra=(("chrX", 40), ("chrM", 5), (None, 6)))
+    X = cases.synthetic_expr(n_obs, len(v["names"]), seed=77)
+    labels = np.array(["n1", "n2", "t"])[np.random.RandomState(4).randint(0, 3, n_obs)]
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    obs = pd.DataFrame({"group": labels})
+    if fmt == "csr":
+        X = sp.csr_matrix(X)
+    return X, obs, var
+
+
+def _api_run(X, obs, var, **kw):
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+
+    tm = {}
+    out = cnv.tl.infercnv(SimpleAnnData(X, obs=obs, var=var), inplace=False, chunksize=100, _timings=tm, **kw)
+    return out, tm
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_public_api_shards_on_one_gpu(fmt):
+    """``tl.infercnv(devices=[0, 0, 0])``: three chunk-aligned row shards, each with its own uploader, plan, stream
+    and CSR drain, on one GPU.  With ``reference=`` given X_cnv is bit-equal to the one-shard result (also gene
+    values); with means formed from the shards' sums only last-bit differences of a mean may move entries."""
+    X, obs, var = _api_inputs(fmt)
+    ref = np.asarray(X[:200].mean(axis=0), dtype=np.float64).ravel().astype(np.float32)
+    for kw in (dict(reference=ref), dict(reference=ref, window_size=250), dict(reference=ref, calculate_gene_values=True),
+               dict(reference=np.vstack([ref, ref * 0.5 + 0.01]).astype(np.float32))):
+        (pos1, res1, gv1), tm1 = _api_run(X, obs, var, devices=[0], **kw)
+        assert tm1["devices"] == [0] and "shards" not in tm1
+        for devs in ([0, 0], [0, 0, 0]):
+            (pos, res, gv), tm = _api_run(X, obs, var, devices=devs, **kw)
+            assert tm["devices"] == devs and [s["rows"] for s in tm["shards"]] == ([600, 550] if len(devs) == 2 else [400, 400, 350])
+            assert list(pos.items()) == list(pos1.items())
+            assert res.shape == res1.shape and res.dtype == res1.dtype
+            np.testing.assert_array_equal(res.indptr, res1.indptr)
+            np.testing.assert_array_equal(res.indices, res1.indices)
+            np.testing.assert_array_equal(res.data, res1.data)
+            if gv1 is not None:
+                np.testing.assert_array_equal(gv, gv1)
+    for kw in (dict(), dict(reference_key="group", reference_cat=["n1", "n2"]), dict(reference_key="group", reference_cat="n1")):
+        (_, res1, _), _ = _api_run(X, obs, var, devices=[0], **kw)
+        (_, res3, _), tm = _api_run(X, obs, var, devices=[0, 0, 0], **kw)
+        a, b = res1.toarray(), res3.toarray()
+        assert np.mean((a == 0) != (b == 0)) < 1e-4
+        both = (a != 0) & (b != 0)
+        np.testing.assert_allclose(a[both], b[both], rtol=0, atol=1e-6)
+        assert "reference_pass" in tm
+    # n_jobs: the reference's knob.  More jobs than GPUs or chunks: capped; n_jobs=1: one shard
+    (_, res_j, _), tm = _api_run(X, obs, var, n_jobs=64, reference=ref)
+    import torch
+
+    assert len(tm["devices"]) == min(torch.cuda.device_count(), 12)
+    (_, res_1, _), tm = _api_run(X, obs, var, n_jobs=1, reference=ref)
+    assert tm["devices"] == [torch.cuda.current_device()]
+    np.testing.assert_array_equal(res_j.toarray(), res_1.toarray())
+
+
+def test_public_api_shard_failure_is_raised_and_leaves_no_threads(monkeypatch):
+    """A shard that fails (here: its second kernel launch) aborts the others, the exception reaches the caller and
+    every helper thread (uploaders, drains, shard threads) is gone afterwards."""
+    import threading
+
+    from infercnvpy_amd import _engine
+
+    X, obs, var = _api_inputs("dense")
+    ref = np.asarray(X[:200].mean(axis=0), dtype=np.float64).ravel().astype(np.float32)
+    real = _engine.run_hot_path
+    calls = {"n": 0}
+    lock = threading.Lock()
+
+    def flaky(*a, **k):
+        with lock:
+            calls["n"] += 1
+            n = calls["n"]
+        if n == 2:
+            raise RuntimeError("injected failure")
+        return real(*a, **k)
+
+    monkeypatch.setattr(_engine, "run_hot_path", flaky)
+    before = threading.active_count()
+    for devs in ([0, 0, 0], [0]):
+        calls["n"] = 0 if len(devs) > 1 else 1
+        with pytest.raises(RuntimeError, match="injected failure"):
+            _api_run(X, obs, var, devices=devs, reference=ref)
+        assert threading.active_count() == before
+    monkeypatch.setattr(_engine, "run_hot_path", real)
+    (_, res, _), _ = _api_run(X, obs, var, devices=[0, 0], reference=ref)  # and the next call works
+    assert res.shape[0] == X.shape[0]
+
+
+def test_public_api_shards_on_two_gpus():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    for fmt in ("dense", "csr"):
+        X, obs, var = _api_inputs(fmt)
+        ref = np.asarray(X[:200].mean(axis=0), dtype=np.float64).ravel().astype(np.float32)
+        (_, res1, _), _ = _api_run(X, obs, var, devices=[0], reference=ref)
+        (_, res2, _), tm = _api_run(X, obs, var, devices=[0, 1], reference=ref)
+        assert [s["device"] for s in tm["shards"]] == [0, 1]
+        np.testing.assert_array_equal(res1.toarray(), res2.toarray())
+        (_, res3, _), _ = _api_run(X, obs, var, devices=[1], reference=ref)
+        np.testing.assert_array_equal(res1.toarray(), res3.toarray())

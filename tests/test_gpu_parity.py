@@ -55,6 +55,34 @@ def test_golden_explicit_reference(name):
     np.testing.assert_allclose(got, g.out, rtol=0, atol=ATOL_TIGHT)
 
 
+SD_CASES = [n for n in _RUNNABLE if GoldenCase(n).fmt in ("csr", "csc") and GoldenCase(n).in_dtype == "float32"
+            and GoldenCase(n).kwargs.get("window_size", 100) % 2 == 0
+            and np.gcd(GoldenCase(n).kwargs.get("step", 10), GoldenCase(n).kwargs.get("window_size", 100) // 2) > 1
+            and np.result_type(np.float32, np.asarray(GoldenCase(n).kwargs.get("reference", np.float32(0))).dtype) == np.float32]
+
+
+@pytest.mark.parametrize("name", SD_CASES)
+def test_sparse_float32_goldens_take_the_stored_entries_kernel(name, monkeypatch):
+    """float32 CSR / CSC input in block form runs k_smooth_sd (stored entries only: fixed-point block bins, windows
+    from prefix sums) -- asserted through the plan's `last_kernel` record -- and its X_cnv equals that of the
+    kernels that rebuild the row in LDS (developer knob ICV_NO_SD) up to the last float32 bit, zero pattern
+    included.  (The golden comparison itself is test_golden_explicit_reference / test_golden_reference_mean_on_gpu.)"""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd import _lib
+
+    g = GoldenCase(name)
+    tm = {}
+    _, res, _ = cnv.tl.infercnv(_adata(g), inplace=False, _timings=tm, **g.api_kwargs())
+    assert tm["kernel"] == _lib.ICV_KERNEL_SD
+    monkeypatch.setenv("ICV_NO_SD", "1")
+    tm2 = {}
+    _, res2, _ = cnv.tl.infercnv(_adata(g), inplace=False, _timings=tm2, **g.api_kwargs())
+    assert tm2["kernel"] in (_lib.ICV_KERNEL_WS_CSR, _lib.ICV_KERNEL_GENERIC)
+    a, b = res.toarray(), res2.toarray()
+    np.testing.assert_array_equal(a == 0, b == 0)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2.5e-7)
+
+
 def _exact_means(g):
     """Correctly rounded per-group means, in the dtype numpy would return (what the GPU path produces)."""
     X = g.X_dense
@@ -393,12 +421,15 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
         # default (k_smooth_x16 where the geometry admits it, else k_smooth_ws), k_smooth_ws forced,
         # prepared-entry CSR, generic CSR
-        # long windows (more than 10 blocks) on CSR input: k_smooth_sd adds the stored entries' differences to the
-        # zero row into block bins and reads the windows off prefix sums -- another float64 evaluation order, equal
-        # to the canonical one to ~1e-12 (float32 x_res: last-bit differences in a few entries per 100 000)
-        pfx = window == 250 and step == 10
-        for env, mat, exact in (([], dm, True), (["ICV_NO_X16"], dm, True), ([], dm_csr, not pfx),
-                                (["ICV_FORCE_GENERIC"], dm_csr, True)):
+        # float32 CSR input: k_smooth_sd adds the stored entries' differences to the zero row into block bins and
+        # reads the windows off prefix sums -- another float64 evaluation order, equal to the canonical one to
+        # ~1e-12 (float32 x_res: last-bit differences in a few entries per 100 000)
+        # (every block-form float32 CSR geometry runs k_smooth_sd; ICV_NO_SD: the prepared-entry kernel k_smooth_ws<CSR>
+        # where the geometry admits it, else the generic kernel -- both in the canonical order)
+        from infercnvpy_amd import _lib
+
+        for env, mat, exact in (([], dm, True), (["ICV_NO_X16"], dm, True), ([], dm_csr, False),
+                                (["ICV_NO_SD"], dm_csr, True), (["ICV_FORCE_GENERIC"], dm_csr, True)):
             def same(a, b, what):
                 a, b = torch.nan_to_num(a, nan=123.0), torch.nan_to_num(b, nan=123.0)
                 if exact:
@@ -410,6 +441,9 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
 
             tol = 1e-12 if exact else 1e-9
             fast = run(plan, mat, ref, env)
+            if mat is dm_csr:
+                assert plan.last_kernel() == (_lib.ICV_KERNEL_SD if not env else
+                                              (_lib.ICV_KERNEL_GENERIC if env == ["ICV_FORCE_GENERIC"] else plan.last_kernel()))
             same(fast.out, gen.out, "out")
             same(fast.cell_median, gen.cell_median, "median")
             for a, b in ((fast.cell_stats, gen.cell_stats), (fast.thr, gen.thr)):
@@ -430,14 +464,15 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
 
 def test_csr_long_windows_do_not_depend_on_entry_order():
     """k_smooth_sd accumulates in fixed point: any order of a row's stored entries gives the same bits, and so do
-    repeated runs.  Geometries: the benchmark's (window 250 / step 10) and one with other block sizes, masked
-    columns and a chromosome shorter than the window (flat window)."""
+    repeated runs.  Geometries: the benchmark's (window 250 / step 10; window 100 / step 10) and one with other block
+    sizes, masked columns and a chromosome shorter than the window (flat window)."""
     import torch
 
     from infercnvpy_amd import _engine
     from infercnvpy_amd._plan import GenePlan
 
     for genes, window, step, extra in ((cases.GENES_PER_CHROM_20K, 250, 10, (("chrX", 31), (None, 3))),
+                                       (cases.GENES_PER_CHROM_20K, 100, 10, (("chrX", 30),)),
                                        ([1500, 700, 333, 90], 120, 4, ((None, 5),))):
         v = cases.synthetic_var(genes, extra=extra)
         n_genes = len(v["names"]) - len(v["names"]) % 4
@@ -464,6 +499,9 @@ def test_csr_long_windows_do_not_depend_on_entry_order():
             return res
 
         base, again, shuffled = run(csr.indices, csr.data), run(csr.indices, csr.data), run(indices, data)
+        from infercnvpy_amd import _lib
+
+        assert plan.last_kernel() == _lib.ICV_KERNEL_SD
         for other in (again, shuffled):
             assert torch.equal(base.out, other.out)
             assert torch.equal(base.cell_median, other.cell_median)
@@ -816,12 +854,19 @@ def test_ward_column_layouts_agree(n, d, monkeypatch):
 
     X = _blobs(n, d, 9, seed=n + 1)
     xd = torch.from_numpy(X).cuda()
-    Zs, rs = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd))  # default allocation: n / 2 spare columns
+    Zs, rs = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, spare=True), spare=True)  # n / 2 spare columns
     monkeypatch.setenv("ICV_WARD_IN_PLACE", "1")
-    Zi, ri = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd))
+    Zi, ri = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, spare=True), spare=True)
     monkeypatch.delenv("ICV_WARD_IN_PLACE")
     d2 = torch.empty((n, (n + 3) // 4 * 4), dtype=torch.float32, device="cuda")[:, :n]
     Zn, rn = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, out=d2))
+    # a column slice of a wider buffer: without the spare flag nothing outside the n x n block is touched
+    wide = torch.full((n, 2 * n + 8), 7.0, dtype=torch.float32, device="cuda")
+    Zw, rw = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, out=wide[:, :n]))
+    assert bool((wide[:, n:] == 7.0).all()) and rw == rn
+    np.testing.assert_array_equal(Zw, Zn)
+    with pytest.raises(ValueError):  # the spare layout needs its stride
+        _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, out=d2), spare=True)
     assert rs == ri == rn
     np.testing.assert_array_equal(Zs, Zi)
     np.testing.assert_array_equal(Zn, Zi)
@@ -849,21 +894,31 @@ def test_ward_linkage_properties_at_20000_cells():
 # --------------------------------------------------------------------------- #
 # randomized sweep over geometries / dtypes / formats / reference kinds, and the multi-slab driver
 # --------------------------------------------------------------------------- #
+N_SWEEP = 18
+SWEEP_SD_FROM = 12  # seeds from here on: float32 CSR / CSC input in block form = the stored-entries kernel k_smooth_sd
+
+
 def _sweep_case(seed):
     rng = np.random.RandomState(1000 + seed)
     n_chr = rng.randint(2, 8)
-    sizes = [int(rng.choice([5, 17, 40, 99, 100, 101, 180, 333])) for _ in range(n_chr)]
+    sd = seed >= SWEEP_SD_FROM
+    sizes = [int(rng.choice([17, 99, 100, 101, 180, 333, 400, 700] if sd else [5, 17, 40, 99, 100, 101, 180, 333]))
+             for _ in range(n_chr)]
     names = [f"chr{i}" for i in rng.choice(np.arange(1, 23), size=n_chr, replace=False)]
     extra = [("chrX", int(rng.randint(3, 40))), ("chrM", 4), (None, int(rng.randint(1, 6)))][: rng.randint(0, 4)]
     v = cases.synthetic_var(sizes, names=names, extra=tuple(extra), seed_start=seed, seed_perm=seed + 1)
     G = len(v["names"])
     n_obs = int(rng.randint(25, 140))
     kind = rng.choice(["f32", "f64", "int"])
+    if sd:
+        kind = "f32"
     if kind == "int":
         X = rng.poisson(1.3, size=(n_obs, G)).astype(np.int64)
     else:
         X = cases.synthetic_expr(n_obs, G, seed=seed + 7, dtype=np.float32 if kind == "f32" else np.float64)
     fmt = rng.choice(["dense", "csr", "csc"])
+    if sd:
+        fmt = ["csr", "csc"][seed % 2]
     labels = rng.choice(["a", "b", "c"], size=n_obs)
     labels[:3] = ["a", "b", "c"]
     kw = dict(window_size=int(rng.choice([4, 6, 10, 20, 50, 100, 101])), step=int(rng.choice([1, 2, 5, 10])),
@@ -871,10 +926,15 @@ def _sweep_case(seed):
               dynamic_threshold=[None, 0.5, 1.5][rng.randint(0, 3)],
               exclude_chromosomes=[("chrX", "chrY"), None, (names[0],)][rng.randint(0, 3)])
     ref_kind = rng.choice(["none", "array", "cat1", "cat2"])
+    if sd:  # even windows with a block size gcd(step, window / 2) > 1, clips up to 10, every reference kind
+        pairs = [(20, 2), (20, 4), (100, 2), (100, 10), (120, 4), (120, 5), (250, 10), (250, 5), (50, 10), (100, 4)]
+        win, stp = pairs[rng.randint(0, len(pairs))]
+        kw.update(window_size=win, step=stp, lfc_clip=float(rng.choice([0.5, 3.0, 10.0])))
+        ref_kind = ["none", "array", "cat1", "cat2"][seed % 4]
     return v, X, fmt, labels, kw, ref_kind, rng
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_SWEEP))
 def test_random_sweep_public_api_against_oracle(seed):
     import infercnvpy_amd as cnv
     from infercnvpy_amd._compat import SimpleAnnData
@@ -896,7 +956,12 @@ def test_random_sweep_public_api_against_oracle(seed):
         api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
         ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in cats]).astype(
             mean_dtype)
-    chr_pos, res, _ = cnv.tl.infercnv(ad, inplace=False, **api)
+    tm = {}
+    chr_pos, res, _ = cnv.tl.infercnv(ad, inplace=False, _timings=tm, **api)
+    if seed >= SWEEP_SD_FROM:
+        from infercnvpy_amd import _lib
+
+        assert tm["kernel"] == _lib.ICV_KERNEL_SD, (tm["kernel"], kw)
     e_pos, e_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, **kw)
     assert {k: int(p) for k, p in chr_pos.items()} == {k: int(p) for k, p in e_pos.items()}
     got, exp = res.toarray(), e_res.toarray()

@@ -44,7 +44,7 @@ def main():
         torch.cuda.synchronize()
         t_pd = time.perf_counter() - t0
         t0 = time.perf_counter()
-        Z, rounds = _engine.ward_linkage(d2)
+        Z, rounds = _engine.ward_linkage(d2, spare=not a.in_place)
         t_w = time.perf_counter() - t0
         rec = {"cells": n, "features": a.features, "pdist_s": round(t_pd, 4),
                # executed flops: tiles on / above the diagonal only
