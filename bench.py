@@ -594,13 +594,21 @@ def main():
     dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
                         args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
                         no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key)
-    host_group = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # a CPU-side group for waiting without a collective kernel spinning on the idle GPUs (the e2e leg below)
-        host_group = dist.new_group(backend="gloo")
+
+    def host_barrier(tag):
+        """Ranks meet through the rendezvous store (CPU only): no collective kernel spins on the idle GPUs while rank
+        0 drives them in the e2e leg, and no second process group (gloo prints to stdout) is created."""
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            store.set(f"icv_bench_{tag}_{rank}", b"1")
+            store.wait([f"icv_bench_{tag}_{r}" for r in range(world)])
+        except Exception:
+            dist.barrier()
+
 
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps)
@@ -671,18 +679,18 @@ def main():
         # the public API over all GPUs of the job, from host memory: rank 0 drives every GPU from one process while
         # the other ranks have released their HBM and wait
         torch.cuda.synchronize()
-        dist.barrier(group=host_group)
+        host_barrier("e2e_begin")
         if rank == 0:
             try:
                 devs = [0] * n_gpus if dry else list(range(n_gpus))
                 result["e2e"] = e2e_multi_gpu(torch, devs, cells_per_gpu=10_000 if dry else 100_000)
             except Exception as e:
                 result["e2e"] = {"error": repr(e)}
-        dist.barrier(group=host_group)
+        host_barrier("e2e_end")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier(group=host_group)
+        host_barrier("exit")
         dist.destroy_process_group()
 
 

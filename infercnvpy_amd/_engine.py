@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import scipy.sparse as sp
@@ -160,13 +161,14 @@ class SlabStream:
         np_dtype = np.float32 if tdtype == torch.float32 else np.float64
         self.n_rows = X.shape[0]
         self.bounds = [(r, min(self.n_rows, r + piece_rows)) for r in range(0, self.n_rows, piece_rows)]
-        self._q = queue.Queue()
         self._landed = 0
-        self._stream = torch.cuda.Stream()
-        device = torch.cuda.current_device()  # the helper thread starts on device 0 otherwise
+        device = torch.cuda.current_device()  # the helper threads start on device 0 otherwise
         creator_stream = torch.cuda.current_stream()
         self._err = None
         self._cancel = threading.Event()
+        # one uploader thread (and stream) per host array: a CSR slab is two arrays, and two threads keep the link
+        # busy where one thread alternating between them does not (measured with cold pages and a device -> host
+        # copy beside them: 54 against 39 GB/s, tools/exp_h2d_csr.py)
         if sp.issparse(X):
             indptr64 = np.ascontiguousarray(X.indptr.astype(np.int64, copy=False))
             nnz = int(indptr64[-1])
@@ -177,11 +179,17 @@ class SlabStream:
                                    indptr_host=indptr64)
             idx_h, dat_h = X.indices, X.data
 
-            def copy_piece(r0, r1):
+            def copy_indices(r0, r1):
                 k0, k1 = int(indptr64[r0]), int(indptr64[r1])
                 if k1 > k0:
                     d_indices[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(idx_h[k0:k1].astype(np.int32, copy=False))))
+
+            def copy_data(r0, r1):
+                k0, k1 = int(indptr64[r0]), int(indptr64[r1])
+                if k1 > k0:
                     d_data[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(dat_h[k0:k1].astype(np_dtype, copy=False))))
+
+            copiers = [copy_indices, copy_data]
         else:
             dense = torch.empty(X.shape, dtype=tdtype, device="cuda")
             self.dm = DeviceMatrix(dense=dense)
@@ -189,58 +197,69 @@ class SlabStream:
             def copy_piece(r0, r1):
                 dense[r0:r1].copy_(torch.from_numpy(np.ascontiguousarray(X[r0:r1].astype(np_dtype, copy=False))))
 
-        def work():
+            copiers = [copy_piece]
+
+        self._streams = [torch.cuda.Stream() for _ in copiers]
+        self._queues = [queue.Queue() for _ in copiers]
+        self._busy = [0.0 for _ in copiers]
+
+        def work(k):
+            import time
+
+            t0 = time.perf_counter()
+            stream, q, copy = self._streams[k], self._queues[k], copiers[k]
             try:
                 torch.cuda.set_device(device)
                 # the buffers were allocated on the creator's stream: whatever that stream still has queued on a
                 # recycled block (kernels of the previous slab) comes before the first copy into it
-                self._stream.wait_stream(creator_stream)
-                with torch.cuda.stream(self._stream):
+                stream.wait_stream(creator_stream)
+                with torch.cuda.stream(stream):
                     for r0, r1 in self.bounds:
                         if self._cancel.is_set():
                             break
-                        copy_piece(r0, r1)
+                        copy(r0, r1)
                         ev = torch.cuda.Event()
-                        ev.record(self._stream)
-                        self._q.put((r0, r1, ev))
+                        ev.record(stream)
+                        q.put(ev)
+                stream.synchronize()
             except BaseException as e:  # surfaced in the consumer
                 self._err = e
-                self._q.put(None)
+                q.put(None)
+            self._busy[k] = time.perf_counter() - t0
 
-        self.h2d_seconds = 0.0
-        inner = work
+        self._threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(len(copiers))]
+        for th in self._threads:
+            th.start()
 
-        def timed():
-            import time
-
-            t0 = time.perf_counter()
-            inner()
-            self._stream.synchronize()
-            self.h2d_seconds = time.perf_counter() - t0
-
-        self._thread = threading.Thread(target=timed, daemon=True)
-        self._thread.start()
+    @property
+    def h2d_seconds(self):
+        """Wall-clock seconds the slowest uploader thread took (they run side by side)."""
+        return max(self._busy)
 
     def pieces(self):
         """Row ranges in order; blocks (stream-wise) only for pieces that have not landed yet.  Re-iterable."""
         torch = _torch()
         for k in range(len(self.bounds)):
             if k >= self._landed:
-                item = self._q.get()
-                if item is None:
-                    raise self._err
-                torch.cuda.current_stream().wait_event(item[2])
+                for q in self._queues:  # a piece has landed when every array's part of it has
+                    ev = q.get()
+                    if ev is None:
+                        raise self._err
+                    torch.cuda.current_stream().wait_event(ev)
                 self._landed += 1
             yield self.bounds[k]
-        if self._thread.is_alive():
-            self._thread.join()
+        self._join()
+
+    def _join(self):
+        for th in self._threads:
+            if th.is_alive():
+                th.join()
 
     def close(self, cancel=False):
         """Stop the uploader (``cancel``: skip the pieces it has not started) and drop the slab's device buffers."""
         if cancel:
             self._cancel.set()
-        if self._thread.is_alive():
-            self._thread.join()
+        self._join()
         if self.dm is not None:
             # kernels of the consumer's stream may still read the slab: the caching allocator must not hand the
             # blocks (allocated on the creator's stream) to anyone before those kernels have run
@@ -248,7 +267,8 @@ class SlabStream:
             cur = torch.cuda.current_stream()
             for t in self.dm._keep:
                 t.record_stream(cur)
-                t.record_stream(self._stream)
+                for st in self._streams:
+                    t.record_stream(st)
         self.dm = None
 
 
@@ -274,6 +294,95 @@ def threshold_mask(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc
         res.out.stride(0), _ptr(res.cell_median), _ptr(res.thr), int(chunksize), int(row_phase), _ptr(mask),
         _ptr(counts), _stream_ptr(torch)))
     return PackedRows(res.out, mask, counts, res.thr)
+
+
+_PAGE = 4096
+
+
+def _prefault(arrays, start=0, n_threads=8):
+    """Write one byte into every page of freshly allocated numpy arrays (from element ``start`` on), from a few
+    threads in parallel: numpy releases the GIL for the strided store, the page faults run concurrently."""
+    import threading
+
+    jobs = []
+    for a in arrays:
+        b = a.view(np.uint8).reshape(-1)
+        lo = (start * a.itemsize) // _PAGE * _PAGE
+        n_pages = (b.shape[0] - lo + _PAGE - 1) // _PAGE
+        if n_pages < 256:  # < 1 MB: not worth a thread
+            continue
+        per = (n_pages + n_threads - 1) // n_threads
+        for k in range(n_threads):
+            p0, p1 = k * per, min(n_pages, (k + 1) * per)
+            if p0 < p1:
+                jobs.append(b[lo + p0 * _PAGE: min(b.shape[0], lo + p1 * _PAGE): _PAGE])
+    threads = [threading.Thread(target=lambda v=v: v.fill(0)) for v in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+
+
+class _PinnedRing:
+    """Device -> pageable host copies through a small ring of pinned staging buffers (one ring per GPU and process).
+
+    A copy straight into pageable memory runs at ~13 GB/s through the driver's staging path and holds back the
+    uploads running beside it; here the DMA engine writes 16 MB chunks into pinned slots at link speed and a few
+    host threads move them into the final arrays (numpy copies release the GIL)."""
+
+    _rings = {}
+    _lock = None
+
+    @classmethod
+    def get(cls, torch):
+        import threading
+
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        dev = torch.cuda.current_device()
+        with cls._lock:
+            if dev not in cls._rings:
+                cls._rings[dev] = cls(torch)
+            return cls._rings[dev]
+
+    def __init__(self, torch, n_slots=8, slot_bytes=16 << 20, n_threads=3):
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.torch = torch
+        self.slot_bytes = slot_bytes
+        self.slots = [torch.empty(slot_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)]
+        self.views = [t.numpy() for t in self.slots]
+        self.free = queue.Queue()
+        for i in range(n_slots):
+            self.free.put(i)
+        self.pool = ThreadPoolExecutor(n_threads, thread_name_prefix="icv-d2h")
+
+    def _land(self, i, ev, dst, n):
+        try:
+            ev.synchronize()
+            np.copyto(dst, self.views[i][:n])
+        finally:
+            self.free.put(i)
+
+    def download(self, src, dst, stream):
+        """Enqueue ``dst[...] = src`` (1-D device tensor -> contiguous numpy array of the same dtype and length) on
+        ``stream``; returns the futures of the chunks (the copy is complete when all of them are)."""
+        torch = self.torch
+        src_b = src.view(torch.uint8)
+        dst_b = dst.view(np.uint8).reshape(-1)
+        n_bytes = src_b.numel()
+        assert dst_b.shape[0] == n_bytes
+        futs = []
+        for a in range(0, n_bytes, self.slot_bytes):
+            n = min(self.slot_bytes, n_bytes - a)
+            i = self.free.get()
+            with torch.cuda.stream(stream):
+                self.slots[i][:n].copy_(src_b[a:a + n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            futs.append(self.pool.submit(self._land, i, ev, dst_b[a:a + n], n))
+        return futs
 
 
 class CsrDrain:
@@ -302,16 +411,31 @@ class CsrDrain:
         self.busy_seconds = 0.0
         device = torch.cuda.current_device()
         lib = _lib.load()
+        ring = None if os.environ.get("ICV_NO_PINNED_D2H") else _PinnedRing.get(torch)  # knob: A/B timing
+        self._pending = []  # futures of chunks on their way into indices_h / data_h
+
+        def settle():
+            pending, self._pending = self._pending, []
+            for f in pending:
+                f.result()
+
+        self._settle = settle
 
         def reserve(extra, rows_after):
             need = self.nnz + extra
             if need <= self.indices_h.shape[0]:
                 return
+            settle()  # the arrays are about to be replaced
             # density so far extrapolated to all rows, + 25 %
             est = int(need / max(rows_after, 1) * self.n_rows * 1.25) + 1024 if rows_after < self.n_rows else need
             cap = max(need, est)
             # (plain allocations: huge-page-advised mappings were measured and are 2x slower to fill from the device)
             idx, dat = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.float64)
+            # Fresh pages are mapped (and zeroed) by the kernel at first touch.  Left to the device -> host copy, those
+            # faults happen inside the driver's copy path, one at a time, and slow the uploads running beside it as
+            # well (measured: 39 instead of 55 GB/s host -> HBM).  Touch them here from a few threads instead.
+            if not os.environ.get("ICV_NO_PREFAULT"):  # developer knob for A/B timing
+                _prefault((idx, dat), start=self.nnz)
             idx[: self.nnz] = self.indices_h[: self.nnz]
             dat[: self.nnz] = self.data_h[: self.nnz]
             self.indices_h, self.data_h = idx, dat
@@ -345,8 +469,13 @@ class CsrDrain:
                                 _ptr(part.out), n, self.n_cols, part.out.stride(0), _ptr(part.mask), _ptr(ip), _ptr(idx_d),
                                 _ptr(dat_d), self._stream.cuda_stream))
                             o = self.nnz
-                            torch.from_numpy(self.indices_h[o:o + nnz]).copy_(idx_d)
-                            torch.from_numpy(self.data_h[o:o + nnz]).copy_(dat_d)
+                            if ring is not None:
+                                self._pending += ring.download(idx_d, self.indices_h[o:o + nnz], self._stream)
+                                self._pending += ring.download(dat_d, self.data_h[o:o + nnz], self._stream)
+                            else:
+                                torch.from_numpy(self.indices_h[o:o + nnz]).copy_(idx_d)
+                                torch.from_numpy(self.data_h[o:o + nnz]).copy_(dat_d)
+                            # (freed in stream order: the allocator reuses the blocks behind the copies enqueued above)
                             del idx_d, dat_d
                         self.indptr_h[self.rows_done + 1:self.rows_done + n + 1] = ip_h[1:] + self.nnz
                         self.rows_done += n
@@ -355,6 +484,10 @@ class CsrDrain:
                         self.busy_seconds += time.perf_counter() - t0
             except BaseException as e:  # surfaced in finish()
                 self._err = e
+                try:
+                    settle()
+                except BaseException:
+                    pass
                 while True:  # keep consuming (and releasing) submitted parts until the sentinel arrives
                     try:
                         if self._q.get(timeout=60) is None:
@@ -381,6 +514,7 @@ class CsrDrain:
         self._thread.join()
         if self._err is not None:
             raise self._err
+        self._settle()
         assert self.rows_done == self.n_rows, (self.rows_done, self.n_rows)
         if arrays:
             return self.indptr_h, self.indices_h[: self.nnz], self.data_h[: self.nnz]
@@ -395,6 +529,10 @@ class CsrDrain:
             self._q.put(None)
         if self._thread.is_alive():
             self._thread.join()
+        try:
+            self._settle()
+        except BaseException:
+            pass
 
 
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,

@@ -20,6 +20,7 @@
 #include "icv_kernel_ws.hpp"
 #include "icv_kernel_x16.hpp"
 #include "icv_kernel_sd.hpp"
+#include "icv_kernel_se.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -71,7 +72,8 @@ struct icv_plan_s {
     int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
     uint32_t* d_x16_wdesc = nullptr;
-    int32_t *d_w_srel = nullptr, *d_blk_g0 = nullptr;  // k_smooth_ws prefix-sum form
+    int32_t *d_w_srel = nullptr, *d_blk_g0 = nullptr;  // k_smooth_sd
+    uint32_t *d_se_w0 = nullptr, *d_se_w1 = nullptr;   // k_smooth_se (plan: se_window_words)
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
     // Gene sets whose padded row does not fit LDS (float32: > ~40 000 genes, float64: > ~20 000): the
@@ -183,6 +185,8 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
     HIP_TRY(up(p.w_srel.data(), p.w_srel.size() * 4, (void**)&pl->d_w_srel));
     HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
+    HIP_TRY(up(p.se_w0.data(), p.se_w0.size() * 4, (void**)&pl->d_se_w0));
+    HIP_TRY(up(p.se_w1.data(), p.se_w1.size() * 4, (void**)&pl->d_se_w1));
     pl->zrow_elems = (size_t)icv::round_up(p.Gp, 4) + 4;  // >= Gp + 1: the trash slot reads 0
     HIP_TRY(hipMalloc(&pl->d_zrow, pl->zrow_elems * 8));
     pl->device = dev;
@@ -349,6 +353,14 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
             return ICV_OK;
         }
         (void)hipFree(d);
+        if (lds == icv::kSeLds) {  // k_smooth_se (-DICV_SE_PROFILE=<thread>): work of phase 0..3, each followed by its barrier wait
+            std::fprintf(stderr, "[icv se profile] grid=%lld rows=%lld cycles per cell of the profiled thread:", (long long)grid,
+                         (long long)K.n_rows);
+            const char* nm[8] = {"ph0", "A", "ph1", "B1", "ph2", "B2", "ph3", "B3"};
+            for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)h[i] / (double)K.n_rows);
+            std::fprintf(stderr, "\n");
+            return ICV_OK;
+        }
         if (lds == icv::kSdLds) {  // k_smooth_sd (-DICV_SD_PROFILE): work of phase 0..4, each followed by its barrier wait
             std::fprintf(stderr, "[icv sd profile] grid=%lld rows=%lld cycles per cell (thread 64):", (long long)grid,
                          (long long)K.n_rows);
@@ -489,6 +501,92 @@ int launch_smooth_sd(icv_plan_t pl, icv::KParams K, int sd_k, hipStream_t st, hi
     if (rc) return rc;
     hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
                        K.n_rows, K.cell_stats);
+    pl->last_kernel = ICV_KERNEL_SD;
+    return launch_hand_back(pl, K, st, true);
+}
+
+// k_smooth_se: fraction bits of its bins.  A bin starts at 1.5 * 2^52 and must stay within 2^51 of it: at most B
+// entries of |d| <= 2 cap each in S0 (units 2^-k0), sum of j |d| <= B (B - 1) / 2 * 2 cap in S1 (units 2^-k1).  Fewer
+// than 40 bits (a clip value beyond ~100) and the geometry falls back to k_smooth_sd / the kernels with a row in LDS.
+bool se_fraction_bits(const icv::Plan& p, double cap, int* k0, int* k1) {
+    if (!p.se_ok || std::getenv("ICV_SE_OFF")) return false;  // ICV_SE_OFF: developer knob, the first generation
+    int e = 0;
+    (void)std::frexp((double)p.B * 2.0 * cap + 1.0, &e);  // < 2^e
+    const int a = 51 - e;
+    (void)std::frexp((double)p.B * (double)(p.B - 1) * cap + 1.0, &e);
+    const int b = 51 - e;
+    if (a < 40 || b < 36) return false;
+    *k0 = a;
+    *k1 = b;
+    return true;
+}
+
+// the CSR float32 input takes the stored-entries kernels: 2 = k_smooth_se, 1 = k_smooth_sd, 0 = neither; *sd_k: the
+// fraction bits of the fixed-point bins of k_smooth_sd.  (Same test in launch_smooth and in the chunk-moment set-up
+// of icv_infercnv_run.)
+int stored_entries_kernel(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
+                          int* sd_k) {
+    if (!(lay.fits && m->dtype == ICV_F32 && m->format == ICV_CSR && std::isfinite(K.cap) &&
+          m->csr_end > m->csr_begin && !std::getenv("ICV_FORCE_GENERIC")))
+        return 0;
+    if (std::getenv("ICV_NO_SD")) return 0;  // developer knob: the CSR kernels that build the row in LDS
+    int k0 = 0, k1 = 0;
+    if (se_fraction_bits(pl->p, K.cap, &k0, &k1)) return 2;
+    const int k = sd_fraction_bits(pl->p, K.cap);
+    if (k < 0) return 0;
+    if (sd_k) *sd_k = k;
+    return 1;
+}
+
+// k_smooth_se (icv_kernel_se.hpp): the second generation of the stored-entries kernel
+int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t kernel_done = nullptr) {
+    const icv::Plan& p = pl->p;
+    int k0 = 0, k1 = 0;
+    if (!se_fraction_bits(p, K.cap, &k0, &k1)) return fail(ICV_ERR_INVALID, "k_smooth_se does not apply");
+    AsyncBuf tab_guard, hi_guard, wt_guard, g_guard;  // per-column, per-window, per-block tables: released on every exit path
+    const int nz = (int)pl->zrow_elems;
+    hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
+                       static_cast<float*>(pl->d_zrow), nz);
+    HIP_TRY(tab_guard.alloc((size_t)K.n_cols * 16, st));
+    HIP_TRY(wt_guard.alloc((size_t)p.W * 16, st));
+    HIP_TRY(g_guard.alloc((size_t)(p.NB + 8) * 4, st));
+    if (K.bounded) HIP_TRY(hi_guard.alloc((size_t)K.n_cols * 4, st));
+    K.sd_tab = tab_guard.p;
+    K.sd_tab_hi = K.bounded ? hi_guard.as<float>() : nullptr;
+    K.sd_wtab = wt_guard.p;
+    K.sd_g16 = g_guard.as<float>();
+    K.sd_scale = std::ldexp(1.0, k0);
+    K.sd_qinv = std::ldexp(1.0, -k0);
+    K.sd_q1inv = std::ldexp(1.0, -k1);
+    K.sd_r = std::ldexp(1.0, k1 - k0);
+    K.sd_window = p.window;
+    hipLaunchKernelGGL(icv::k_se_table, dim3((unsigned)((K.n_cols + 255) / 256)), dim3(256), 0, st, K,
+                       tab_guard.as<icv::u32x4>(), const_cast<float*>(K.sd_tab_hi), (float)std::ldexp(1.0, k1));
+    const int n_wt = p.W > p.NB + 8 ? p.W : p.NB + 8;
+    hipLaunchKernelGGL(icv::k_se_wtab, dim3((unsigned)((n_wt + 255) / 256)), dim3(256), 0, st, K,
+                       static_cast<const float*>(pl->d_zrow), pl->d_se_w0, pl->d_se_w1, wt_guard.as<icv::u32x4>(),
+                       g_guard.as<float>(), (float)K.sd_r);
+    if (int rc = hand_back_workspace(pl, K, st)) return rc;
+    int per_cu = icv::kLdsLimit / icv::kSeLds;
+    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
+        const int v = std::atoi(e);
+        if (v >= 1 && v < per_cu) per_cu = v;
+    }
+    int64_t grid = (int64_t)pl->n_cu * per_cu;
+    if (grid > K.n_rows) grid = K.n_rows;
+    if (grid < 1) {
+        if (kernel_done) HIP_TRY(hipEventRecord(kernel_done, st));
+        return ICV_OK;
+    }
+    void (*kern)(const icv::KParams);
+    if (K.chunk_part) kern = K.bounded ? icv::k_smooth_se<4, true, true> : icv::k_smooth_se<4, true, false>;
+    else kern = K.bounded ? icv::k_smooth_se<4, false, true> : icv::k_smooth_se<4, false, false>;
+    int rc = run_kernel(kern, grid, icv::kSeLds, K, st);
+    if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
+    if (rc) return rc;
+    if (!K.chunk_part)
+        hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
+                           K.n_rows, K.cell_stats);
     pl->last_kernel = ICV_KERNEL_SD;
     return launch_hand_back(pl, K, st, true);
 }
@@ -703,10 +801,11 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
         }
     }
     if (fast_allowed && m->format == ICV_CSR && m->csr_end > m->csr_begin) {
-        const int sd_k = sd_fraction_bits(pl->p, K.cap);
-        if (sd_k >= 0) {
+        int sd_k = -1;
+        const int gen = stored_entries_kernel(pl, m, K, lay, &sd_k);
+        if (gen) {
             if (recorded) *recorded = kernel_done != nullptr;
-            return launch_smooth_sd(pl, K, sd_k, st, kernel_done);
+            return gen == 2 ? launch_smooth_se(pl, K, st, kernel_done) : launch_smooth_sd(pl, K, sd_k, st, kernel_done);
         }
         if (pl->p.ws_ok && aligned16(K.ref_lo)) {
             const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
@@ -801,6 +900,8 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_x16_wdesc);
         (void)hipFree(pl->d_w_srel);
         (void)hipFree(pl->d_blk_g0);
+        (void)hipFree(pl->d_se_w0);
+        (void)hipFree(pl->d_se_w1);
         (void)hipFree(pl->d_zrow);
         if (pl->done_ev) (void)hipEventDestroy(pl->done_ev);
     }
@@ -887,7 +988,9 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         HIP_TRY(hipGetLastError());
         return ICV_OK;
     }
-    const int rows_per_slab = 256;
+    // slab height from the row count alone (the sums must not depend on the device): 1024 rows stream fastest
+    // (tools/microbench_colsum.hip), shorter slabs keep every CU busy on small matrices
+    const int rows_per_slab = m->n_rows >= 65536 ? 1024 : 256;
     const int64_t n_slabs = (m->n_rows + rows_per_slab - 1) / rows_per_slab;
     AsyncBuf partial_b;
     HIP_TRY(partial_b.alloc((size_t)n_slabs * nc * sizeof(double), st));
@@ -990,8 +1093,11 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
             pl->hb_stats_cap = m->n_rows;
         }
         K.cell_stats = pl->d_hb_stats;
+        // k_smooth_x16: n_cu workgroups x 16 wavefronts; k_smooth_se: 2 n_cu workgroups x 8 wavefronts
         const int64_t n_part = (int64_t)pl->n_cu * icv::XWAVE;
-        if (x16_applies(pl, m, K, *lay) && n_chunks * n_part <= (int64_t)(64 << 20) / 16) {
+        static_assert(icv::XWAVE == 2 * icv::NWAVE, "one partial-moment slot per wavefront of a CU");
+        if ((x16_applies(pl, m, K, *lay) || stored_entries_kernel(pl, m, K, *lay, nullptr) == 2) &&
+            n_chunks * n_part <= (int64_t)(64 << 20) / 16) {
             chunk_mode = true;
             if (pl->chunk_part_cap < n_chunks * n_part) {
                 (void)hipFree(pl->d_chunk_part);
@@ -1019,11 +1125,22 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     if ((rc = launch_smooth(pl, m, K, *lay, st, timed ? ev[1] : nullptr, &ev1_done))) return rc;
     if (timed && !ev1_done) HIP_TRY(hipEventRecord(ev[1], st));
     if (do_thr && chunk_mode) {
-        // workgroups of the x16 launch: min(CUs, rows); slots of absent workgroups are zero
-        int64_t gx = pl->n_cu;
-        if (gx > m->n_rows) gx = m->n_rows;
+        // partial slots of the launch: min(CUs, rows) workgroups x 16 wavefronts (k_smooth_x16), min(2 CUs, rows) x 8
+        // (k_smooth_se); slots of absent workgroups are zero
+        int64_t n_slots;
+        if (m->format == ICV_CSR) {
+            int64_t gx = 2 * (int64_t)pl->n_cu;
+            if (const char* e = std::getenv("ICV_WGS_PER_CU"))
+                if (std::atoi(e) == 1) gx = pl->n_cu;
+            if (gx > m->n_rows) gx = m->n_rows;
+            n_slots = gx * icv::NWAVE;
+        } else {
+            int64_t gx = pl->n_cu;
+            if (gx > m->n_rows) gx = m->n_rows;
+            n_slots = gx * icv::XWAVE;
+        }
         hipLaunchKernelGGL(icv::k_chunk_thr_part, dim3((unsigned)n_chunks), dim3(256), 0, st, pl->d_chunk_part,
-                           (int)(gx * icv::XWAVE), pl->d_hb_stats, m->n_rows, chunksize, row_phase, pl->p.W,
+                           (int)n_slots, pl->d_hb_stats, m->n_rows, chunksize, row_phase, pl->p.W,
                            dynamic_threshold, thr);
         HIP_TRY(hipGetLastError());
     } else if (do_thr && m->n_rows > 0) {

@@ -64,6 +64,10 @@ struct Plan {
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
     bool ws_ok = false;              // ... and the wave-specialised k_smooth_ws
     bool sd_ok = false;              // geometry admits k_smooth_sd (CSR float32 input: stored entries only)
+    // k_smooth_se (the second generation of that kernel): per window the LDS slots of its three prefix sums and the
+    // wavefront totals to add, packed into two words (se_window_words)
+    bool se_ok = false;
+    std::vector<uint32_t> se_w0, se_w1;
     int fast_lds = 0, fast_scratch_off = 0, ws_win_off = 0, ws_hist_off = 0;
     // k_smooth_sp (one 1024-thread workgroup per CU): row | {S0,S1} | histogram | scratch, nothing aliased
     bool sp_ok = false;
@@ -76,6 +80,28 @@ struct Plan {
     std::vector<uint32_t> x16_wdesc;  // per thread: the pair of adjacent windows it owns (icv_kernels.hpp KParams)
     Layout lay32, lay64;
 };
+
+// k_smooth_se keeps the per-block sums {S0, T1} of a cell -- and then their prefix sums over the blocks of each
+// WAVEFRONT (thread t of 512 owns blocks 8 t .. 8 t + 7, wavefront w blocks 512 w .. 512 w + 511) -- at slot
+// (b & 7) * 513 + (b >> 3) of its LDS planes (16 bytes per slot; slot 512 of plane 0 is never written: zero).
+// A window needs the prefix at the block before it (b-), at the last block of its first half (m1) and at its last
+// block (m2); differences of prefixes of one wavefront are exact differences, and where m1 / m2 lie in the
+// wavefront after that of b- the total of b-'s wavefront is added (a window is shorter than 512 blocks).
+//   w0 = slot(b-) | slot(m1) << 13 | tm << 26 | flat << 31      tm / te: index into tot[16] of the total to add to the
+//   w1 = slot(m2) | sg << 13 | te << 27                         prefix at m1 / m2: wavefront of b-, or 8 + it (zero)
+// sg: gene offset of the window inside its chromosome (pyramid), or the gene count of the chromosome (flat window).
+constexpr int kSePlane = 513;
+constexpr int se_slot(int b) { return (b & 7) * kSePlane + (b >> 3); }
+constexpr int kSeZeroSlot = 512;  // plane 0, slot 512
+inline void se_window_words(int bs, int nbw, int hbw, bool flat, int flat_blocks, int sg, uint32_t& w0, uint32_t& w1) {
+    const int wb = bs > 0 ? (bs - 1) >> 9 : 0;
+    const int m1 = flat ? bs : bs + hbw - 1;
+    const int m2 = bs + (flat ? flat_blocks : nbw) - 1;
+    const uint32_t sb = bs > 0 ? (uint32_t)se_slot(bs - 1) : (uint32_t)kSeZeroSlot;
+    const uint32_t tm = (uint32_t)(((m1 >> 9) != wb) ? wb : 8 + wb), te = (uint32_t)(((m2 >> 9) != wb) ? wb : 8 + wb);
+    w0 = sb | ((uint32_t)se_slot(m1) << 13) | (tm << 26) | ((flat ? 1u : 0u) << 31);
+    w1 = (uint32_t)se_slot(m2) | ((uint32_t)sg << 13) | (te << 27);
+}
 
 inline int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -254,6 +280,20 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
         // k_smooth_sd: block bins in 8 planes of 512 slots, four windows per thread of a 512-thread workgroup; the
         // cells it hands back go to the generic kernel (one row in LDS)
         p.sd_ok = window % 2 == 0 && p.NB <= 8 * kThreads && p.W <= 4 * kThreads && p.lay32.fits;
+        // k_smooth_se: windows shorter than a wavefront's 512 blocks, gene offsets that fit the 14-bit field
+        p.se_ok = p.sd_ok && window / B <= 512;
+        for (int c = 0; c < n_chr && p.se_ok; ++c) p.se_ok = p.pad_off[c + 1] - p.pad_off[c] < 16384;
+        p.se_w0.clear(); p.se_w1.clear();
+        if (p.se_ok) {
+            p.se_w0.resize(p.W);
+            p.se_w1.resize(p.W);
+            const int nbw = window / B, hbw = nbw / 2;
+            for (int j = 0; j < p.W; ++j) {
+                const bool flat = p.w_len[j] < 0;
+                se_window_words(p.w_start[j] / B, nbw, hbw, flat, flat ? -p.w_len[j] / B : 0,
+                                flat ? (int)p.w_denom[j] : p.w_srel[j], p.se_w0[j], p.se_w1[j]);
+            }
+        }
     }
 
     // fast path: float32 dense, blocked form, row + tables fit the register/LDS budget

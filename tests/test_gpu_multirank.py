@@ -406,6 +406,7 @@ def test_public_api_shard_failure_is_raised_and_leaves_no_threads(monkeypatch):
             raise RuntimeError("injected failure")
         return real(*a, **k)
 
+    _api_run(X, obs, var, devices=[0], reference=ref)  # (the process-wide pinned staging ring starts its threads once)
     monkeypatch.setattr(_engine, "run_hot_path", flaky)
     before = threading.active_count()
     for devs in ([0, 0, 0], [0]):
