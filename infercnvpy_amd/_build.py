@@ -48,6 +48,17 @@ def _accepts(hipcc: str, flags: list[str]) -> bool:
         return r.returncode == 0
 
 
+def _extra_flags() -> list[str]:
+    """ICV_EXTRA_HIPCC_FLAGS for tuning builds.  The upper-bound experiments of the kernels (code behind
+    ICV_DEV_EXPERIMENTS: they produce WRONG results on purpose) never go into the package's library: they are built
+    side by side with tools/build_variant.sh."""
+    flags = os.environ.get("ICV_EXTRA_HIPCC_FLAGS", "").split()
+    if any("ICV_DEV_EXPERIMENTS" in f or "_EXP_" in f for f in flags):
+        raise RuntimeError("ICV_EXTRA_HIPCC_FLAGS: experiment switches (ICV_DEV_EXPERIMENTS / *_EXP_*) are refused for "
+                           "the package library; use tools/build_variant.sh")
+    return flags
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
@@ -63,7 +74,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         *vgpr_form,
         "-Wall", "-Wno-unused-function",
         "-o", LIB + ".tmp",
-    ] + os.environ.get("ICV_EXTRA_HIPCC_FLAGS", "").split() + SOURCES
+    ] + _extra_flags() + SOURCES
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
 #else
 #define ICV_SEP(i)
 #endif
+    // (Static wave priority by age -- the arbiter prefers the older wavefronts of a SIMD, so wavefront 7 reaches every
+    // barrier last -- was measured in three gradings: it moves the barrier waits to other wavefronts and leaves the
+    // kernel time unchanged, 6.3 ms: the SIMDs' instruction issue is what bounds the kernel.)
     __syncthreads();
 #ifdef ICV_SE_PROFILE
     if (P.dbg && t == ICV_SE_PROFILE) sc->tacc[8] = __builtin_amdgcn_s_memtime();
@@ -472,8 +475,19 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
                 const int n = ncr < 64 ? ncr : 64;
                 const double mine = (lane < n) ? mine_raw : __builtin_inf();
                 int r = 0;
-                for (int q = 0; q < n; ++q) {  // n is wavefront-uniform (typically 2..4)
-                    const double o = readlane_d(mine, q);
+                // n is wavefront-uniform (5 .. 20 windows share the median bins); the other candidates come as LDS
+                // broadcast reads, four in flight (lane reads through SGPRs serialise: measured 1 700 cycles here)
+                int q = 0;
+                for (; q + 4 <= n; q += 4) {
+                    const double2 oa = *reinterpret_cast<const double2*>(sc->cand + q);
+                    const double2 ob = *reinterpret_cast<const double2*>(sc->cand + q + 2);
+                    r += (int)(oa.x < mine) | ((int)(oa.x == mine) & (int)(q < lane));
+                    r += (int)(oa.y < mine) | ((int)(oa.y == mine) & (int)(q + 1 < lane));
+                    r += (int)(ob.x < mine) | ((int)(ob.x == mine) & (int)(q + 2 < lane));
+                    r += (int)(ob.y < mine) | ((int)(ob.y == mine) & (int)(q + 3 < lane));
+                }
+                for (; q < n; ++q) {
+                    const double o = sc->cand[q];
                     r += (int)(o < mine) | ((int)(o == mine) & (int)(q < lane));
                 }
                 const unsigned long long m1 = __builtin_amdgcn_ballot_w64(lane < n && r == k1 - s.z);

@@ -95,17 +95,8 @@ __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_sca
 #ifndef ICV_X_WCH
 #define ICV_X_WCH 2  // {S0,S1} pairs of a window read per batch (register budget: 5 spills next to the resident tables)
 #endif
-#ifndef ICV_X_PRIO
-#define ICV_X_PRIO 0  // wave priority experiments: 1 static by age (youngest first), 2 rotating per iteration
-#endif
-#ifndef ICV_X_LFIRST
-#define ICV_X_LFIRST 0  // 1: odd wavefronts run L before W in phase B (LDS-write-bound next to float64-bound work)
-#endif
 #ifndef ICV_X_ROW_AUX
 #define ICV_X_ROW_AUX 2  // cache policy of the row loads: nt (the row is read once, by one CU): -3 % kernel time in alternating runs
-#endif
-#ifndef ICV_X_ADDR
-#define ICV_X_ADDR 1  // 1: LDS byte addresses of the scatter resident (20 VGPRs) instead of the packed table (10)
 #endif
 
 // CHUNK: the moments of x_res are accumulated per thread over the consecutive cells of a noise-threshold chunk and
@@ -147,24 +138,24 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     // ---- per-thread constants, loaded once -------------------------------------------------------
     u32x4 refv[REFRES ? XU : 1];
     const __amdgpu_buffer_rsrc_t ref_rs = make_rsrc(P.ref_lo, row_bytes);
-#if ICV_X_ADDR
-    unsigned laddr[XU][4];
-#else
-    u32x2 dtab[XU];
-#endif
+    unsigned laddr[XU][4];  // LDS byte addresses of the thread's 20 genes, resident for the whole kernel
     {
         const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(XU * XT * 8));
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             if constexpr (REFRES) refv[u] = __builtin_amdgcn_raw_buffer_load_b128(ref_rs, voff, u * XT * 16, 0);
             const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(d16_rs, (unsigned)t * 8u, u * XT * 8, 0);
-#if ICV_X_ADDR
             laddr[u][0] = (d.x & 0xffffu) * 4u;
             laddr[u][1] = (d.x >> 16) * 4u;
             laddr[u][2] = (d.y & 0xffffu) * 4u;
             laddr[u][3] = (d.y >> 16) * 4u;
-#else
-            dtab[u] = d;
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_LINSCAT)
+            // upper-bound experiment (WRONG RESULTS; tools/build_variant.sh only): conflict-free scatter addresses
+            laddr[u][0] = ((unsigned)(u * 4 + 0) * 1000u + (unsigned)t) * 4u;
+            laddr[u][1] = ((unsigned)(u * 4 + 1) * 1000u + (unsigned)t) * 4u;
+            laddr[u][2] = ((unsigned)(u * 4 + 2) * 1000u + (unsigned)t) * 4u;
+            laddr[u][3] = ((unsigned)(u * 4 + 3) * 1000u + (unsigned)t) * 4u;
+            if (t >= 1000) laddr[u][0] = laddr[u][1] = laddr[u][2] = laddr[u][3] = 80000u;
 #endif
         }
     }
@@ -205,13 +196,19 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);
     }
-    unsigned two = 2u;
-    asm volatile("" : "+v"(two));  // a VGPR operand for the SDWA shifts
 
     // centre, clip and scatter the row in xq, re-requesting every vector for cell `c_next` as it is consumed
     auto l_phase = [&](int64_t c_next) __attribute__((always_inline)) {
         const bool more = c_next < P.n_rows;
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_NOLOAD)
+        // upper-bound experiment (WRONG RESULTS; tools/build_variant.sh only): empty range, no HBM row traffic
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase, (more && c_next < 0) ? row_bytes : 0u);
+#elif defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_L2ROW)
+        // upper-bound experiment (WRONG RESULTS): every cell re-reads the workgroup's first row (L2 hits)
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, more ? row_bytes : 0u);
+#else
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (more ? c_next : 0) * P.ld, more ? row_bytes : 0u);
+#endif
         u32x4 rloc[REFRES ? 1 : XU];
         if constexpr (!REFRES) {
 #pragma unroll
@@ -220,13 +217,15 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             const u32x4 rv = REFRES ? refv[REFRES ? u : 0] : rloc[REFRES ? 0 : u];
-            const float y0 = __uint_as_float(xq[u].x) - __uint_as_float(rv.x);
-            const float y1 = __uint_as_float(xq[u].y) - __uint_as_float(rv.y);
-            const float y2 = __uint_as_float(xq[u].z) - __uint_as_float(rv.z);
-            const float y3 = __uint_as_float(xq[u].w) - __uint_as_float(rv.w);
+            // two subtractions per instruction (v_pk_add_f32 with negated second operand)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 ya = f32x2{__uint_as_float(xq[u].x), __uint_as_float(xq[u].y)} -
+                             f32x2{__uint_as_float(rv.x), __uint_as_float(rv.y)};
+            const f32x2 yb = f32x2{__uint_as_float(xq[u].z), __uint_as_float(xq[u].w)} -
+                             f32x2{__uint_as_float(rv.z), __uint_as_float(rv.w)};
+            const float y0 = ya.x, y1 = ya.y, y2 = yb.x, y3 = yb.y;
             // v_med3 drops NaNs, np.clip keeps them: unordered pairs take the (never taken on real data) fix-up
             const bool un = __builtin_isunordered(y0, y1) | __builtin_isunordered(y2, y3);
-#if ICV_X_ADDR
             ICV_LDS_F32_AT(laddr[u][0]) = __builtin_amdgcn_fmed3f(y0, -cap, cap);
             ICV_LDS_F32_AT(laddr[u][1]) = __builtin_amdgcn_fmed3f(y1, -cap, cap);
             ICV_LDS_F32_AT(laddr[u][2]) = __builtin_amdgcn_fmed3f(y2, -cap, cap);
@@ -237,30 +236,14 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 if (y2 != y2) ICV_LDS_F32_AT(laddr[u][2]) = y2;
                 if (y3 != y3) ICV_LDS_F32_AT(laddr[u][3]) = y3;
             }
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_NOLOAD)
+            asm volatile("" : "+v"(xq[u]));  // the workgroup's first row stays in the registers: no row traffic at all
 #else
-            ICV_LDS_F32_AT(lds_off_lo16(dtab[u].x, two)) = __builtin_amdgcn_fmed3f(y0, -cap, cap);
-            ICV_LDS_F32_AT(lds_off_hi16(dtab[u].x, two)) = __builtin_amdgcn_fmed3f(y1, -cap, cap);
-            ICV_LDS_F32_AT(lds_off_lo16(dtab[u].y, two)) = __builtin_amdgcn_fmed3f(y2, -cap, cap);
-            ICV_LDS_F32_AT(lds_off_hi16(dtab[u].y, two)) = __builtin_amdgcn_fmed3f(y3, -cap, cap);
-            if (__builtin_expect(un, 0)) {
-                unsigned dx = dtab[u].x, dy = dtab[u].y;
-                asm volatile("" : "+v"(dx), "+v"(dy));  // keep the unpacked addresses out of LICM (20 VGPRs)
-                if (y0 != y0) row[dx & 0xffffu] = y0;
-                if (y1 != y1) row[dx >> 16] = y1;
-                if (y2 != y2) row[dy & 0xffffu] = y2;
-                if (y3 != y3) row[dy >> 16] = y3;
-            }
-#endif
             xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);  // out of range: zeros, no traffic
+#endif
         }
     };
 
-#if ICV_X_PRIO == 1  // static: the younger wavefronts of a SIMD (arbitration losers at equal priority) go first
-    if ((t >> 8) == 0) __builtin_amdgcn_s_setprio(0);
-    else if ((t >> 8) == 1) __builtin_amdgcn_s_setprio(1);
-    else if ((t >> 8) == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-#endif
     // the first row is scattered before the loop; its successor is requested right away
     l_phase((int64_t)blockIdx.x + gridDim.x);
 
@@ -309,7 +292,11 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
 
         // =============================== phase A ================================================
         const int ts = tl - XT / 2;  // wavefronts 8..15 (wavefronts 0, 1 carry the median chains of this phase)
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_NOSTORE)
+        if (st16 && it >= 3 && ts >= 0 && 4 * ts < W && P.dbg) {  // upper-bound experiment (WRONG RESULTS): no x_res stores
+#else
         if (st16 && it >= 3 && ts >= 0 && 4 * ts < W) {
+#endif
             // ---- x_res of cell it-3, staged in LDS by phase B of the previous iteration: one 16-byte store ----
             float* orow = P.out + (cell - 3 * (int64_t)gridDim.x) * P.ldo;
             const float4 q = *reinterpret_cast<const float4*>(stage + 4 * ts);
@@ -461,15 +448,6 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         __syncthreads();  // barrier 1: {S0,S1} of cell it complete, row dead; bins / median published
         ICV_XPH(1)
         asm volatile("" : "+v"(tl));
-#if ICV_X_PRIO == 2  // rotating: each wavefront of a SIMD is the preferred one in one of four consecutive phases
-        {
-            const int q = (__builtin_amdgcn_readfirstlane(tl >> 8) + (int)(it & 3)) & 3;
-            if (q == 0) __builtin_amdgcn_s_setprio(0);
-            else if (q == 1) __builtin_amdgcn_s_setprio(1);
-            else if (q == 2) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(3);
-        }
-#endif
 
         // =============================== phase B ================================================
         // ---- x_res of cell it-2 from its windows (still in wvA): staged in LDS (stored as 16-byte vectors by phase
@@ -564,10 +542,6 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             if (tl < XREP * XCOARSE) coarse[p1 * (XREP * XCOARSE) + tl] = zero;
         }
         ICV_XPH(4)
-#if ICV_X_LFIRST
-        const bool l_first = (__builtin_amdgcn_readfirstlane(tl >> 6) & 1) != 0;
-        if (l_first && cell + gridDim.x < P.n_rows) l_phase(cell + 2 * (int64_t)gridDim.x);
-#endif
         if (have0 && wave_w) {
             // ---- W: windows 2t, 2t+1 of cell it from {S0,S1}, histogram atomics --------------------
             double v0, v1;
@@ -660,13 +634,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             if (w0 && vs != vs) sc->nanflag[p0] = 1;  // benign race: every writer stores 1
         }
         ICV_XPH(5)
-#if ICV_X_LFIRST  // odd wavefronts ran the L phase before W (below)
-        const int64_t nxt = cell + gridDim.x;
-        if (!l_first && nxt < P.n_rows) l_phase(nxt + gridDim.x);
-#else
         const int64_t nxt = cell + gridDim.x;
         if (nxt < P.n_rows) l_phase(nxt + gridDim.x);
-#endif
         if (have2) {
             const int64_t pcell = cell - 2 * (int64_t)gridDim.x;
             if (!st16) {  // unaligned result rows: 4-byte stores, after the row loads of the L phase
