@@ -19,7 +19,6 @@
 #include "icv_kernels.hpp"
 #include "icv_kernel_ws.hpp"
 #include "icv_kernel_x16.hpp"
-#include "icv_kernel_sd.hpp"
 #include "icv_kernel_se.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
@@ -72,7 +71,7 @@ struct icv_plan_s {
     int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
     uint32_t* d_x16_wdesc = nullptr;
-    int32_t *d_w_srel = nullptr, *d_blk_g0 = nullptr;  // k_smooth_sd
+    int32_t* d_blk_g0 = nullptr;  // per block: first-gene offset inside its chromosome (k_se_wtab)
     uint32_t *d_se_w0 = nullptr, *d_se_w1 = nullptr;   // k_smooth_se (plan: se_window_words)
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
     size_t zrow_elems = 0;
@@ -183,7 +182,6 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
-    HIP_TRY(up(p.w_srel.data(), p.w_srel.size() * 4, (void**)&pl->d_w_srel));
     HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
     HIP_TRY(up(p.se_w0.data(), p.se_w0.size() * 4, (void**)&pl->d_se_w0));
     HIP_TRY(up(p.se_w1.data(), p.se_w1.size() * 4, (void**)&pl->d_se_w1));
@@ -305,7 +303,6 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.pad_idx = pl->d_pad;
     K.w_pack = pl->d_wpack;
     K.x16_wdesc = pl->d_x16_wdesc;
-    K.w_srel = pl->d_w_srel;
     K.blk_g0 = pl->d_blk_g0;
     K.x16_half = p.x16_half;
     K.n_pad = (int32_t)p.pad_idx.size();
@@ -361,16 +358,6 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
             std::fprintf(stderr, "\n");
             return ICV_OK;
         }
-        if (lds == icv::kSdLds) {  // k_smooth_sd (-DICV_SD_PROFILE): work of phase 0..4, each followed by its barrier wait
-            std::fprintf(stderr, "[icv sd profile] grid=%lld rows=%lld cycles per cell (thread 64):", (long long)grid,
-                         (long long)K.n_rows);
-            // ph1 = locate + entries, ph2 = gather + scan, ph4 = stores + windows + moments
-            const char* nm[14] = {"ph0", "A", "entries", "B1", "scan", "B2", "ph3", "B3", "moments", "B4",
-                                  "locate", "gather", "stores", "windows"};
-            for (int i = 0; i < 14; ++i) std::fprintf(stderr, " %s %.0f", nm[i], (double)h[i] / (double)K.n_rows);
-            std::fprintf(stderr, "\n");
-            return ICV_OK;
-        }
         const char* names[6] = {"L load+scatter", "S block sums", "W windows", "M2 rank/select", "O output",
                                 "M1 pivot search"};
         double tot = 0;
@@ -399,25 +386,6 @@ bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K
            ((p.B == 10 && p.window == 100 && p.x16_fine == 4096) || (p.B == 5 && p.window == 250 && p.x16_fine == 1024));
 }
 
-// CSR float32 input in block form: fraction bits of the fixed-point bins of k_smooth_sd, or -1 when the kernel does
-// not apply (geometry: Plan::sd_ok).  A bin holds at most B entries: |S0| <= B * 2 cap * 2^k and
-// |S1| <= B (B - 1) / 2 * 2 cap * 2^k must stay below 2^62; fewer than 46 fraction bits (a clip value beyond ~1e3)
-// would no longer be negligible next to the float64 rounding of the windows.
-int sd_fraction_bits(const icv::Plan& p, double cap) {
-    if (!p.sd_ok) return -1;
-    if (std::getenv("ICV_NO_SD")) return -1;  // developer knob: the CSR kernels that build the row in LDS
-    if (const char* e = std::getenv("ICV_SD_MIN_NBW"))  // developer knob: only windows of more than this many blocks
-        if (p.window / p.B <= std::atoi(e)) return -1;
-    const double per_bin = (double)p.B * (double)(p.B > 3 ? p.B - 1 : 2) * cap + 1.0;
-    int e = 0;
-    (void)std::frexp(per_bin, &e);  // per_bin < 2^e
-    int k = 62 - e;
-    // one entry: |d| * 2^k <= 2 cap * 2^k must stay below 2^51 (the kernel rounds with the 1.5 * 2^52 addition)
-    (void)std::frexp(2.0 * cap + 1.0, &e);
-    if (k > 51 - e) k = 51 - e;
-    return k >= 46 ? k : -1;
-}
-
 // plan-owned workspace of the kernels that hand cells back to the generic k_smooth: the list of those cells, its
 // counter (zeroed here) and the per-wavefront partial moments
 int hand_back_workspace(icv_plan_t pl, icv::KParams& K, hipStream_t st) {
@@ -432,7 +400,7 @@ int hand_back_workspace(icv_plan_t pl, icv::KParams& K, hipStream_t st) {
         (void)hipFree(pl->d_cell_part);
         pl->d_cell_part = nullptr;
         pl->cell_part_cap = 0;
-        // 16 wavefront partial pairs per cell (k_smooth_x16; k_smooth_ws / k_smooth_sd use the first 8)
+        // 16 wavefront partial pairs per cell (k_smooth_x16; k_smooth_ws / k_smooth_se use the first 8)
         HIP_TRY(hipMalloc((void**)&pl->d_cell_part, (size_t)K.n_rows * 32 * sizeof(double)));
         pl->cell_part_cap = K.n_rows;
     }
@@ -465,51 +433,11 @@ int launch_hand_back(icv_plan_t pl, const icv::KParams& K, hipStream_t st, bool 
     return ICV_OK;
 }
 
-// CSR float32 input, block form (Plan::sd_ok): k_smooth_sd touches the stored entries only -- their differences to
-// the zero row go into fixed-point block bins, windows come off prefix sums (icv_kernel_sd.hpp)
-int launch_smooth_sd(icv_plan_t pl, icv::KParams K, int sd_k, hipStream_t st, hipEvent_t kernel_done = nullptr) {
-    const icv::Plan& p = pl->p;
-    AsyncBuf tab_guard, base_guard;  // per-column table, zero-row window sums: released on every exit path
-    const int nz = (int)pl->zrow_elems;
-    hipLaunchKernelGGL(icv::k_zero_row<float>, dim3((nz + 255) / 256), dim3(256), 0, st, K,
-                       static_cast<float*>(pl->d_zrow), nz);
-    HIP_TRY(tab_guard.alloc((size_t)K.n_cols * 16, st));
-    HIP_TRY(base_guard.alloc((size_t)p.W * sizeof(double), st));
-    K.sd_tab = tab_guard.p;
-    K.sd_base = base_guard.as<double>();
-    K.sd_scale = std::ldexp(1.0, sd_k);
-    K.sd_qinv = std::ldexp(1.0, -sd_k);
-    K.sd_window = p.window;
-    hipLaunchKernelGGL(icv::k_sd_table, dim3((unsigned)((K.n_cols + 255) / 256)), dim3(256), 0, st, K,
-                       tab_guard.as<icv::u32x4>());
-    hipLaunchKernelGGL(icv::k_sd_base, dim3((unsigned)((p.W + 255) / 256)), dim3(256), 0, st, K,
-                       static_cast<const float*>(pl->d_zrow), base_guard.as<double>());
-    if (int rc = hand_back_workspace(pl, K, st)) return rc;
-    int per_cu = icv::kLdsLimit / icv::kSdLds;
-    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
-        const int v = std::atoi(e);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
-    int64_t grid = (int64_t)pl->n_cu * per_cu;
-    if (grid > K.n_rows) grid = K.n_rows;
-    if (grid < 1) {
-        if (kernel_done) HIP_TRY(hipEventRecord(kernel_done, st));
-        return ICV_OK;
-    }
-    int rc = run_kernel(icv::k_smooth_sd<4>, grid, icv::kSdLds, K, st);
-    if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
-    if (rc) return rc;
-    hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st, K.cell_part,
-                       K.n_rows, K.cell_stats);
-    pl->last_kernel = ICV_KERNEL_SD;
-    return launch_hand_back(pl, K, st, true);
-}
-
 // k_smooth_se: fraction bits of its bins.  A bin starts at 1.5 * 2^52 and must stay within 2^51 of it: at most B
 // entries of |d| <= 2 cap each in S0 (units 2^-k0), sum of j |d| <= B (B - 1) / 2 * 2 cap in S1 (units 2^-k1).  Fewer
-// than 40 bits (a clip value beyond ~100) and the geometry falls back to k_smooth_sd / the kernels with a row in LDS.
+// than 40 bits (a clip value beyond ~100) and the input takes the kernels that build the row in LDS.
 bool se_fraction_bits(const icv::Plan& p, double cap, int* k0, int* k1) {
-    if (!p.se_ok || std::getenv("ICV_SE_OFF")) return false;  // ICV_SE_OFF: developer knob, the first generation
+    if (!p.se_ok || std::getenv("ICV_NO_SD")) return false;  // ICV_NO_SD: developer knob, the kernels with a row in LDS
     int e = 0;
     (void)std::frexp((double)p.B * 2.0 * cap + 1.0, &e);  // < 2^e
     const int a = 51 - e;
@@ -521,24 +449,17 @@ bool se_fraction_bits(const icv::Plan& p, double cap, int* k0, int* k1) {
     return true;
 }
 
-// the CSR float32 input takes the stored-entries kernels: 2 = k_smooth_se, 1 = k_smooth_sd, 0 = neither; *sd_k: the
-// fraction bits of the fixed-point bins of k_smooth_sd.  (Same test in launch_smooth and in the chunk-moment set-up
-// of icv_infercnv_run.)
-int stored_entries_kernel(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay,
-                          int* sd_k) {
+// the CSR float32 input takes the stored-entries kernel k_smooth_se (same test in launch_smooth and in the chunk-moment
+// set-up of icv_infercnv_run)
+bool stored_entries_kernel(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay) {
     if (!(lay.fits && m->dtype == ICV_F32 && m->format == ICV_CSR && std::isfinite(K.cap) &&
           m->csr_end > m->csr_begin && !std::getenv("ICV_FORCE_GENERIC")))
-        return 0;
-    if (std::getenv("ICV_NO_SD")) return 0;  // developer knob: the CSR kernels that build the row in LDS
+        return false;
     int k0 = 0, k1 = 0;
-    if (se_fraction_bits(pl->p, K.cap, &k0, &k1)) return 2;
-    const int k = sd_fraction_bits(pl->p, K.cap);
-    if (k < 0) return 0;
-    if (sd_k) *sd_k = k;
-    return 1;
+    return se_fraction_bits(pl->p, K.cap, &k0, &k1);
 }
 
-// k_smooth_se (icv_kernel_se.hpp): the second generation of the stored-entries kernel
+// k_smooth_se (icv_kernel_se.hpp): CSR float32 input in block form, stored entries only
 int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t kernel_done = nullptr) {
     const icv::Plan& p = pl->p;
     int k0 = 0, k1 = 0;
@@ -801,11 +722,9 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
         }
     }
     if (fast_allowed && m->format == ICV_CSR && m->csr_end > m->csr_begin) {
-        int sd_k = -1;
-        const int gen = stored_entries_kernel(pl, m, K, lay, &sd_k);
-        if (gen) {
+        if (stored_entries_kernel(pl, m, K, lay)) {
             if (recorded) *recorded = kernel_done != nullptr;
-            return gen == 2 ? launch_smooth_se(pl, K, st, kernel_done) : launch_smooth_sd(pl, K, sd_k, st, kernel_done);
+            return launch_smooth_se(pl, K, st, kernel_done);
         }
         if (pl->p.ws_ok && aligned16(K.ref_lo)) {
             const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
@@ -898,7 +817,6 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_x16_wdesc);
-        (void)hipFree(pl->d_w_srel);
         (void)hipFree(pl->d_blk_g0);
         (void)hipFree(pl->d_se_w0);
         (void)hipFree(pl->d_se_w1);
@@ -1096,7 +1014,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         // k_smooth_x16: n_cu workgroups x 16 wavefronts; k_smooth_se: 2 n_cu workgroups x 8 wavefronts
         const int64_t n_part = (int64_t)pl->n_cu * icv::XWAVE;
         static_assert(icv::XWAVE == 2 * icv::NWAVE, "one partial-moment slot per wavefront of a CU");
-        if ((x16_applies(pl, m, K, *lay) || stored_entries_kernel(pl, m, K, *lay, nullptr) == 2) &&
+        if ((x16_applies(pl, m, K, *lay) || stored_entries_kernel(pl, m, K, *lay)) &&
             n_chunks * n_part <= (int64_t)(64 << 20) / 16) {
             chunk_mode = true;
             if (pl->chunk_part_cap < n_chunks * n_part) {

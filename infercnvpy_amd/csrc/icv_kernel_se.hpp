@@ -1,6 +1,7 @@
-// k_smooth_se: CSR float32 input in block form, second generation of the stored-entries kernel (k_smooth_sd).
+// k_smooth_se: CSR float32 input in block form -- the work of a cell is proportional to its STORED ENTRIES.
+// (Second generation of the round-2 kernel k_smooth_sd, which it replaces.)
 //
-// Same algorithm: a cell without stored entries is the pre-centred zero row z = clip(0 - ref), whose window sums
+// A cell without stored entries is the pre-centred zero row z = clip(0 - ref), whose window sums
 // ("base") are the same for every cell; a stored entry changes gene g from z[g] to v = clip(x - ref[g]), windows are
 // linear in the gene values, so only the differences d = v - z[g] of the stored entries are accumulated -- into
 // per-block bins {S0 = sum d, S1 = sum j d} (j: gene offset inside the block) in 64-bit FIXED POINT with LDS integer
@@ -37,14 +38,37 @@
 //   phase 3   x_res, moments of k-1                                 | windows of k, histogram of k
 //   barrier B3
 // A NaN among the stored values of a cell (never on real data) and a cell with more than 64 windows in its median
-// bins are handed back to the generic k_smooth (row_list), like k_smooth_sd does.
+// bins are handed back to the generic k_smooth (row_list).
 #pragma once
 #include <cstddef>
 
-#include "icv_kernel_sd.hpp"
+#include "icv_kernel_ws.hpp"
 #include "icv_kernel_x16.hpp"
+#include "icv_plan.hpp"
 
 namespace icv {
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_shift0(double v) {  // lanes without a source receive 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sums over the 64 lanes in float64, fixed order (row shifts 1, 2, 4, 8, then the row totals)
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    v += dpp_shift0<0x111, 0xf>(v);
+    v += dpp_shift0<0x112, 0xf>(v);
+    v += dpp_shift0<0x114, 0xf>(v);
+    v += dpp_shift0<0x118, 0xf>(v);
+    v += dpp_shift0<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+    v += dpp_shift0<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// The bins {S0,S1} of block b, and then the prefix sums up to b, live at slot b >> 3 of plane b & 7 (8 planes of 512
+// 16-byte pairs, plane stride 513 pairs = icv_plan.hpp: se_slot): the eight accesses of a thread that owns blocks
+// 8t .. 8t+7 (one plane, consecutive slots over the lanes) are conflict-free
+constexpr int kWsPlane = kSePlane;
+constexpr int kSdPlaneBytes = 16 * 8 * kWsPlane;
 
 constexpr int kSePF = 4;  // stored entries prefetched per thread (rows with <= 2048 entries; longer rows fetch the
                           // rest inside phase 1)
@@ -54,7 +78,6 @@ constexpr int kSeCoarseOff = kSeHistOff + NBIN * 2;
 constexpr int kSeScratchOff = kSeCoarseOff + kSeCoarse * kSeRep * 4;
 constexpr int kSeScratchBytes = 1024;
 constexpr int kSeLds = kSeScratchOff + kSeScratchBytes;
-static_assert(kSePlane == kWsPlane, "icv_plan.hpp packs the window table for this plane stride");
 
 struct ScratchE {
     double2 tot[16];  // {S0, T1} totals of the wavefronts' blocks; entries 8 .. 15 stay zero (se_window_words)
@@ -90,7 +113,7 @@ __global__ void __launch_bounds__(256) k_se_table(const KParams P, u32x4* tab, f
 }
 
 // per window {w0, w1 (plan: se_window_words), zero-row window sum as float64}: the numerator before the division by
-// the pyramid weight sum / the gene count, canonical order (as k_sd_base)
+// the pyramid weight sum / the gene count, canonical order
 __global__ void __launch_bounds__(256) k_se_wtab(const KParams P, const float* zrow, const uint32_t* w0,
                                                  const uint32_t* w1, u32x4* wt, float* g_r, float r) {
     const int j = blockIdx.x * 256 + threadIdx.x;

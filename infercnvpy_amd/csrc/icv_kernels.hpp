@@ -89,22 +89,17 @@ struct KParams {
     // block count | gene count << 16
     const uint32_t* x16_wdesc;
     int32_t x16_half, _pad4;  // k_smooth_x16: slots of the even-block {S0,S1} array
-    // k_smooth_sd: per window the gene offset inside its chromosome, per block the gene offset of its first gene
-    // inside its chromosome
-    const int32_t* w_srel;
+    // k_smooth_se (CSR float32, stored entries only).  Per block the gene offset of its first gene inside its
+    // chromosome; per input column {LDS address of the block's bins, ref_lo, in-block offset * 2^k1, clip(0 - ref)}
+    // (k_se_table), ref_hi per column (bounded references); per window {w0, w1, zero-row sum} (k_se_wtab); per block
+    // its first-gene offset * 2^(k1-k0); the fixed-point scales 2^k0, 2^-k0, 2^-k1, 2^(k1-k0)
     const int32_t* blk_g0;
-    // k_smooth_sd (CSR, long windows): per input column {block | offset inside the block << 16, ref_lo, ref_hi,
-    // clip(0 - ref)} (k_sd_table); per window the sum of the zero row (k_sd_base); fixed-point scale of the bins
     const void* sd_tab;
-    const double* sd_base;
-    double sd_scale, sd_qinv;  // 2^k and 2^-k
-    int32_t sd_window, _pad5;
-    // k_smooth_se: ref_hi per column (bounded references), per window {w0, w1, zero-row sum} (k_se_wtab), per block
-    // its first-gene offset / 16
     const float* sd_tab_hi;
     const void* sd_wtab;
     const float* sd_g16;
-    double sd_q1inv, sd_r;  // k_smooth_se: 2^-k1 (S1 bins) and 2^(k1-k0)
+    double sd_scale, sd_qinv, sd_q1inv, sd_r;
+    int32_t sd_window, _pad5;
 };
 
 struct Scratch {
@@ -732,7 +727,7 @@ __global__ void __launch_bounds__(256) k_chunk_thr_part(const double* chunk_part
 // decides except when it lies within one float32 ulp of float32(thr): then the window is recomputed
 // from the input with the canonical evaluation order above (bit-identical to k_smooth) and compared
 // in float64.  The one-ulp band makes the decision independent of the smoothing kernel that wrote
-// x_res: k_smooth_sd sums its windows in another float64 order (equal to ~1e-12), so its float32
+// x_res: k_smooth_se sums its windows in another float64 order (equal to ~1e-12), so its float32
 // value can differ from the canonical one in the last bit.
 // ---------------------------------------------------------------------------------------
 // |y| against the float32 threshold: -1 below, +1 above, 0 float32 cannot decide (a NaN threshold or value: +1)

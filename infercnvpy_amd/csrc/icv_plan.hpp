@@ -63,8 +63,7 @@ struct Plan {
     double pyr_den = 1.0, pyr_rcp = 1.0;
     bool fast_ok = false;            // geometry admits k_smooth_fast (dense float32 input)
     bool ws_ok = false;              // ... and the wave-specialised k_smooth_ws
-    bool sd_ok = false;              // geometry admits k_smooth_sd (CSR float32 input: stored entries only)
-    // k_smooth_se (the second generation of that kernel): per window the LDS slots of its three prefix sums and the
+    // k_smooth_se (CSR float32 input: stored entries only): per window the LDS slots of its three prefix sums and the
     // wavefront totals to add, packed into two words (se_window_words)
     bool se_ok = false;
     std::vector<uint32_t> se_w0, se_w1;
@@ -260,9 +259,9 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
                                   : (double)((window + 1) / 2) * (double)((window + 1) / 2);
     p.pyr_rcp = 1.0 / p.pyr_den;
 
-    // packed window table {start block (16 bits) | length << 16} of the ws / sd kernels; k_smooth_sd: per window the
+    // packed window table {start block (16 bits) | length << 16} of the ws / se kernels; k_smooth_se: per window the
     // gene offset inside its chromosome, per block that of its first gene.  Needs every length to fit 16 signed bits.
-    p.sd_ok = false;
+    p.se_ok = false;
     bool pack_ok = B > 1 && window <= 32767 && p.NB <= 65535;
     for (int c = 0; c < n_chr && pack_ok; ++c) pack_ok = p.pad_off[c + 1] - p.pad_off[c] <= 32767;
     p.w_pack.clear(); p.w_srel.clear(); p.blk_g0.clear();
@@ -277,11 +276,10 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
             for (int q = 0; q < wc; ++q) p.w_srel[w0 + q] = p.w_start[w0 + q] - p.pad_off[c];
             for (int b = p.pad_off[c] / B; b < p.pad_off[c + 1] / B; ++b) p.blk_g0[b] = b * B - p.pad_off[c];
         }
-        // k_smooth_sd: block bins in 8 planes of 512 slots, four windows per thread of a 512-thread workgroup; the
-        // cells it hands back go to the generic kernel (one row in LDS)
-        p.sd_ok = window % 2 == 0 && p.NB <= 8 * kThreads && p.W <= 4 * kThreads && p.lay32.fits;
-        // k_smooth_se: windows shorter than a wavefront's 512 blocks, gene offsets that fit the 14-bit field
-        p.se_ok = p.sd_ok && window / B <= 512;
+        // k_smooth_se: block bins in 8 planes of 512 slots, four windows per thread of a 512-thread workgroup; the
+        // cells it hands back go to the generic kernel (one row in LDS); windows shorter than a wavefront's 512
+        // blocks, gene offsets that fit the 14-bit field
+        p.se_ok = window % 2 == 0 && p.NB <= 8 * kThreads && p.W <= 4 * kThreads && p.lay32.fits && window / B <= 512;
         for (int c = 0; c < n_chr && p.se_ok; ++c) p.se_ok = p.pad_off[c + 1] - p.pad_off[c] < 16384;
         p.se_w0.clear(); p.se_w1.clear();
         if (p.se_ok) {

@@ -27,8 +27,10 @@ from .._plan import GenePlan
 
 log = logging.getLogger("infercnvpy_amd")
 
-# n_jobs=None (the reference's "all cores"): an extra GPU is used only if it gets at least this many chunks
+# n_jobs=None (the reference's "all cores"): an extra GPU is used only if every GPU gets at least this many chunks and
+# this many cells (a GPU smooths 30 M cells/s: small inputs are not worth a second context and uploader)
 _MIN_CHUNKS_PER_DEVICE = 4
+_MIN_ROWS_PER_DEVICE = 50_000
 
 
 def _reference_groups(obs, reference_key, reference_cat):
@@ -64,7 +66,7 @@ def _means_from_sums(sums, counts, cats, mean_dtype):
     return (sums / counts[:, None]).astype(mean_dtype)
 
 
-def _resolve_devices(n_jobs, devices, n_chunks, torch):
+def _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs=None):
     """GPU of every row shard.  ``devices`` wins (a device may be listed more than once: several shards share it);
     else ``n_jobs`` GPUs starting at 0 (``n_jobs=1``: the current device); else all visible GPUs, as far as each
     gets a few chunks of work.  Never more shards than chunks."""
@@ -90,6 +92,8 @@ def _resolve_devices(n_jobs, devices, n_chunks, torch):
             in_group = False
         # inside a torch.distributed job every rank owns ONE GPU: never reach for the others
         k = 1 if in_group else max(1, min(n_dev, n_chunks // _MIN_CHUNKS_PER_DEVICE))
+        if n_obs is not None:
+            k = max(1, min(k, int(n_obs) // _MIN_ROWS_PER_DEVICE))
         devs = [torch.cuda.current_device()] if k == 1 else list(range(k))
     return devs[: max(1, n_chunks)]
 
@@ -133,7 +137,7 @@ def infercnv(
     ``n_jobs`` keeps the reference's meaning -- how many workers share the row chunks (:28, :120-135) -- with GPUs
     as the workers: ``n_jobs=k`` shards the rows over the first ``k`` visible GPUs, ``n_jobs=1`` uses the current
     device only, ``None`` (the reference's "all cores") uses every visible GPU that would get at least
-    four chunks (one GPU inside a ``torch.distributed`` job).  ``devices`` (not part of the reference API) names
+    four chunks and 50 000 cells (one GPU inside a ``torch.distributed`` job).  ``devices`` (not part of the reference API) names
     the GPUs explicitly; a GPU listed twice carries two shards.  Shard boundaries are multiples of ``chunksize``,
     so the noise threshold -- the standard deviation of each ``chunksize``-cell chunk, reference :449-451 -- never
     couples two shards and ``X_cnv`` does not depend on the number of GPUs when ``reference`` is given.  When the
@@ -227,7 +231,7 @@ def infercnv(
     from ..dist import shard_bounds
 
     n_chunks = -(-n_obs // chunksize) if n_obs else 0
-    devs = _resolve_devices(n_jobs, devices, n_chunks, torch)
+    devs = _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs)
     bounds = [b for b in shard_bounds(n_obs, len(devs), chunksize) if b[1] > b[0]] or [(0, n_obs)]
     devs = devs[: len(bounds)]
     shards = [_Shard(i, d, devs.count(d), g0, g1) for i, (d, (g0, g1)) in enumerate(zip(devs, bounds))]

@@ -52,6 +52,10 @@ def test_resolve_devices():
     assert T._resolve_devices(None, None, 9, t8) == [0, 1]
     assert T._resolve_devices(None, None, 3, t8) == [3]
     assert T._resolve_devices(None, None, 0, t8) == [3]
+    # ... and 50 000 cells
+    assert T._resolve_devices(None, None, 200, t8, n_obs=1_000_000) == list(range(8))
+    assert T._resolve_devices(None, None, 200, t8, n_obs=120_000) == [0, 1]
+    assert T._resolve_devices(None, None, 200, t8, n_obs=4000) == [3]
 
 
 def test_means_from_shard_sums_equal_the_reference_semantics():
