@@ -58,16 +58,6 @@ __device__ __forceinline__ unsigned lds_off_hi16(unsigned w, unsigned two) {
 typedef __attribute__((address_space(3))) float lds_float_t;
 #define ICV_LDS_F32_AT(OFF) (*reinterpret_cast<lds_float_t*>(static_cast<uintptr_t>(OFF)))
 
-// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS traffic)
-__device__ __forceinline__ int wave_scan_dpp(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
 // Monotone non-decreasing map window value -> histogram bin.  Piecewise linear: |v| < bound/8 is
 // resolved by 3072 bins (medians of centred, smoothed expression live there), the tails by 512 each.
 __device__ __forceinline__ int hist_bin(double v, float inv_bound) {

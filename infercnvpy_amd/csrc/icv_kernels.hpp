@@ -276,6 +276,16 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v += dpp_move<0x140>(v);  // row_mirror
     return ((readlane_d(v, 0) + readlane_d(v, 16)) + readlane_d(v, 32)) + readlane_d(v, 48);
 }
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS traffic)
+__device__ __forceinline__ int wave_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 __device__ __forceinline__ double wave_min_dpp(double v) {
     double o;
     o = dpp_move<0xB1>(v); v = o < v ? o : v;
@@ -882,32 +892,42 @@ __global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double*
     if (threadIdx.x == 0) tie_n = 0;
     __syncthreads();
     int kept = 0;
-    for (int j0 = 0; j0 < P.W; j0 += 256) {
-        const int j = j0 + (int)threadIdx.x;
-        bool keep = false;
-        if (j < P.W) {
-            const float y = orow[j];
-            const float a = fabsf(y);
-            keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
-            if (has_thr) {
-                const int cmp = thr_compare(a, thf);
-                if (cmp < 0) keep = false;
-                else if (cmp == 0 && keep) {  // float32 cannot decide: exact float64 recomputation below
-                    const int idx = atomicAdd(&tie_n, 1);
-                    if (idx < 32) {
-                        tie_j[idx] = j;
-                    } else {  // > 32 ties in one row: resolve serially
-                        const int st = P.w_start[j];
-                        const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
-                                          P.cell_median[cell];
-                        if (fabs(yd) < th) keep = false;
+    // batches of four values per thread: all loads of a batch are in flight before the first decision
+    for (int j0 = 0; j0 < P.W; j0 += 4 * 256) {
+        float yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256 + (int)threadIdx.x;
+            yv[u] = j < P.W ? orow[j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256 + (int)threadIdx.x;
+            bool keep = false;
+            if (j < P.W) {
+                const float y = yv[u];
+                const float a = fabsf(y);
+                keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
+                if (has_thr) {
+                    const int cmp = thr_compare(a, thf);
+                    if (cmp < 0) keep = false;
+                    else if (cmp == 0 && keep) {  // float32 cannot decide: exact float64 recomputation below
+                        const int idx = atomicAdd(&tie_n, 1);
+                        if (idx < 32) {
+                            tie_j[idx] = j;
+                        } else {  // > 32 ties in one row: resolve serially
+                            const int st = P.w_start[j];
+                            const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                                              P.cell_median[cell];
+                            if (fabs(yd) < th) keep = false;
+                        }
                     }
                 }
             }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if ((threadIdx.x & 63) == 0 && j < P.W) mrow[j >> 6] = m;
+            kept += (threadIdx.x & 63) == 0 ? __popcll(m) : 0;
         }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if ((threadIdx.x & 63) == 0 && j < P.W) mrow[j >> 6] = m;
-        kept += (threadIdx.x & 63) == 0 ? __popcll(m) : 0;
     }
     __syncthreads();  // mask words and the tie list are complete (workgroup scope)
     const int nt = tie_n < 32 ? tie_n : 32;
@@ -1355,7 +1375,10 @@ __global__ void __launch_bounds__(256) k_csr_row_abs_sum(const T* data, const in
     if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
 }
 
-// pack the kept entries (bit mask of k_thr_mask) of the dense float32 result: one wavefront per row
+// pack the kept entries (bit mask of k_thr_mask) of the dense float32 result: one wavefront per row.  The row's mask
+// words are loaded at once (lane w: word w), their kept counts scanned over the lanes: every word's output offset is
+// known before the first value is touched, so the 64-window steps carry no dependency (round 2 walked the words with
+// one scalar load and one running offset per step: a memory round trip per 64 windows).
 __global__ void __launch_bounds__(256) k_csr_fill_masked(const float* x, int64_t n_rows, int n_cols, int64_t ld,
                                                          const unsigned long long* mask, int n_words,
                                                          const int64_t* indptr, int32_t* indices, double* data) {
@@ -1365,16 +1388,26 @@ __global__ void __launch_bounds__(256) k_csr_fill_masked(const float* x, int64_t
     const float* xr = x + row * ld;
     const unsigned long long* mrow = mask + row * (int64_t)n_words;
     int64_t base = indptr[row];
-    for (int w = 0; w < n_words; ++w) {
-        const unsigned long long m = mrow[w];
-        if (m == 0ull) continue;  // wavefront-uniform
-        const int j = w * 64 + lane;
-        if ((m >> lane) & 1ull) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            indices[base + pos] = j;
-            data[base + pos] = (double)xr[j];
+    for (int w0 = 0; w0 < n_words; w0 += 64) {  // 64 words = 4096 windows per pass
+        const int nw = n_words - w0 < 64 ? n_words - w0 : 64;
+        const unsigned long long mine = lane < nw ? mrow[w0 + lane] : 0ull;
+        const int cnt = __popcll(mine);
+        const int incl = wave_scan_dpp(cnt);
+        const int excl = incl - cnt;
+        const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+        for (int w = 0; w < nw; ++w) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)mlo, w), hi = (unsigned)__builtin_amdgcn_readlane((int)mhi, w);
+            if ((lo | hi) == 0u) continue;  // wavefront-uniform
+            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+            const int off = __builtin_amdgcn_readlane(excl, w);
+            if ((m >> lane) & 1ull) {
+                const int j = (w0 + w) * 64 + lane;
+                const int pos = off + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+                indices[base + pos] = j;
+                data[base + pos] = (double)xr[j];
+            }
         }
-        base += __popcll(m);
+        base += __builtin_amdgcn_readlane(incl, 63);
     }
 }
 
