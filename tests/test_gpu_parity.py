@@ -513,6 +513,42 @@ def test_csr_long_windows_do_not_depend_on_entry_order():
         torch.testing.assert_close(base.cell_median, dense.cell_median, rtol=0, atol=1e-11)
 
 
+def test_csr_rows_without_entries_and_ragged_rows():
+    """The stored-entries kernel on ragged input: rows without any stored entry (their windows are the zero row's),
+    rows with one entry, rows with more entries than the prefetch covers (> 2048), explicit zeros among the stored
+    values, at the benchmark geometry (windows that cross into the next wavefront's blocks) -- against the oracle."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd import _lib
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K, extra=(("chrX", 30), (None, 2)))
+    n_genes = len(v["names"])
+    rng = np.random.RandomState(12)
+    X = np.zeros((41, n_genes), dtype=np.float32)
+    for r in range(41):
+        nnz = [0, 1, 2, 7, 300, 1400, 2047, 2048, 2049, 5000, n_genes][r % 11]
+        cols = rng.choice(n_genes, size=nnz, replace=False)
+        X[r, cols] = rng.gamma(0.5, 1.0, size=nnz).astype(np.float32) + 0.01
+    ref = (rng.gamma(0.3, 0.2, size=n_genes)).astype(np.float32)
+    Xs = sp.csr_matrix(X)
+    # explicit zeros stored in the matrix: a stored 0 is still the value 0 (x - ref), like an implicit one
+    Xs.data[::17] = 0.0
+    Xd = Xs.toarray()
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    for window, step in ((100, 10), (250, 10)):
+        tm = {}
+        pos, res, _ = cnv.tl.infercnv(SimpleAnnData(Xs.copy(), var=var), reference=ref, window_size=window, step=step,
+                                      chunksize=16, inplace=False, _timings=tm)
+        assert tm["kernel"] == _lib.ICV_KERNEL_SD
+        e_pos, e_res, _, _ = O.infercnv(Xd, v["chromosome"], v["start"], reference=ref, window_size=window, step=step,
+                                        chunksize=16)
+        assert {k: int(p) for k, p in pos.items()} == {k: int(p) for k, p in e_pos.items()}
+        got, exp = res.toarray(), e_res.toarray()
+        np.testing.assert_array_equal(got == 0, exp == 0)
+        np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
+
+
 @pytest.mark.parametrize("fmt", ["dense", "csr"])
 def test_threshold_ties_are_decided_in_float64(fmt):
     """Force the rare tie path of k_apply_thr: choose thr = (double)float32(|x|) of existing entries, so
