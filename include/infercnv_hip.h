@@ -120,6 +120,14 @@ enum {
     ICV_KERNEL_SPLIT = 6    /* chromosome groups (row larger than LDS) + median on float64 windows in HBM */
 };
 int icv_plan_last_kernel(icv_plan_t plan, int32_t *h_kind);
+/* Host tables of the CSR stored-entries kernel (k_smooth_se), for tests that restate its arithmetic on the CPU:
+ * *h_applies = 1 if the plan's geometry admits the kernel (else nothing more is written); per input column the
+ * block of its gene (-1: masked) and the gene's offset inside the block; per block the offset of its first gene
+ * inside its chromosome; per window the two packed words that name the LDS slots of its three prefix sums and the
+ * wavefront totals to add (csrc/icv_plan.hpp: se_window_words).  Any of the array pointers may be NULL. */
+int icv_plan_se_tables(icv_plan_t plan, int32_t *h_applies, int32_t *h_col_block /* n_cols_all */,
+                       int32_t *h_col_offset /* n_cols_all */, int32_t *h_block_gene0 /* n_blocks */,
+                       uint32_t *h_w0 /* W */, uint32_t *h_w1 /* W */);
 
 /* ---- reference profile (reference :385, :400) --------------------------------------------
  * Per-group column sums in float64.  h/d: `row_group` (device, n_rows int32; -1 = row not in

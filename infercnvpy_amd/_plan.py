@@ -130,6 +130,23 @@ class GenePlan:
         _lib.check(_lib.load().icv_plan_window_table(self._handle, st.ctypes.data, ln.ctypes.data))
         return st, ln
 
+    def se_tables(self):
+        """Host tables of the CSR stored-entries kernel (``icv_plan_se_tables``), or None if the geometry does not
+        admit it: dict(col_block, col_offset, block_gene0, w0, w1)."""
+        lib = _lib.load()
+        ok = C.c_int32(0)
+        _lib.check(lib.icv_plan_se_tables(self._handle, C.byref(ok), None, None, None, None, None))
+        if not ok.value:
+            return None
+        cb = np.zeros(self.n_cols_all, dtype=np.int32)
+        co = np.zeros(self.n_cols_all, dtype=np.int32)
+        g0 = np.zeros(int(self.info.n_blocks), dtype=np.int32)
+        w0 = np.zeros(self.n_windows, dtype=np.uint32)
+        w1 = np.zeros(self.n_windows, dtype=np.uint32)
+        _lib.check(lib.icv_plan_se_tables(self._handle, C.byref(ok), cb.ctypes.data, co.ctypes.data, g0.ctypes.data,
+                                          w0.ctypes.data, w1.ctypes.data))
+        return dict(col_block=cb, col_offset=co, block_gene0=g0, w0=w0, w1=w1)
+
     def last_kernel(self) -> int:
         """``_lib.ICV_KERNEL_*`` of the smoothing kernel the last compute call on this plan launched."""
         kind = C.c_int32(0)

@@ -864,6 +864,24 @@ int icv_plan_window_table(icv_plan_t pl, int32_t* h_start, int32_t* h_len) {
     return ICV_OK;
 }
 
+int icv_plan_se_tables(icv_plan_t pl, int32_t* h_applies, int32_t* h_col_block, int32_t* h_col_offset,
+                       int32_t* h_block_gene0, uint32_t* h_w0, uint32_t* h_w1) {
+    if (!pl || !h_applies) return fail(ICV_ERR_INVALID, "null argument");
+    const icv::Plan& p = pl->p;
+    *h_applies = p.se_ok ? 1 : 0;
+    if (!p.se_ok) return ICV_OK;
+    if (h_col_block && h_col_offset)
+        for (int g = 0; g < p.n_cols_all; ++g) {
+            const int pos = p.dst[g];
+            h_col_block[g] = pos < 0 ? -1 : pos / p.B;
+            h_col_offset[g] = pos < 0 ? 0 : pos % p.B;
+        }
+    if (h_block_gene0) std::memcpy(h_block_gene0, p.blk_g0.data(), (size_t)p.NB * sizeof(int32_t));
+    if (h_w0) std::memcpy(h_w0, p.se_w0.data(), (size_t)p.W * sizeof(uint32_t));
+    if (h_w1) std::memcpy(h_w1, p.se_w1.data(), (size_t)p.W * sizeof(uint32_t));
+    return ICV_OK;
+}
+
 int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, double* sums, void* stream) {
     if (!m || !sums || n_groups < 1) return fail(ICV_ERR_INVALID, "bad colsum arguments");
     if (m->n_rows == 0) return ICV_OK;
