@@ -264,7 +264,7 @@ def kernel_label(fmt, window, step):
     if fmt == "dense" and window == 250 and step == 10:
         return "k_smooth_x16<5,50,chunk moments> (dense fp32, window 250 / step 10)"
     if fmt == "csr" and window % 2 == 0 and math.gcd(step, window // 2) > 1:
-        return ("k_sd_table + k_sd_base + k_smooth_sd (CSR fp32, block form: stored entries only, differences to the "
+        return ("k_se_table + k_se_wtab + k_smooth_se (CSR fp32, block form: stored entries only, differences to the "
                 "zero row in fixed-point block bins, windows from prefix sums)")
     if fmt == "csr":
         return "k_smooth<CSR> (generic: one row in LDS)"

@@ -220,7 +220,7 @@ def main():
     run_case(ref, "w250_s10_csr", Xw, var_w, dict(reference=refw, window_size=250, step=10), fmt="csr")
     run_case(ref, "w250_s5", Xw, var_w, dict(reference=refw, window_size=250, step=5))
 
-    # CSR input in block form = the stored-entries kernel (k_smooth_sd): bounded references (:424-432), other clip
+    # CSR input in block form = the stored-entries kernel (k_smooth_se): bounded references (:424-432), other clip
     # values (its fixed-point scale), other block sizes; columns without a chromosome / on chrX, a chromosome with
     # fewer genes than the window (flat window, :227-236), one with exactly `window` genes
     var_s = cases.synthetic_var([600, 260, 251, 250, 249, 90], seed_start=12, seed_perm=13,

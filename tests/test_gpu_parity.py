@@ -63,7 +63,7 @@ SD_CASES = [n for n in _RUNNABLE if GoldenCase(n).fmt in ("csr", "csc") and Gold
 
 @pytest.mark.parametrize("name", SD_CASES)
 def test_sparse_float32_goldens_take_the_stored_entries_kernel(name, monkeypatch):
-    """float32 CSR / CSC input in block form runs k_smooth_sd (stored entries only: fixed-point block bins, windows
+    """float32 CSR / CSC input in block form runs k_smooth_se (stored entries only: fixed-point block bins, windows
     from prefix sums) -- asserted through the plan's `last_kernel` record -- and its X_cnv equals that of the
     kernels that rebuild the row in LDS (developer knob ICV_NO_SD) up to the last float32 bit, zero pattern
     included.  (The golden comparison itself is test_golden_explicit_reference / test_golden_reference_mean_on_gpu.)"""
@@ -421,10 +421,10 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
         dm_csr = _engine.to_device_matrix(sp.csr_matrix(X.cpu().numpy()))  # prepared-entry CSR fast path
         # default (k_smooth_x16 where the geometry admits it, else k_smooth_ws), k_smooth_ws forced,
         # prepared-entry CSR, generic CSR
-        # float32 CSR input: k_smooth_sd adds the stored entries' differences to the zero row into block bins and
+        # float32 CSR input: k_smooth_se adds the stored entries' differences to the zero row into block bins and
         # reads the windows off prefix sums -- another float64 evaluation order, equal to the canonical one to
         # ~1e-12 (float32 x_res: last-bit differences in a few entries per 100 000)
-        # (every block-form float32 CSR geometry runs k_smooth_sd; ICV_NO_SD: the prepared-entry kernel k_smooth_ws<CSR>
+        # (every block-form float32 CSR geometry runs k_smooth_se; ICV_NO_SD: the prepared-entry kernel k_smooth_ws<CSR>
         # where the geometry admits it, else the generic kernel -- both in the canonical order)
         from infercnvpy_amd import _lib
 
@@ -463,7 +463,7 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
 
 
 def test_csr_long_windows_do_not_depend_on_entry_order():
-    """k_smooth_sd accumulates in fixed point: any order of a row's stored entries gives the same bits, and so do
+    """k_smooth_se accumulates in fixed point: any order of a row's stored entries gives the same bits, and so do
     repeated runs.  Geometries: the benchmark's (window 250 / step 10; window 100 / step 10) and one with other block
     sizes, masked columns and a chromosome shorter than the window (flat window)."""
     import torch
@@ -931,7 +931,7 @@ def test_ward_linkage_properties_at_20000_cells():
 # randomized sweep over geometries / dtypes / formats / reference kinds, and the multi-slab driver
 # --------------------------------------------------------------------------- #
 N_SWEEP = 18
-SWEEP_SD_FROM = 12  # seeds from here on: float32 CSR / CSC input in block form = the stored-entries kernel k_smooth_sd
+SWEEP_SD_FROM = 12  # seeds from here on: float32 CSR / CSC input in block form = the stored-entries kernel k_smooth_se
 
 
 def _sweep_case(seed):
