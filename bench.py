@@ -244,6 +244,13 @@ def e2e_multi_gpu(torch, devices, cells_per_gpu=100_000):
     import numpy as np
 
     legs = {}
+    try:  # the host copy of the input must fit comfortably (64 GB at 8 x 100 000 cells): a quarter of what is free
+        import psutil
+
+        room = psutil.virtual_memory().available // 4
+        cells_per_gpu = int(max(5_000, min(cells_per_gpu, room // (G * 4 * len(devices)) // 5_000 * 5_000)))
+    except ImportError:
+        pass
     n = cells_per_gpu * len(devices)
     Xd = np.empty((n, G), dtype=np.float32)
     for r0 in range(0, n, 50_000):  # generated on this rank's GPU, 4 GB at a time
@@ -556,10 +563,13 @@ def main():
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
-            if torch.cuda.device_count() <= local_rank:
+            isolated = torch.cuda.device_count() == 1 and any(
+                os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+            dev_index = 0 if isolated else local_rank  # a launcher may show each rank only its own GPU
+            if torch.cuda.device_count() <= dev_index:
                 sys.exit(f"bench.py: rank {rank} has no GPU (device_count {torch.cuda.device_count()})")
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
@@ -682,7 +692,8 @@ def main():
         host_barrier("e2e_begin")
         if rank == 0:
             try:
-                devs = [0] * n_gpus if dry else list(range(n_gpus))
+                # (a launcher that shows each rank only its own GPU leaves rank 0 one device: the leg then says so)
+                devs = [0] * n_gpus if dry else list(range(min(n_gpus, torch.cuda.device_count())))
                 result["e2e"] = e2e_multi_gpu(torch, devs, cells_per_gpu=10_000 if dry else 100_000)
             except Exception as e:
                 result["e2e"] = {"error": repr(e)}
