@@ -470,12 +470,12 @@ int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t k
                        static_cast<float*>(pl->d_zrow), nz);
     HIP_TRY(tab_guard.alloc((size_t)K.n_cols * 16, st));
     HIP_TRY(wt_guard.alloc((size_t)p.W * 16, st));
-    HIP_TRY(g_guard.alloc((size_t)(p.NB + 8) * 4, st));
+    HIP_TRY(g_guard.alloc((size_t)(p.NB + 8) * 8, st));
     if (K.bounded) HIP_TRY(hi_guard.alloc((size_t)K.n_cols * 4, st));
     K.sd_tab = tab_guard.p;
     K.sd_tab_hi = K.bounded ? hi_guard.as<float>() : nullptr;
     K.sd_wtab = wt_guard.p;
-    K.sd_g16 = g_guard.as<float>();
+    K.sd_g16 = g_guard.as<double>();
     K.sd_scale = std::ldexp(1.0, k0);
     K.sd_qinv = std::ldexp(1.0, -k0);
     K.sd_q1inv = std::ldexp(1.0, -k1);
@@ -486,7 +486,7 @@ int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t k
     const int n_wt = p.W > p.NB + 8 ? p.W : p.NB + 8;
     hipLaunchKernelGGL(icv::k_se_wtab, dim3((unsigned)((n_wt + 255) / 256)), dim3(256), 0, st, K,
                        static_cast<const float*>(pl->d_zrow), pl->d_se_w0, pl->d_se_w1, wt_guard.as<icv::u32x4>(),
-                       g_guard.as<float>(), (float)K.sd_r);
+                       g_guard.as<double>(), K.sd_r);
     if (int rc = hand_back_workspace(pl, K, st)) return rc;
     int per_cu = icv::kLdsLimit / icv::kSeLds;
     if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments

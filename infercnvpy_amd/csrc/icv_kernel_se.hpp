@@ -50,8 +50,10 @@ namespace icv {
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_shift0(double v) {  // lanes without a source receive 0
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    // all rows written: bound_ctrl supplies the zeros (no v_mov of the old value); masked rows need old = 0
+    constexpr bool kBound = ROWMASK == 0xf;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, kBound);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, kBound);
     return __hiloint2double(hi, lo);
 }
 // inclusive prefix sums over the 64 lanes in float64, fixed order (row shifts 1, 2, 4, 8, then the row totals)
@@ -73,11 +75,15 @@ constexpr int kSdPlaneBytes = 16 * 8 * kWsPlane;
 constexpr int kSePF = 4;  // stored entries prefetched per thread (rows with <= 2048 entries; longer rows fetch the
                           // rest inside phase 1)
 constexpr int kSeCoarse = NBIN / 64, kSeRep = 4;     // coarse histogram: 64 bins x 4 replicas (lane & 3)
-constexpr int kSeHistOff = kSdPlaneBytes;             // fine histogram: NBIN 16-bit counters
-constexpr int kSeCoarseOff = kSeHistOff + NBIN * 2;
-constexpr int kSeScratchOff = kSeCoarseOff + kSeCoarse * kSeRep * 4;
+// LDS map: scratch (the wavefront totals first: offset 0) | coarse histogram | planes | fine histogram.  Everything but
+// the fine histogram lies below 64 KB, so that its base travels in the offset field of the LDS instruction
+constexpr int kSeScratchOff = 0;
 constexpr int kSeScratchBytes = 1024;
-constexpr int kSeLds = kSeScratchOff + kSeScratchBytes;
+constexpr int kSeCoarseOff = kSeScratchOff + kSeScratchBytes;
+constexpr int kSePlanesOff = kSeCoarseOff + kSeCoarse * kSeRep * 4;
+constexpr int kSeHistOff = kSePlanesOff + kSdPlaneBytes;  // fine histogram: NBIN 16-bit counters
+constexpr int kSeLds = kSeHistOff + NBIN * 2;
+static_assert(kSePlanesOff + 7 * 16 * kWsPlane < 65536, "plane offsets must fit the LDS offset field");
 
 struct ScratchE {
     double2 tot[16];  // {S0, T1} totals of the wavefronts' blocks; entries 8 .. 15 stay zero (se_window_words)
@@ -103,7 +109,7 @@ __global__ void __launch_bounds__(256) k_se_table(const KParams P, u32x4* tab, f
     u32x4 e = {0xffffffffu, 0u, 0u, 0u};
     if (pos >= 0) {
         const int blk = pos / P.B;
-        e.x = (uint32_t)(16 * se_slot(blk));
+        e.x = (uint32_t)(kSePlanesOff + 16 * se_slot(blk));
         e.y = __float_as_uint(lo[g]);
         e.z = __float_as_uint((float)(pos - blk * P.B) * scale1);
         e.w = __float_as_uint(centre_clip<float>(0.0f, lo[g], hi[g], (float)P.cap, P.bounded, P.trunc));
@@ -115,9 +121,9 @@ __global__ void __launch_bounds__(256) k_se_table(const KParams P, u32x4* tab, f
 // per window {w0, w1 (plan: se_window_words), zero-row window sum as float64}: the numerator before the division by
 // the pyramid weight sum / the gene count, canonical order
 __global__ void __launch_bounds__(256) k_se_wtab(const KParams P, const float* zrow, const uint32_t* w0,
-                                                 const uint32_t* w1, u32x4* wt, float* g_r, float r) {
+                                                 const uint32_t* w1, u32x4* wt, double* g_r, double r) {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j < P.NB + 8) g_r[j] = j < P.NB ? (float)P.blk_g0[j] * r : 0.0f;  // first-gene offset of block j, times 2^(k1-k0)
+    if (j < P.NB + 8) g_r[j] = j < P.NB ? (double)P.blk_g0[j] * r : 0.0;  // first-gene offset of block j, times 2^(k1-k0)
     if (j >= P.W) return;
     const int wp = P.w_pack[j];
     const int ln = wp >> 16;
@@ -138,11 +144,15 @@ typedef __attribute__((address_space(3))) f64x2 lds_f64x2_t;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 // 16 bytes at an absolute LDS byte offset (the dynamic LDS of the kernel starts at 0)
 #define ICV_LDS_D2_AT(OFF) (*reinterpret_cast<const lds_f64x2_t*>(static_cast<uintptr_t>(OFF)))
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+#define ICV_LDS_ADD_U32(OFF, V)                                                                                   \
+    __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(OFF)), (V), __ATOMIC_RELAXED, \
+                           __HIP_MEMORY_SCOPE_WORKGROUP)
 
 template <int MAXW, bool CHUNK, bool BOUNDED>
 __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double2* SP = reinterpret_cast<double2*>(smem);
+    double2* SP = reinterpret_cast<double2*>(smem + kSePlanesOff);
     unsigned* hist = reinterpret_cast<unsigned*>(smem + kSeHistOff);      // two 16-bit bins per word
     unsigned* coarse = reinterpret_cast<unsigned*>(smem + kSeCoarseOff);  // [bin][replica]
     ScratchE* sc = reinterpret_cast<ScratchE*>(smem + kSeScratchOff);
@@ -170,7 +180,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
     const __amdgpu_buffer_rsrc_t tab_rs = make_rsrc(P.sd_tab, (unsigned)P.n_cols * 16u);
     const __amdgpu_buffer_rsrc_t thi_rs = make_rsrc(BOUNDED ? P.sd_tab_hi : P.sd_tab, BOUNDED ? (unsigned)P.n_cols * 4u : 0u);
     const __amdgpu_buffer_rsrc_t wt_rs = make_rsrc(P.sd_wtab, (unsigned)W * 16u);
-    const __amdgpu_buffer_rsrc_t g16_rs = make_rsrc(P.sd_g16, (unsigned)(NB + 8) * 4u);
+    const __amdgpu_buffer_rsrc_t g16_rs = make_rsrc(P.sd_g16, (unsigned)(NB + 8) * 8u);
     // row offsets travel through vector loads (a provably uniform address becomes a scalar load, whose counter is
     // shared with the LDS operations of the phase that follows)
     int zoff = 0;
@@ -324,10 +334,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
         const bool has_next = nxt >= 0 && nxt < P.n_rows;
         const int64_t nrow = has_next ? nxt : 0;
         const int64_t n0 = P.indptr[nrow + zoff], n1 = P.indptr[nrow + 1 + zoff];
-        u32x4 g16a = {0u, 0u, 0u, 0u}, g16b = {0u, 0u, 0u, 0u};
+        // first-gene offsets of the thread's blocks (times r, float64), consumed in phase 2
+        u32x4 g16q[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         if (more) {
-            g16a = __builtin_amdgcn_raw_buffer_load_b128(g16_rs, (unsigned)tl * 32u, 0, 0);
-            g16b = __builtin_amdgcn_raw_buffer_load_b128(g16_rs, (unsigned)tl * 32u, 16, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g16q[k] = __builtin_amdgcn_raw_buffer_load_b128(g16_rs, (unsigned)tl * 64u, k * 16, 0);
         }
         if (have1 && tl < 64) {
             // ---- wavefront 0, second half: the fine bins inside the located coarse bins
@@ -448,9 +459,6 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
             if (tl < kSeCoarse * kSeRep / 4) reinterpret_cast<int4*>(coarse)[tl] = make_int4(0, 0, 0, 0);
         }
         if (more && wblk) {
-            const float g16v[8] = {__uint_as_float(g16a.x), __uint_as_float(g16a.y), __uint_as_float(g16a.z),
-                                   __uint_as_float(g16a.w), __uint_as_float(g16b.x), __uint_as_float(g16b.y),
-                                   __uint_as_float(g16b.z), __uint_as_float(g16b.w)};
             // {S0 [2^-k0], T1 = g0 r S0 + S1 [2^-k1]} of the thread's blocks 8 t .. 8 t + 7; their prefix sums
             // over the blocks of this WAVEFRONT go back in place, the wavefront's totals to the scratch
             double s0[8], s1[8], t0 = 0.0, t1 = 0.0;
@@ -458,7 +466,9 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
             for (int k = 0; k < 8; ++k) {
                 const double2 v = SP[k * kWsPlane + tl];  // 1.5 * 2^52 + the bin's integer, exactly
                 s0[k] = v.x - 6755399441055744.0;
-                s1[k] = fma((double)g16v[k], s0[k], v.y - 6755399441055744.0);
+                const double g0r = (k & 1) ? __hiloint2double((int)g16q[k >> 1].w, (int)g16q[k >> 1].z)
+                                           : __hiloint2double((int)g16q[k >> 1].y, (int)g16q[k >> 1].x);
+                s1[k] = fma(g0r, s0[k], v.y - 6755399441055744.0);
                 t0 = t0 + s0[k];
                 t1 = t1 + s1[k];
             }
@@ -531,6 +541,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
             // window is a difference of P0 (+ the zero row's sum) over the gene count
             int lnan = 0;
             const unsigned tot_base = (unsigned)(kSeScratchOff + offsetof(ScratchE, tot));
+            const unsigned lane4 = ((unsigned)tl & (kSeRep - 1)) * 4u;
 #pragma unroll
             for (int i = 0; i < MAXW; ++i) {
                 const int j = tl + i * NT;
@@ -539,14 +550,14 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
                 if (j < W) {
                     const unsigned w0 = wt[i].x, w1 = wt[i].y;
                     const double wbase = __hiloint2double((int)wt[i].w, (int)wt[i].z);
-                    const f64x2 pb = ICV_LDS_D2_AT((w0 & 0x1fffu) << 4);
-                    const f64x2 pe = ICV_LDS_D2_AT((w1 & 0x1fffu) << 4);
+                    const f64x2 pb = ICV_LDS_D2_AT(kSePlanesOff + ((w0 & 0x1fffu) << 4));
+                    const f64x2 pe = ICV_LDS_D2_AT(kSePlanesOff + ((w1 & 0x1fffu) << 4));
                     // (skipping the two total reads in wavefronts without a crossing window was measured: no gain)
                     const f64x2 te = ICV_LDS_D2_AT(tot_base + (((w1 >> 27) & 0xfu) << 4));
                     const double sgd = (double)(int)((w1 >> 13) & 0x3fffu);
                     double v;
                     if (__builtin_expect((int)w0 >= 0, 1)) {
-                        const f64x2 pm = ICV_LDS_D2_AT(((w0 >> 13) & 0x1fffu) << 4);
+                        const f64x2 pm = ICV_LDS_D2_AT(kSePlanesOff + (((w0 >> 13) & 0x1fffu) << 4));
                         const f64x2 tm = ICV_LDS_D2_AT(tot_base + (((w0 >> 26) & 0xfu) << 4));
                         const double pmx = pm.x + tm.x, pmy = pm.y + tm.y;
                         const double pex = pe.x + te.x, pey = pe.y + te.y;
@@ -562,8 +573,9 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
                     lnan |= (v != v);
                     const int hb = hist_bin(v, inv_bound);
                     hb16 = (unsigned)hb;
-                    atomicAdd(&hist[hb >> 1], 1u << ((hb & 1) * 16));  // 16-bit bins, two per word
-                    atomicAdd(&coarse[(hb >> 6) * kSeRep + (tl & (kSeRep - 1))], 1u);
+                    // 16-bit fine bins, two per word; coarse bin hb >> 6, replica lane & 3: absolute LDS addresses
+                    ICV_LDS_ADD_U32((unsigned)kSeHistOff + (((unsigned)hb >> 1) << 2), 1u << ((hb & 1) * 16));
+                    ICV_LDS_ADD_U32((unsigned)kSeCoarseOff + ((((unsigned)hb >> 2) & 0x3f0u) | lane4), 1u);
                 }
                 wbA[i >> 1] = (i & 1) ? ((wbA[i >> 1] & 0xffffu) | (hb16 << 16)) : hb16 | 0xffff0000u;
             }

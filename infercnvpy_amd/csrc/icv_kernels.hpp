@@ -97,7 +97,7 @@ struct KParams {
     const void* sd_tab;
     const float* sd_tab_hi;
     const void* sd_wtab;
-    const float* sd_g16;
+    const double* sd_g16;
     double sd_scale, sd_qinv, sd_q1inv, sd_r;
     int32_t sd_window, _pad5;
 };
