@@ -78,6 +78,14 @@ def one_case(seed):
     for g in np.unique(groups):
         exp = np.mean(np.abs(X[groups == g].astype(np.float64)))
         assert abs(got[g] - exp) <= 1e-9 * max(1.0, abs(exp)), desc + f" cnv_score {g}: {got[g]} vs {exp}"
+    # ithcna: IQR of the cell-cell Pearson correlations per group (float32 MFMA Gram matrix vs np.corrcoef: 1e-5)
+    if n >= 4:
+        g2 = np.where(np.arange(n) % 2 == 0, "even", "odd")
+        ad.obs["g2"] = g2
+        got = cnv.tl.ithcna(ad, "g2", inplace=False)
+        exp = O.ith_score(X.astype(np.float64), list(g2))
+        for g in ("even", "odd"):
+            assert (np.isnan(got[g]) and np.isnan(exp[g])) or abs(got[g] - exp[g]) <= 1e-5, desc + f" ithcna {g}: {got[g]} vs {exp[g]}"
     return desc + ("" if same_sizes or dup else " SIZES-DIFFER")
 
 
