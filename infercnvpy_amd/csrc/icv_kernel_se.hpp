@@ -262,7 +262,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
         }
         // wavefront 0, first half of the median search of cell it-1: the coarse bins of its two middle ranks
         int ch_st = 0, ch_C0 = 0, ch_C1 = 0, ch_b0 = 0, ch_b1 = 0;  // state, coarse bins, windows below them
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_SE_EXP_NOMEDIAN)  // upper bound: no median search at all (wrong results)
+        if (false) {
+#else
         if (have1 && tl < 64) {
+#endif
             const int nanf = sc->nanflag, badf = sc->bad[par ^ 1];
             const uint4 c4 = reinterpret_cast<const uint4*>(coarse)[tl];
             if (badf) {
@@ -344,7 +348,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
             // ---- wavefront 0, second half: the fine bins inside the located coarse bins
             int4 r = make_int4(0, 0, 0, 0);
             int c2n = 0, st = ch_st;
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_SE_EXP_NOMEDIAN)
+            if (false) {
+#else
             if (st == 0) {
+#endif
                 int Cprev = -1, f = 0, fincl = 0;
                 int res[2][3];
 #pragma unroll
@@ -504,7 +512,11 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
             double ma = 0.0, mb = 0.0;  // handed-back cell: placeholder, rewritten by k_smooth
             if (st1 == 1) {
                 ma = mb = __builtin_nan("");
+#if defined(ICV_DEV_EXPERIMENTS) && (defined(ICV_SE_EXP_NOMEDIAN) || defined(ICV_SE_EXP_NORANK))
+            } else if (false) {  // upper bound: the ranking step costs nothing (wrong results)
+#else
             } else if (st1 == 0) {
+#endif
                 const int n = ncr < 64 ? ncr : 64;
                 const double mine = (lane < n) ? mine_raw : __builtin_inf();
                 int r = 0;
