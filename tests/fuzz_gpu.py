@@ -1,5 +1,5 @@
-"""Random cases of tests/test_gpu_parity.py's sweep over MORE seeds than the test suite runs (GPU box; developer tool):
-    python tools/fuzz_gpu.py [first_seed] [n_seeds]
+"""Random cases of tests/test_gpu_parity.py's sweep over MORE seeds than the test suite runs (GPU box; test infrastructure like the rest of tests/: it checks the product against oracle/):
+    python tests/fuzz_gpu.py [first_seed] [n_seeds]
 Odd seeds take the block-form float32 CSR / CSC family (k_smooth_se), even seeds the general family.  Every case goes
 through cnv.tl.infercnv and is compared with the oracle (chr_pos, exact zero pattern, values to 1e-6).  Prints the
 failing seeds with their parameters; exit status 1 if any."""

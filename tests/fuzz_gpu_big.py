@@ -1,6 +1,6 @@
 """Random cases at the BENCHMARK geometry (20 000 genes on chr1..22, random var order) against the oracle, with the
-inputs the register-prefetch kernels treat specially (GPU box; developer tool):
-    python tools/fuzz_gpu_big.py [first_seed] [n_seeds]
+inputs the register-prefetch kernels treat specially (GPU box; test infrastructure like the rest of tests/: it checks the product against oracle/):
+    python tests/fuzz_gpu_big.py [first_seed] [n_seeds]
 Per case: dense float32 (k_smooth_x16 / k_smooth_ws) or CSR float32 (k_smooth_se); window 100 or 250 at step 10 (now and
 then another block-form pair); 150-700 cells in chunks of 64 / 100 / 5000; lfc_clip 0.5 / 3 / 10; one or two
 reference categories, a given reference or none; and rows that leave the fast path: rows equal to the reference (every

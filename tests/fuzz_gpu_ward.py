@@ -1,5 +1,5 @@
-"""Random Ward-linkage / score cases against scipy and numpy (GPU box; developer tool):
-    python tools/fuzz_gpu_ward.py [first_seed] [n_seeds]
+"""Random Ward-linkage / score cases against scipy and numpy (GPU box; test infrastructure like the rest of tests/: it checks the product against oracle/):
+    python tests/fuzz_gpu_ward.py [first_seed] [n_seeds]
 Per seed: n in 2..1500 cells, d in 4..99 features, 1..10 blobs (now and then with duplicated cells, or without any
 structure), both column layouts of the Ward rounds (spare columns / in place).  Checked against scipy's float64
 `linkage(method="ward")`: a valid linkage, the multiset of cluster sizes, sorted heights to 2e-4 relative (float32

@@ -977,7 +977,7 @@ def test_random_sweep_public_api_against_oracle(seed):
 
 
 def _check_sweep_case(seed, sd, extras=False):
-    """One random case through the public API against the oracle (also driven by tools/fuzz_gpu.py over more seeds;
+    """One random case through the public API against the oracle (also driven by tests/fuzz_gpu.py over more seeds;
     `extras`: a third of the cases each also with calculate_gene_values / as two row shards on the one GPU)."""
     import infercnvpy_amd as cnv
     from infercnvpy_amd._compat import SimpleAnnData
@@ -1023,7 +1023,7 @@ def _check_sweep_case(seed, sd, extras=False):
     # The zero pattern is exact, except for entries at the rounding noise of the window sum itself: without a noise
     # threshold a window that TIES with the row's median in exact arithmetic is 0 or ~1e-17 depending on the order of
     # the float64 additions -- and np.convolve's own order depends on the BLAS kernel numpy picks for the host CPU
-    # (n <= ~16: sequential; longer: vectorised partial sums).  tools/fuzz_gpu.py finds such ties in ~1 % of the
+    # (n <= ~16: sequential; longer: vectorised partial sums).  tests/fuzz_gpu.py finds such ties in ~1 % of the
     # integer-count cases with dynamic_threshold=None; with a threshold those entries are zero on both sides.
     differ = (got == 0) != (exp == 0)
     assert np.all(np.maximum(np.abs(got), np.abs(exp))[differ] < 1e-13), int(differ.sum())
