@@ -8,13 +8,13 @@
 // atomics (order-independent, bit-reproducible) -- the bins become float64 prefix sums over the blocks, and a pyramid
 // window is a linear combination of the prefix sums at three blocks.
 //
-// What changed against k_smooth_sd (PMC counters: 6 050 VALU + 1 890 SALU wave-instructions per cell there; the
-// kernel is bound by instruction issue, 16 wavefronts per CU):
+// What changed against k_smooth_sd (PMC counters: 6 050 VALU + 1 890 SALU wave-instructions per cell there, 4 060 +
+// 1 500 here):
 //   * prefix sums are kept PER WAVEFRONT (thread t owns blocks 8 t .. 8 t + 7); a window adds the total of one
 //     wavefront where it crosses into the next (plan table, icv_plan.hpp: se_window_words).  No second-level scan,
 //     one barrier less (four per cell), smaller magnitudes in the differences;
 //   * the three LDS slots of a window, its gene offset and the zero-row sum come in ONE 16-byte table entry per
-//     window (k_se_wtab), the first-gene offsets of a thread's blocks in two 16-byte loads;
+//     window (k_se_wtab), the first-gene offsets of a thread's blocks (float64, times r) in four 16-byte loads;
 //   * the bins start every cell at the bit pattern of 1.5 * 2^52 and stay below 2^51 in magnitude (S0 in units of
 //     2^-k0, S1 of 2^-k1, k0 / k1 from the clip value and the block size: se_fraction_bits): the scan turns a bin
 //     into float64 with ONE subtraction instead of a 64-bit integer conversion;
@@ -26,17 +26,18 @@
 //     reductions, no per-cell moment traffic;
 //   * no per-phase priorities, tables and flags read once per phase.
 //
-// Per cell and workgroup (512 threads, two workgroups per CU); the median of cell k-1 shares the barriers of cell k:
-//   phase 0   wavefront 0: both middle bins of k-1 located          | bins of k zeroed; table entries of its columns
-//   barrier A                                                         requested
-//   phase 1   windows of k-1 in the middle bins gathered (<= 64);   | entries of k added to the bins
-//             histogram cleared
+// Per workgroup (512 threads, two workgroups per CU) iteration `it` handles three cells at once; every single-wavefront
+// step of the median sits beside bulk work of all wavefronts (what bounds the kernel, and everything that was measured
+// not to: DESIGN.md 4.4, profiles/r03_se_late_experiments.txt, r03_se_occupancy.txt):
+//   phase 0   cell it: bins reset to the bias pattern     | cell it-2: x_res, moments | wavefront 0: coarse bins of the
+//   barrier A                                                                           two middle ranks of cell it-1
+//   phase 1   cell it: stored entries -> bins (2 ds_add_u64 per entry)                | wavefront 0: their fine bins
 //   barrier B1
-//   phase 2   one wavefront ranks the candidates -> median of k-1   | bins -> float64 prefix sums per wavefront;
-//                                                                     window table and {column, value} of k+1 requested
+//   phase 2   cell it: bins -> float64 prefix sums per wavefront; window table,       | cell it-1: windows in the
+//             {column, value} of cell it+1 requested                                    middle bins gathered (<= 64)
 //   barrier B2
-//   phase 3   x_res, moments of k-1                                 | windows of k, histogram of k
-//   barrier B3
+//   phase 3   cell it: windows, histogram atomics; table entries of cell it+1         | last wavefront: exact ranks of
+//   barrier B3         gathered                                                         the candidates -> median of it-1
 // A NaN among the stored values of a cell (never on real data) and a cell with more than 64 windows in its median
 // bins are handed back to the generic k_smooth (row_list).
 #pragma once
