@@ -140,6 +140,28 @@ int icv_plan_se_tables(icv_plan_t plan, int32_t *h_applies, int32_t *h_col_block
 int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, double *sums,
                void *stream);
 
+/* The same profile in the REFERENCE'S OWN EVALUATION ORDER, so that `reference=None` / `reference_cat` reproduce the
+ * reference bit for bit (float32 sums are not associative):
+ *   - np.mean(X, axis=0) of a C-contiguous matrix (reference :385, :400) is, per column, the sequential chain
+ *     acc = fl(acc + x[r][g]) over the rows in order, in the matrix dtype (float32 stays float32), then acc / n;
+ *   - scipy's CSR mean is the same chain over fl(x * fl(1/n)) (no division afterwards);
+ *   - scipy's CSC mean is np.add.reduceat per column: first stored entry + numpy's pairwise sum of the others.
+ * icv_colchain continues the chains: `acc` (device, n_cols values of the MATRIX dtype; zero before the first call) is
+ * read, the rows `rows[0..n_sel)` of `m` (device int32, ascending; NULL = all rows of m) are added in order, and the
+ * new accumulators are written back -- row pieces, slabs and shards are chained by calling in row order with the same
+ * `acc`.  `scale` is used for CSR input only (1 / n of the whole group, rounded to the matrix dtype inside).
+ * Columns are the only parallelism an exact chain has: one workgroup per 128..512-byte tile of a row streams its rows
+ * through an LDS ring (LDS-DMA) while one wavefront adds them in order.  CSR needs 4 * (tiles + 1) bytes of temporary
+ * device memory per row (stream-ordered).  A row list on a dense matrix whose row stride is not a multiple of 16 bytes
+ * synchronises the stream once (the last list entry is read back).
+ * icv_colchain_mean: mean[c] = acc[c] / count in the dtype (dense); for CSR the accumulators already are the means.
+ * icv_colmean_csc: means of a CSC matrix (colptr n_cols + 1 int64, row_idx int32, values), entries of rows with
+ * row_group[row] == group only (row_group NULL: all), scale = 1 / n as above; `mean` n_cols values of the dtype. */
+int icv_colchain(const icv_matrix *m, const int32_t *rows, int64_t n_sel, double scale, void *acc, void *stream);
+int icv_colchain_mean(const void *acc, int32_t dtype, int32_t n_cols, int64_t count, void *mean, void *stream);
+int icv_colmean_csc(const void *values, int32_t dtype, const int64_t *colptr, const int32_t *row_idx, int32_t n_cols,
+                    const int32_t *row_group, int32_t group, double scale, void *mean, void *stream);
+
 /* ---- the hot path ------------------------------------------------------------------------
  * Steps 1-4 of `_infercnv_chunk` (:422-442) for every row of `m`, fused in one kernel:
  *   centre on the reference (ref_hi == NULL: x - ref_lo; else bounded difference),

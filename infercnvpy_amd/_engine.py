@@ -127,6 +127,87 @@ def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None, row0=0,
     return sums
 
 
+def column_chain(dm: DeviceMatrix, acc=None, rows=None, count=None, row0=0, row1=None):
+    """Continue the reference-order column sums (``icv_colchain``): ``acc`` (device, ``n_cols`` values of the matrix
+    dtype; None = start from zero) += the rows ``rows`` (ascending indices RELATIVE to ``row0``; None = all) of
+    ``dm[row0:row1]``, added one after the other as numpy's ``np.mean(X, axis=0)`` / scipy's CSR ``mean`` add them.
+    ``count``: rows of the WHOLE group (CSR input multiplies every entry by ``1 / count`` first, as scipy does)."""
+    torch = _torch()
+    lib = _lib.load()
+    if acc is None:
+        acc = torch.zeros(dm.shape[1], dtype=dm.dtype, device="cuda")
+    assert acc.dtype == dm.dtype and acc.is_cuda and acc.numel() == dm.shape[1] and acc.is_contiguous()
+    m = dm.c_struct(row0, row1)
+    rows_d, n_sel = None, m.n_rows
+    if rows is not None:
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        n_sel = int(rows.shape[0])
+        if n_sel == 0:
+            return acc
+        rows_d = torch.from_numpy(rows).to("cuda")
+    scale = 0.0
+    if dm.format == _lib.ICV_CSR:
+        if not count:
+            raise ValueError("column_chain: CSR input needs the row count of the group")
+        scale = 1.0 / float(count)
+    _lib.check(lib.icv_colchain(C.byref(m), _ptr(rows_d), n_sel, scale, _ptr(acc), _stream_ptr(torch)))
+    return acc
+
+
+def chain_mean(acc, count, is_csr):
+    """Means from the accumulators of :func:`column_chain`: ``acc / count`` in the matrix dtype for dense input
+    (numpy's ``true_divide(sum, n)``); CSR accumulators already are the means (scipy scales the entries)."""
+    if is_csr:
+        return acc
+    torch = _torch()
+    lib = _lib.load()
+    out = torch.empty_like(acc)
+    _lib.check(lib.icv_colchain_mean(_ptr(acc), _lib.ICV_F32 if acc.dtype == torch.float32 else _lib.ICV_F64,
+                                     acc.numel(), int(count), _ptr(out), _stream_ptr(torch)))
+    return out
+
+
+def csc_column_means(X, row_group=None, n_groups=1, counts=None, np_dtype=None, max_entries=1 << 28):
+    """Per-group column means of a host scipy CSC matrix in scipy's own order (``np.add.reduceat`` per column: first
+    stored entry + numpy's pairwise sum of the others, entries scaled by 1 / n first): ``n_groups x n_cols`` host array
+    of ``np_dtype``.  The columns travel to the GPU in blocks of at most ``max_entries`` stored entries."""
+    torch = _torch()
+    lib = _lib.load()
+    X = X.tocsc()
+    if not X.has_canonical_format:
+        X = X.copy()
+        X.sum_duplicates()
+    np_dtype = np.dtype(np_dtype or (np.float32 if X.dtype == np.float32 else np.float64))
+    tdt = torch.float32 if np_dtype == np.float32 else torch.float64
+    code = _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64
+    n_cols = X.shape[1]
+    indptr = X.indptr.astype(np.int64, copy=False)
+    out = np.zeros((n_groups, n_cols), dtype=np_dtype)
+    rg = None
+    if row_group is not None:
+        rg = torch.from_numpy(np.ascontiguousarray(row_group, dtype=np.int32)).cuda()
+    if counts is None:
+        counts = [X.shape[0]] * n_groups
+    c = 0
+    while c < n_cols:
+        c1 = int(np.searchsorted(indptr, indptr[c] + max_entries, side="right")) - 1
+        c1 = min(n_cols, max(c1, c + 1))
+        e0, e1 = int(indptr[c]), int(indptr[c1])
+        vals = torch.from_numpy(np.ascontiguousarray(X.data[e0:e1].astype(np_dtype, copy=False))).cuda()
+        rows = torch.from_numpy(np.ascontiguousarray(X.indices[e0:e1].astype(np.int32, copy=False))).cuda()
+        ptr = torch.from_numpy(np.ascontiguousarray(indptr[c:c1 + 1] - e0)).cuda()
+        if e1 == e0:  # nothing stored: (the kernel never dereferences empty arrays, but give it valid pointers)
+            vals = torch.zeros(1, dtype=tdt, device="cuda")
+            rows = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for g in range(n_groups):
+            mean = torch.empty(c1 - c, dtype=tdt, device="cuda")
+            _lib.check(lib.icv_colmean_csc(_ptr(vals), code, _ptr(ptr), _ptr(rows), c1 - c, _ptr(rg), g,
+                                           1.0 / float(counts[g]), _ptr(mean), _stream_ptr(torch)))
+            out[g, c:c1] = mean.cpu().numpy()
+        c = c1
+    return out
+
+
 def alloc_out(rows, n_windows):
     """Device float32 ``rows x n_windows`` result buffer whose rows start on 16-byte boundaries (row stride padded
     to a multiple of 4): the smoothing kernel then writes x_res with 16-byte stores."""

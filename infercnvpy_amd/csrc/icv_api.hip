@@ -20,6 +20,7 @@
 #include "icv_kernel_ws.hpp"
 #include "icv_kernel_x16.hpp"
 #include "icv_kernel_se.hpp"
+#include "icv_kernel_chain.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -763,6 +764,89 @@ int launch_apply(const icv_matrix* m, const icv::KParams& K, const double* thr, 
 
 }  // namespace
 
+// ---- reference profile in the reference's evaluation order (csrc/icv_kernel_chain.hpp) ------------------------------
+namespace {
+int current_cu_count() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) return prop.multiProcessorCount;
+    return 256;
+}
+
+// line -> tile of ChainLaunch's split (tile t owns the lines [t * n_lines / grid, (t + 1) * n_lines / grid))
+__global__ void k_chain_line_tiles(int n_lines, int grid, uint16_t* line_tile) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= grid) return;
+    const int l0 = (int)((int64_t)t * n_lines / grid), l1 = (int)((int64_t)(t + 1) * n_lines / grid);
+    for (int l = l0; l < l1; ++l) line_tile[l] = (uint16_t)t;
+}
+
+template <typename T>
+__global__ void k_chain_mean(const T* acc, int n, T denom, T* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = acc[i] / denom;  // IEEE division (numpy: true_divide(sum, n) in the matrix dtype)
+}
+
+template <typename T>
+int colchain_dense(const icv_matrix* m, const int32_t* rows, int64_t n_sel, T* acc, hipStream_t st) {
+    const icv::ChainLaunch L(m->n_cols, (int)sizeof(T), current_cu_count());
+    constexpr int EPL = 16 / (int)sizeof(T);
+    // the buffer's last row goes through the guarded tail when a 16-byte segment load could run past the end
+    int64_t tail = -1, n_dma = n_sel;
+    if ((int64_t)(m->n_cols + EPL - 1) / EPL * EPL > m->ld) {
+        int64_t last = m->n_rows - 1;
+        if (rows) {
+            int32_t h_last = 0;
+            HIP_TRY(hipMemcpyAsync(&h_last, rows + (n_sel - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            last = h_last;
+        }
+        if (last == m->n_rows - 1) {
+            tail = last;
+            n_dma = n_sel - 1;
+        }
+    }
+    typedef void (*kern_t)(const T*, int64_t, int, int, int, const int32_t*, int64_t, int64_t, T*);
+    const kern_t kern = rows ? (kern_t)icv::k_colchain<T, true> : (kern_t)icv::k_colchain<T, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                icv::kChLdsFull));
+    hipLaunchKernelGGL(kern, dim3(L.grid), dim3(icv::kChThreads), L.lds_bytes, st, (const T*)m->values, m->ld,
+                       m->n_cols, L.n_lines, L.lds_bytes, rows, n_dma, tail, acc);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+template <typename T>
+int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double scale, T* acc, hipStream_t st) {
+    const icv::ChainLaunch L(m->n_cols, (int)sizeof(T), current_cu_count());
+    if (L.grid > 65535) return fail(ICV_ERR_UNSUPPORTED, "icv_colchain: more than 65535 column tiles");
+    AsyncBuf lt_b, bounds_b;
+    HIP_TRY(lt_b.alloc((size_t)L.n_lines * sizeof(uint16_t), st));
+    const int64_t n_blk = (n_sel + icv::kCcBlock - 1) / icv::kCcBlock;
+    HIP_TRY(bounds_b.alloc((size_t)n_blk * (L.grid + 1) * icv::kCcBlock * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_chain_line_tiles, dim3((L.grid + 255) / 256), dim3(256), 0, st, L.n_lines, L.grid,
+                       lt_b.as<uint16_t>());
+    const int esz_shift = sizeof(T) == 4 ? 2 : 3;
+    if (rows)
+        hipLaunchKernelGGL(icv::k_csr_tile_bounds<true>, dim3((unsigned)n_blk), dim3(256), 0, st, m->indptr, m->indices,
+                           rows, n_sel, lt_b.as<uint16_t>(), esz_shift, L.grid, bounds_b.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(icv::k_csr_tile_bounds<false>, dim3((unsigned)n_blk), dim3(256), 0, st, m->indptr, m->indices,
+                           rows, n_sel, lt_b.as<uint16_t>(), esz_shift, L.grid, bounds_b.as<uint32_t>());
+    typedef void (*kern_t)(const T*, const int64_t*, const int32_t*, int64_t, const int32_t*, int64_t, int, int, int,
+                           const uint32_t*, T, T*);
+    const kern_t kern = rows ? (kern_t)icv::k_colchain_csr<T, true> : (kern_t)icv::k_colchain_csr<T, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                icv::kChLdsFull));
+    hipLaunchKernelGGL(kern, dim3(L.grid), dim3(icv::kChThreads), L.lds_bytes, st, (const T*)m->values, m->indptr,
+                       m->indices, m->n_rows, rows, n_sel, m->n_cols, L.n_lines, L.lds_bytes,
+                       (const uint32_t*)bounds_b.as<uint32_t>(), (T)scale, acc);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char* icv_last_error(void) { return g_err.c_str(); }
@@ -942,6 +1026,54 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 63) / 64), dim3(1024), 0, st, partial, (int)n_slabs, nc,
                            sums + (int64_t)g * nc);
     }
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_colchain(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double scale, void* acc, void* stream) {
+    if (!m || !acc) return fail(ICV_ERR_INVALID, "bad colchain arguments");
+    if (m->dtype != ICV_F32 && m->dtype != ICV_F64) return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
+    if (!rows) n_sel = m->n_rows;
+    if (n_sel < 0 || n_sel > m->n_rows) return fail(ICV_ERR_INVALID, "icv_colchain: n_sel out of range");
+    if (n_sel == 0 || m->n_cols == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (m->format == ICV_CSR)
+        return m->dtype == ICV_F32 ? colchain_csr<float>(m, rows, n_sel, scale, (float*)acc, st)
+                                   : colchain_csr<double>(m, rows, n_sel, scale, (double*)acc, st);
+    if (m->format != ICV_DENSE) return fail(ICV_ERR_INVALID, "format must be dense or csr");
+    return m->dtype == ICV_F32 ? colchain_dense<float>(m, rows, n_sel, (float*)acc, st)
+                               : colchain_dense<double>(m, rows, n_sel, (double*)acc, st);
+}
+
+int icv_colchain_mean(const void* acc, int32_t dtype, int32_t n_cols, int64_t count, void* mean, void* stream) {
+    if (!acc || !mean || count < 1 || n_cols < 0) return fail(ICV_ERR_INVALID, "bad colchain_mean arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_cols == 0) return ICV_OK;
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(k_chain_mean<float>, dim3((n_cols + 255) / 256), dim3(256), 0, st, (const float*)acc, n_cols,
+                           (float)count, (float*)mean);
+    else if (dtype == ICV_F64)
+        hipLaunchKernelGGL(k_chain_mean<double>, dim3((n_cols + 255) / 256), dim3(256), 0, st, (const double*)acc,
+                           n_cols, (double)count, (double*)mean);
+    else
+        return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_colmean_csc(const void* values, int32_t dtype, const int64_t* colptr, const int32_t* row_idx, int32_t n_cols,
+                    const int32_t* row_group, int32_t group, double scale, void* mean, void* stream) {
+    if (!values || !colptr || !row_idx || !mean || n_cols < 0) return fail(ICV_ERR_INVALID, "bad colmean_csc arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_cols == 0) return ICV_OK;
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(icv::k_colpair_csc<float>, dim3((n_cols + 63) / 64), dim3(64), 0, st, (const float*)values,
+                           colptr, row_idx, n_cols, row_group, group, (float)scale, (float*)mean);
+    else if (dtype == ICV_F64)
+        hipLaunchKernelGGL(icv::k_colpair_csc<double>, dim3((n_cols + 63) / 64), dim3(64), 0, st, (const double*)values,
+                           colptr, row_idx, n_cols, row_group, group, scale, (double*)mean);
+    else
+        return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

@@ -1,0 +1,567 @@
+// Reference-order column sums (reference tl/_infercnv.py:385, :400: `np.mean(X, axis=0)` of the matrix as stored).
+//
+// numpy reduces a C-contiguous cells x genes matrix over axis 0 row by row: every column is ONE sequential chain
+// `acc = fl(acc + x[r][g])` in the matrix dtype (float32 stays float32), rows ascending, then `acc / n`.  scipy's CSR
+// mean is the same chain over `fl(x * fl(1/n))` (csc_matvecs of the transposed matrix walks the rows in order).  A
+// float32 chain is not associative, so the only parallelism an exact reproduction has is ACROSS columns:
+//
+//   k_colchain<T>: one 1024-thread workgroup per tile of 512 bytes of a row (128 float32 / 64 float64 columns).
+//     15 loader wavefronts copy the tile's row segments HBM -> LDS with LDS-DMA (`global_load_lds_dwordx4`: no staging
+//     registers, no ds_write), kChDepth rounds of 30 rows ahead -- the LDS ring IS the set of bytes in flight (135 KB
+//     per CU); ONE chain wavefront (lane = 2 float32 columns / 1 float64 column) adds the landed rows in order with
+//     v_pk_add_f32 / v_add_f64, 8-byte conflict-free LDS reads.  One s_barrier per round hands a ring slot over.
+//     The chain costs ~5 cycles per row (0.25 ms per 100 000 rows), far below the stream time of the tile, so the
+//     kernel runs at the rate the loaders pull HBM.
+//   CSR (k_colchain_csr): the same consumer; the loaders rebuild 64-row slices of the tile in LDS (zeros + the row's
+//     stored entries of the tile's columns times 1/n); adding the zeros of the absent entries is exact (acc + 0 = acc).
+//     Which entries of a row belong to a tile comes from k_csr_tile_bounds (one pass over the column indices).
+//   CSC input (k_colpair_csc): scipy reduces a CSC matrix per column with np.add.reduceat = first entry + numpy's
+//     pairwise sum of the rest; one thread per column restates that tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "icv_kernels.hpp"  // make_rsrc, u32x4
+
+namespace icv {
+
+constexpr int kChThreads = 1024;
+constexpr int kChLoaders = 15;   // wavefronts 0..14 load, wavefront 15 adds
+constexpr int kChMaxLines = 4;   // a tile is 1..4 cache lines (128 B) of a row: 64 chain lanes x 8 bytes at most
+constexpr int kChLdsFull = 160 * 1024, kChLdsHalf = 80 * 1024;  // one / two workgroups per CU
+
+typedef float chain_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void chain_add(chain_f2& acc, const chain_f2 v) {
+    // two columns per lane in one issue slot; IEEE round-to-nearest per component, denormals kept
+    asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc) : "v"(v));
+}
+__device__ __forceinline__ void chain_add(double& acc, const double v) {
+    asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc) : "v"(v));
+}
+
+template <typename T> struct ChainLane;
+template <> struct ChainLane<float> { typedef chain_f2 type; };
+template <> struct ChainLane<double> { typedef double type; };
+
+// LDS-DMA: 16 bytes per lane from `src` (per lane) to lds_base + 16 * lane (wave-uniform base, LDS byte address)
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+// Geometry of a tile of NL cache lines: LDS-DMA lanes per row, rows per 1 KB load, rows per round, bytes per ring slot
+// (u = loads per loader wavefront and round: 2 with the whole LDS of a CU, 1 with half of it)
+struct ChainGeom {
+    int lpr, rpl, round_rows, row_bytes, slot_bytes;
+    __host__ __device__ ChainGeom(int nl, int u)
+        : lpr(8 * nl), rpl(64 / (8 * nl)), round_rows(u * kChLoaders * (64 / (8 * nl))), row_bytes(128 * nl),
+          slot_bytes(u * kChLoaders * (64 / (8 * nl)) * 128 * nl) {}
+};
+
+// wait until at most n of this wavefront's LDS-DMA loads are outstanding (n wave-uniform, <= 15: the ring depth)
+__device__ __forceinline__ void chain_wait_vmcnt(int n) {
+    switch (n) {
+#define ICV_CH_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        ICV_CH_W(1) ICV_CH_W(2) ICV_CH_W(3) ICV_CH_W(4) ICV_CH_W(5) ICV_CH_W(6) ICV_CH_W(7) ICV_CH_W(8)
+        ICV_CH_W(9) ICV_CH_W(10) ICV_CH_W(11) ICV_CH_W(12) ICV_CH_W(13) ICV_CH_W(14) ICV_CH_W(15)
+#undef ICV_CH_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// The chain wavefront's loop for a tile of NL lines, RR rows per round (= ring slot); lane = 8 bytes of the row (2 float32 /
+// 1 float64 columns).  Hand-scheduled in chunks of ten rows (the asm operand limit is 30): the ten 8-byte LDS reads of
+// the NEXT ten rows are issued, then the ten dependent adds of the current ten run in their shadow, one lgkmcnt wait per
+// chunk; plain ds_read_b64 (the compiler's merged ds_read2st64_b64 costs four times the LDS cycles).  A lone wavefront
+// issues a ds_read_b64 every ~10 cycles, which is what a row costs here: 0.6 ms per 100 000 rows, half the stream time.
+// Measured alternatives (profiles/r04_colchain_experiments.txt): a read between every two adds, reads two chunks ahead in
+// fixed registers with counted waits -- both slower on narrow tiles (the reads' issue, not their latency, is the cost).
+#define ICV_CH_RD(i, RBS) "ds_read_b64 %[n" #i "], %[p] offset:" #i "*" RBS "\n\t"
+#define ICV_CH_AD(OP, i) OP " %[a], %[a], %[c" #i "]\n\t"
+#define ICV_CH_RD10(RBS)                                                                                         \
+    ICV_CH_RD(0, RBS) ICV_CH_RD(1, RBS) ICV_CH_RD(2, RBS) ICV_CH_RD(3, RBS) ICV_CH_RD(4, RBS) ICV_CH_RD(5, RBS) \
+    ICV_CH_RD(6, RBS) ICV_CH_RD(7, RBS) ICV_CH_RD(8, RBS) ICV_CH_RD(9, RBS)
+#define ICV_CH_AD10(OP)                                                                                    \
+    ICV_CH_AD(OP, 0) ICV_CH_AD(OP, 1) ICV_CH_AD(OP, 2) ICV_CH_AD(OP, 3) ICV_CH_AD(OP, 4) ICV_CH_AD(OP, 5) \
+    ICV_CH_AD(OP, 6) ICV_CH_AD(OP, 7) ICV_CH_AD(OP, 8) ICV_CH_AD(OP, 9)
+#define ICV_CH_OUT(NX)                                                                              \
+    [n0] "=&v"(NX[0]), [n1] "=&v"(NX[1]), [n2] "=&v"(NX[2]), [n3] "=&v"(NX[3]), [n4] "=&v"(NX[4]), \
+        [n5] "=&v"(NX[5]), [n6] "=&v"(NX[6]), [n7] "=&v"(NX[7]), [n8] "=&v"(NX[8]), [n9] "=&v"(NX[9])
+#define ICV_CH_IN(CX)                                                                                      \
+    [c0] "v"(CX[0]), [c1] "v"(CX[1]), [c2] "v"(CX[2]), [c3] "v"(CX[3]), [c4] "v"(CX[4]), [c5] "v"(CX[5]), \
+        [c6] "v"(CX[6]), [c7] "v"(CX[7]), [c8] "v"(CX[8]), [c9] "v"(CX[9])
+// ten rows at LDS address PX into NX[], waited for
+#define ICV_CH_LOAD(RBS, NX, PX) asm volatile(ICV_CH_RD10(RBS) "s_waitcnt lgkmcnt(0)" : ICV_CH_OUT(NX) : [p] "v"(PX))
+// the next ten rows into NX[] while the ten rows in CX[] are added
+#define ICV_CH_STEP(RBS, OP, AX, NX, CX, PX)                                  \
+    asm volatile(ICV_CH_RD10(RBS) ICV_CH_AD10(OP) "s_waitcnt lgkmcnt(0)"      \
+                 : [a] "+v"(AX), ICV_CH_OUT(NX)                               \
+                 : [p] "v"(PX), ICV_CH_IN(CX))
+#define ICV_CH_ADDS(OP, AX, CX) asm volatile(ICV_CH_AD10(OP) : [a] "+v"(AX) : ICV_CH_IN(CX))
+
+template <typename T, int NL, int RR>
+__device__ __forceinline__ void chain_rounds(const unsigned char* smem, int n_slots, int64_t n_rounds, int64_t n_sel,
+                                             int lane, typename ChainLane<T>::type& a) {
+    typedef typename ChainLane<T>::type lane_t;
+    constexpr int RB = 128 * NL, SLOT = RR * RB;
+    constexpr int NCH = RR / 10;
+    static_assert(RR % 10 == 0, "round rows");
+    int slot_i = 0;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)lane * 8u;
+    for (int64_t k = 0; k < n_rounds; ++k) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");  // the slot was written by the loaders' DMA: read it after the barrier
+        const unsigned p0 = lds0 + (unsigned)slot_i * (unsigned)SLOT;
+        const lane_t* slot = reinterpret_cast<const lane_t*>(smem + (size_t)slot_i * SLOT) + lane;
+        slot_i = slot_i + 1 == n_slots ? 0 : slot_i + 1;
+        const int64_t left = n_sel - k * RR;
+        if (left >= RR) {
+            lane_t va[10], vb[10];
+#define ICV_CH_BODY(RBS, OP)                                            \
+    ICV_CH_LOAD(RBS, va, p0);                                           \
+    _Pragma("unroll") for (int c = 0; c < NCH; c += 2) {                \
+        if (c + 1 < NCH) {                                              \
+            const unsigned p1 = p0 + (unsigned)((c + 1) * 10 * RB);     \
+            ICV_CH_STEP(RBS, OP, a, vb, va, p1);                        \
+            if (c + 2 < NCH) {                                          \
+                const unsigned p2 = p0 + (unsigned)((c + 2) * 10 * RB); \
+                ICV_CH_STEP(RBS, OP, a, va, vb, p2);                    \
+            } else {                                                    \
+                ICV_CH_ADDS(OP, a, vb);                                 \
+            }                                                           \
+        } else {                                                        \
+            ICV_CH_ADDS(OP, a, va);                                     \
+        }                                                               \
+    }
+            if constexpr (sizeof(T) == 4) {
+                if constexpr (NL == 1) { ICV_CH_BODY("128", "v_pk_add_f32") }
+                else if constexpr (NL == 2) { ICV_CH_BODY("256", "v_pk_add_f32") }
+                else if constexpr (NL == 3) { ICV_CH_BODY("384", "v_pk_add_f32") }
+                else { ICV_CH_BODY("512", "v_pk_add_f32") }
+            } else {
+                if constexpr (NL == 1) { ICV_CH_BODY("128", "v_add_f64") }
+                else if constexpr (NL == 2) { ICV_CH_BODY("256", "v_add_f64") }
+                else if constexpr (NL == 3) { ICV_CH_BODY("384", "v_add_f64") }
+                else { ICV_CH_BODY("512", "v_add_f64") }
+            }
+#undef ICV_CH_BODY
+        } else {
+            for (int i = 0; i < (int)left; ++i) chain_add(a, slot[i * (RB / 8)]);
+        }
+    }
+}
+
+// acc[c] (matrix dtype, in/out: a call continues the chain of the previous one) += rows sel[0..n_sel) of the dense
+// row-major matrix x (sel == nullptr: rows 0..n_sel), in that order.  Workgroup b of gridDim.x owns the cache lines
+// [b * n_lines / grid, (b + 1) * n_lines / grid) of every row (1..4 lines: the caller sizes the grid); `lds_bytes` of
+// dynamic LDS (kChLdsFull / kChLdsHalf) are the ring.
+// tail_row >= 0: that row is added last by the chain wavefront with guarded loads (the caller excludes it from n_sel):
+// the one row whose 16-byte segment loads could run past the end of the buffer.
+template <typename T, bool LIST>
+__global__ void __launch_bounds__(kChThreads) k_colchain(const T* __restrict__ x, int64_t ld, int n_cols, int n_lines,
+                                                         int lds_bytes, const int32_t* __restrict__ sel, int64_t n_sel,
+                                                         int64_t tail_row, T* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename ChainLane<T>::type lane_t;
+    constexpr int EPL = 16 / (int)sizeof(T);  // elements per loader lane (one 16-byte load)
+    constexpr int CPL = 8 / (int)sizeof(T);   // columns per chain lane
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int line0 = (int)((int64_t)blockIdx.x * n_lines / gridDim.x);
+    const int nl = (int)((int64_t)(blockIdx.x + 1) * n_lines / gridDim.x) - line0;
+    const int c0 = line0 * (128 / (int)sizeof(T));
+    const int u = lds_bytes > kChLdsHalf ? 2 : 1;  // (uniform over the grid)
+    const ChainGeom g(nl, u);
+    const int n_slots = lds_bytes / g.slot_bytes;
+    int depth = n_slots - 1;  // rounds in flight
+    if (depth * u > 15) depth = 15 / u;
+    const int64_t n_rounds = (n_sel + g.round_rows - 1) / g.round_rows;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;  // LDS byte address of the ring
+
+    if (wave < kChLoaders) {
+        // ---- loaders: lanes [q * lpr, (q + 1) * lpr) copy row q of the load's rpl rows; the rest idle ------------
+        const int q = lane / g.lpr;
+        int col = c0 + (lane - q * g.lpr) * EPL;
+        if (col >= n_cols) col = 0;  // lanes past the last column: any valid address, their LDS bytes are never added
+        // (a segment that straddles n_cols reads on into the row's padding or the next row: in bounds except on the
+        // buffer's last row -- the caller's tail_row)
+        const bool active = q < g.rpl;
+        int issue_slot = 0;
+        // LIST: the rows of one load are consecutive list entries, fetched with scalar loads (a vector load would have
+        // the compiler wait for vmcnt(0) and drain the DMA queue) ONE ROUND AHEAD of their use, selected per lane
+        int32_t rs_next[2] = {0, 0};
+        const auto fetch_list = [&](int64_t round) {
+            if (LIST && round < n_rounds) {
+                for (int j = 0; j < u; ++j) {
+                    const int64_t r0 = round * g.round_rows + (j * kChLoaders + wave) * g.rpl;
+                    int32_t rs = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i < g.rpl) {
+                            const int64_t ri = r0 + i < n_sel ? r0 + i : n_sel - 1;
+                            const int32_t v = sel[ri];
+                            if (q == i) rs = v;
+                        }
+                    rs_next[j] = rs;
+                }
+            }
+        };
+        const auto issue = [&](int64_t round) {
+            const int32_t rs0 = rs_next[0], rs1 = rs_next[1];
+            for (int j = 0; j < u; ++j) {
+                int64_t r = round * g.round_rows + (j * kChLoaders + wave) * g.rpl + q;
+                if (r >= n_sel) r = n_sel - 1;
+                if (LIST) r = j ? rs1 : rs0;
+                const unsigned dst = lds0 + (unsigned)issue_slot * (unsigned)g.slot_bytes +
+                                     (unsigned)((j * kChLoaders + wave) * g.rpl) * (unsigned)g.row_bytes;
+                if (active) lds_dma16(x + r * ld + col, dst);
+            }
+            issue_slot = issue_slot + 1 == n_slots ? 0 : issue_slot + 1;
+            fetch_list(round + 1);
+        };
+        fetch_list(0);
+        for (int64_t k = 0; k < depth - 1 && k < n_rounds; ++k) issue(k);
+        for (int64_t k = 0; k < n_rounds; ++k) {
+            if (k + depth - 1 < n_rounds) {
+                issue(k + depth - 1);
+                chain_wait_vmcnt((depth - 1) * u);  // round k has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        // ---- the chain: lane owns CPL adjacent columns ------------------------------------------------------------
+        const int col = lane * 8 < g.row_bytes ? c0 + lane * CPL : n_cols;
+        lane_t a;
+        if constexpr (sizeof(T) == 4) {
+            a.x = col < n_cols ? acc[col] : 0.f;
+            a.y = col + 1 < n_cols ? acc[col + 1] : 0.f;
+        } else {
+            a = col < n_cols ? acc[col] : 0.0;
+        }
+        const int rl = lane * 8 < g.row_bytes ? lane : 0;  // idle lanes read lane 0's bytes (never stored)
+        constexpr int L = kChLoaders;  // rows per round = loads per round (u x 15) x rows per load (64 / lanes per row)
+        if (u == 2) {
+            if (nl == 1) chain_rounds<T, 1, 2 * L * 8>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else if (nl == 2) chain_rounds<T, 2, 2 * L * 4>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else if (nl == 3) chain_rounds<T, 3, 2 * L * 2>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else chain_rounds<T, 4, 2 * L * 2>(smem, n_slots, n_rounds, n_sel, rl, a);
+        } else {
+            if (nl == 1) chain_rounds<T, 1, L * 8>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else if (nl == 2) chain_rounds<T, 2, L * 4>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else if (nl == 3) chain_rounds<T, 3, L * 2>(smem, n_slots, n_rounds, n_sel, rl, a);
+            else chain_rounds<T, 4, L * 2>(smem, n_slots, n_rounds, n_sel, rl, a);
+        }
+        if (tail_row >= 0) {
+            const T* xr = x + tail_row * ld;
+            if constexpr (sizeof(T) == 4) {
+                chain_f2 v;
+                v.x = col < n_cols ? xr[col] : 0.f;
+                v.y = col + 1 < n_cols ? xr[col + 1] : 0.f;
+                chain_add(a, v);
+            } else {
+                chain_add(a, col < n_cols ? xr[col] : 0.0);
+            }
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (col < n_cols) acc[col] = a.x;
+            if (col + 1 < n_cols) acc[col + 1] = a.y;
+        } else {
+            if (col < n_cols) acc[col] = a;
+        }
+    }
+}
+
+// grid and LDS of k_colchain for n_cols columns of `esz` bytes on a device with n_cu compute units
+struct ChainLaunch {
+    int n_lines, grid, lds_bytes;
+    ChainLaunch(int n_cols, int esz, int n_cu) {
+        n_lines = (int)(((int64_t)n_cols * esz + 127) / 128);
+        if (n_lines <= kChMaxLines * n_cu) {
+            grid = n_lines < n_cu ? n_lines : n_cu;  // one workgroup per CU, the whole LDS each
+            lds_bytes = kChLdsFull;
+        } else {
+            grid = (n_lines + kChMaxLines - 1) / kChMaxLines;
+            lds_bytes = grid <= n_cu ? kChLdsFull : kChLdsHalf;
+        }
+        if (grid < 1) grid = 1;
+    }
+};
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CSR input: the same chain over slices of the tile rebuilt in LDS
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kCcRows = 60;       // rows per round (one loader wavefront, lane = row; a multiple of the chain's ten)
+constexpr int kCcBlock = 64;      // rows per block of the bounds table
+
+// bounds[(blk * (n_tiles + 1) + t) * 64 + r] = number of entries of selected row blk * 64 + r in the tiles before t
+// (t = 0 .. n_tiles; the row's entries of tile t are [bounds[t], bounds[t + 1]) from the row's start): one pass over the
+// column indices, rows' columns ascending (canonical CSR).  line_tile[l] = tile of cache line l of a row.
+// grid = ceil(n_sel / 64) workgroups of four wavefronts; a wavefront takes one row at a time.
+template <bool LIST>
+__global__ void __launch_bounds__(256) k_csr_tile_bounds(const int64_t* __restrict__ indptr,
+                                                         const int32_t* __restrict__ indices,
+                                                         const int32_t* __restrict__ sel, int64_t n_sel,
+                                                         const uint16_t* __restrict__ line_tile, int esz_shift,
+                                                         int n_tiles, uint32_t* __restrict__ bounds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* blk = bounds + (int64_t)blockIdx.x * (n_tiles + 1) * kCcBlock;
+    for (int r = wave; r < kCcBlock; r += 4) {
+        const int64_t i = (int64_t)blockIdx.x * kCcBlock + r;
+        if (i >= n_sel) break;  // (uniform)
+        const int64_t row = LIST ? sel[i] : i;
+        const int64_t e0 = indptr[row];
+        const int64_t len = indptr[row + 1] - e0;
+        int carry = -1;  // tile of the entry before this chunk
+        for (int64_t base = 0; base <= len; base += 64) {
+            const int64_t pos = base + lane;
+            int T = n_tiles;  // pos == len: the terminator closes every remaining tile at `len`
+            if (pos < len) T = line_tile[((unsigned)indices[e0 + pos] << esz_shift) >> 7];
+            int P = __shfl_up(T, 1);
+            if (lane == 0) P = carry;
+            carry = __shfl(T, 63);
+            if (pos <= len)
+                for (int t = P + 1; t <= T; ++t) blk[(int64_t)t * kCcBlock + r] = (uint32_t)pos;
+        }
+    }
+}
+
+// acc[c] += fl(x * scale) over the stored entries of rows sel[0..n_sel) (nullptr: rows 0..n_sel), rows ascending --
+// scipy's CSR mean(axis=0): sum over rows of x * (1/n) in the matrix dtype.  Tiles and ring as k_colchain (grid =
+// ChainLaunch.grid = n_tiles of the bounds table); 15 loader wavefronts take turns: the owner of round k (60 rows,
+// lane = row) zeroes the slot and writes the rows' entries of the tile's columns (prefetched a turn earlier, their
+// bounds two turns earlier), S - 2 rounds ahead of the chain wavefront.
+template <typename T, bool LIST>
+__global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict__ vals, const int64_t* __restrict__ indptr,
+                                                             const int32_t* __restrict__ indices, int64_t n_rows_all,
+                                                             const int32_t* __restrict__ sel, int64_t n_sel, int n_cols,
+                                                             int n_lines, int lds_bytes,
+                                                             const uint32_t* __restrict__ bounds, T scale,
+                                                             T* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename ChainLane<T>::type lane_t;
+    constexpr int CPL = 8 / (int)sizeof(T);
+    constexpr int K = 64 / (int)sizeof(T);  // entries prefetched per row and tile (16 float32 / 8 float64)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int n_tiles = gridDim.x, tile = blockIdx.x;
+    const int line0 = (int)((int64_t)tile * n_lines / n_tiles);
+    const int nl = (int)((int64_t)(tile + 1) * n_lines / n_tiles) - line0;
+    const int c0 = line0 * (128 / (int)sizeof(T));
+    const int row_bytes = 128 * nl, slot_bytes = kCcRows * row_bytes;
+    const int n_slots = lds_bytes / slot_bytes;
+    const int lead = n_slots - 2;  // a slot is written this many rounds before the chain reads it
+    const int64_t n_rounds = (n_sel + kCcRows - 1) / kCcRows;
+
+    if (wave < kChLoaders) {
+        const int64_t e_end = indptr[n_rows_all];
+        // stage A: where the lane's row keeps its entries of this tile; stage B: the first K of them
+        int64_t a_e = 0;
+        int a_cnt = 0;
+        int64_t b_e = 0;
+        int b_cnt = 0;
+        int32_t b_idx[K];
+        T b_val[K];
+        const auto fetch_a = [&](int64_t k) {
+            const int64_t i = k * kCcRows + lane;
+            a_cnt = 0;
+            a_e = 0;
+            if (k < n_rounds && lane < kCcRows && i < n_sel) {
+                const int64_t row = LIST ? sel[i] : i;
+                const uint32_t* bb = bounds + ((i >> 6) * (n_tiles + 1) + tile) * kCcBlock + (i & 63);
+                const uint32_t lo = bb[0], hi = bb[kCcBlock];
+                a_e = indptr[row] + lo;
+                a_cnt = (int)(hi - lo);
+            }
+        };
+        const auto fetch_b = [&]() {
+            b_e = a_e;
+            b_cnt = a_cnt;
+            // range-checked 16-byte loads relative to the wavefront's first entry (rows ascend): lanes without entries
+            // and reads past the end of the arrays return zeros
+            int64_t e_first = b_cnt > 0 ? b_e : e_end;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const int64_t other = ((int64_t)__shfl_xor((int)(e_first >> 32), o) << 32) |
+                                      (unsigned)__shfl_xor((int)e_first, o);
+                e_first = other < e_first ? other : e_first;
+            }
+            e_first = ((int64_t)__builtin_amdgcn_readfirstlane((int)(e_first >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)e_first);
+            const int64_t left = e_end - e_first;
+            const unsigned rec = (unsigned)(left < 0x3fffffff ? left : 0x3fffffff);
+            const __amdgpu_buffer_rsrc_t i_rs = make_rsrc(indices + e_first, rec * 4u);
+            const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vals + e_first, rec * (unsigned)sizeof(T));
+            const int64_t rel = b_cnt > 0 ? b_e - e_first : 0x3fffffff;  // (no entries: out of range, zeros)
+            const unsigned off = (unsigned)(rel < 0x3fffffff ? rel : 0x3fffffff);
+#pragma unroll
+            for (int q = 0; q < K / 4; ++q) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(i_rs, off * 4u, q * 16, 0);
+                b_idx[4 * q] = (int)w.x, b_idx[4 * q + 1] = (int)w.y, b_idx[4 * q + 2] = (int)w.z, b_idx[4 * q + 3] = (int)w.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(v_rs, off * (unsigned)sizeof(T), q * 16, 0);
+                if constexpr (sizeof(T) == 4) {
+                    b_val[4 * q] = __uint_as_float(w.x), b_val[4 * q + 1] = __uint_as_float(w.y);
+                    b_val[4 * q + 2] = __uint_as_float(w.z), b_val[4 * q + 3] = __uint_as_float(w.w);
+                } else {
+                    b_val[2 * q] = __hiloint2double((int)w.y, (int)w.x);
+                    b_val[2 * q + 1] = __hiloint2double((int)w.w, (int)w.z);
+                }
+            }
+        };
+        const auto write_slot = [&](int64_t k) {
+            unsigned char* slot = smem + (size_t)(k % n_slots) * slot_bytes;
+            for (int o = lane * 16; o < slot_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(slot + o) = make_uint4(0, 0, 0, 0);
+            T* row = reinterpret_cast<T*>(slot + (size_t)lane * row_bytes);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                if (j < b_cnt) row[b_idx[j] - c0] = b_val[j] * scale;
+            for (int j = K; j < b_cnt; ++j) row[indices[b_e + j] - c0] = vals[b_e + j] * scale;  // long rows
+        };
+        int64_t mine = wave;  // this wavefront's next round
+        fetch_a(mine);
+        fetch_b();
+        fetch_a(mine + kChLoaders);
+        for (int64_t j = -lead; j < n_rounds; ++j) {
+            if (j + lead == mine && mine < n_rounds) {
+                write_slot(mine);
+                fetch_b();
+                mine += kChLoaders;
+                fetch_a(mine + kChLoaders);
+            }
+            if (j >= 0) __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        const int col = lane * 8 < row_bytes ? c0 + lane * CPL : n_cols;
+        lane_t a;
+        if constexpr (sizeof(T) == 4) {
+            a.x = col < n_cols ? acc[col] : 0.f;
+            a.y = col + 1 < n_cols ? acc[col + 1] : 0.f;
+        } else {
+            a = col < n_cols ? acc[col] : 0.0;
+        }
+        const int rl = lane * 8 < row_bytes ? lane : 0;
+        if (nl == 1) chain_rounds<T, 1, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
+        else if (nl == 2) chain_rounds<T, 2, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
+        else if (nl == 3) chain_rounds<T, 3, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
+        else chain_rounds<T, 4, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
+        if constexpr (sizeof(T) == 4) {
+            if (col < n_cols) acc[col] = a.x;
+            if (col + 1 < n_cols) acc[col + 1] = a.y;
+        } else {
+            if (col < n_cols) acc[col] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CSC input: scipy sums a CSC matrix over axis 0 with np.add.reduceat over each column's stored entries (after the
+// multiplication by 1/n): first entry + numpy's pairwise sum of the others (8 accumulators up to 128 elements, halves
+// rounded down to multiples of 8 above).  One thread per column walks its entries once per pass: the tree only needs
+// the elements in order.  row_group != nullptr: only entries of rows with row_group[row] == group count (X[rows of the
+// category, :] of a CSC matrix is again CSC).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct CscCursor {
+    const T* vals;
+    const int32_t* rows;
+    const int32_t* row_group;
+    int group;
+    int64_t e, e1;
+    T scale;
+    __device__ bool skip() {  // -> positioned on the next counted entry (false: none left)
+        if (row_group)
+            while (e < e1 && row_group[rows[e]] != group) ++e;
+        return e < e1;
+    }
+    __device__ T next() {
+        skip();
+        return vals[e++] * scale;
+    }
+};
+
+template <typename T>
+__device__ T numpy_pairwise_stream(CscCursor<T>& c, int64_t n) {
+    // explicit stack over numpy's recursion pairwise(a, n) = pairwise(a, n2) + pairwise(a + n2, n - n2)
+    int64_t todo[48];
+    T part[48];
+    int state[48];
+    int sp = 0;
+    todo[0] = n;
+    state[0] = 0;
+    T ret = 0;
+    while (sp >= 0) {
+        const int64_t m = todo[sp];
+        if (m <= 128) {
+            T res;
+            if (m < 8) {
+                res = (T)0;
+                for (int64_t i = 0; i < m; ++i) res = res + c.next();
+            } else {
+                T r[8];
+                for (int q = 0; q < 8; ++q) r[q] = c.next();
+                int64_t i = 8;
+                for (; i < m - (m % 8); i += 8)
+                    for (int q = 0; q < 8; ++q) r[q] = r[q] + c.next();
+                res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                for (; i < m; ++i) res = res + c.next();
+            }
+            ret = res;
+            --sp;
+            // return into the parents
+            while (sp >= 0) {
+                if (state[sp] == 1) {  // left half done: descend into the right half
+                    part[sp] = ret;
+                    state[sp] = 2;
+                    int64_t n2 = todo[sp] / 2;
+                    n2 -= n2 % 8;
+                    ++sp;
+                    todo[sp] = todo[sp - 1] - n2;
+                    state[sp] = 0;
+                    break;
+                }
+                ret = part[sp] + ret;  // state 2: both halves done
+                --sp;
+            }
+        } else {
+            state[sp] = 1;
+            int64_t n2 = m / 2;
+            n2 -= n2 % 8;
+            ++sp;
+            todo[sp] = n2;
+            state[sp] = 0;
+        }
+    }
+    return ret;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_colpair_csc(const T* __restrict__ vals, const int64_t* __restrict__ colptr,
+                                                    const int32_t* __restrict__ rows, int n_cols,
+                                                    const int32_t* __restrict__ row_group, int group, T scale,
+                                                    T* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_cols) return;
+    CscCursor<T> cur{vals, rows, row_group, group, colptr[c], colptr[c + 1], scale};
+    int64_t n = cur.e1 - cur.e;
+    if (row_group) {
+        n = 0;
+        for (int64_t e = cur.e; e < cur.e1; ++e) n += row_group[rows[e]] == group;
+    }
+    T res = (T)0;
+    if (n > 0) {
+        res = cur.next();
+        if (n > 1) res = res + numpy_pairwise_stream(cur, n - 1);
+    }
+    out[c] = res;
+}
+
+}  // namespace icv

@@ -1,0 +1,127 @@
+"""GPU tests (``-m gpu``) of the reference-order column means (``icv_colchain`` / ``icv_colmean_csc``).
+
+The reference's default call (``reference=None`` / ``reference_cat``) forms its profile with ``np.mean(X, axis=0)``
+(reference tl/_infercnv.py:385, :400).  numpy / scipy evaluate that in a fixed order -- sequential float32 chains per
+column for a C-contiguous matrix and for CSR, ``np.add.reduceat`` per column for CSC -- and a float32 sum is not
+associative, so "the same mean" means "the same order".  Every comparison here is ``array_equal`` (bit for bit) against
+the oracle's ``reference_profile``, which calls the very numpy / scipy primitives the reference calls.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _expr(n, g, seed, dtype=np.float32, density=None):
+    rs = np.random.RandomState(seed)
+    X = rs.gamma(0.3, 1.0, size=(n, g)).astype(dtype)
+    if density is None:
+        X[X < 0.5] = 0
+    else:
+        X[rs.rand(n, g) >= density] = 0
+    return X
+
+
+def _oracle_means(X, labels=None, cats=None):
+    from oracle import infercnv_oracle as O
+
+    return np.asarray(O.reference_profile(X, labels, cats, None, X.shape[1]))
+
+
+def _gpu_means(X, labels=None, cats=None, pieces=1):
+    """The engine's calls as tl.infercnv makes them: row pieces in order, one chain per category."""
+    from infercnvpy_amd import _engine
+
+    torch = _engine._torch()
+    n = X.shape[0]
+    Xd = X.astype(np.float64) if X.dtype.kind in "iub" else X
+    dm = _engine.to_device_matrix(Xd)
+    groups = [None] if cats is None else [np.asarray(labels) == c for c in cats]
+    bounds = np.linspace(0, n, pieces + 1).astype(int)
+    out = []
+    for sel in groups:
+        count = n if sel is None else int(sel.sum())
+        acc = None
+        for r0, r1 in zip(bounds[:-1], bounds[1:]):
+            if r1 == r0:
+                continue
+            rows = None if sel is None else np.nonzero(sel[r0:r1])[0]
+            acc = _engine.column_chain(dm, acc, rows, count, int(r0), int(r1))
+        out.append(_engine.chain_mean(acc, count, sp.issparse(X)).cpu().numpy())
+    torch.cuda.synchronize()
+    return np.vstack(out)
+
+
+DENSE_SHAPES = [(3001, 1337), (999, 20003), (4000, 20000), (61, 130), (1, 3), (29, 5), (2500, 40001), (700, 257)]
+
+
+@pytest.mark.parametrize("shape", DENSE_SHAPES)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_dense_all_cells_mean_is_numpy_bit_for_bit(shape, dtype):
+    X = _expr(*shape, seed=shape[0], dtype=dtype)
+    got = _gpu_means(X)
+    exp = _oracle_means(X)
+    assert got.dtype == exp.dtype
+    np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize("pieces", [1, 3, 7])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_dense_category_means_over_row_pieces(pieces, dtype):
+    n, g = 2311, 5003
+    X = _expr(n, g, seed=5) if dtype != np.int64 else np.random.RandomState(5).poisson(0.4, (n, g)).astype(np.int64)
+    X = X.astype(dtype)
+    labels = np.array(["a", "b", "c", "d"])[np.random.RandomState(6).randint(0, 4, n)]
+    got = _gpu_means(X, labels, ["c", "a"], pieces=pieces)
+    exp = _oracle_means(X, labels, ["c", "a"])
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(_gpu_means(X, pieces=pieces), _oracle_means(X))
+
+
+@pytest.mark.parametrize("shape,density", [((5000, 20000), 0.07), ((1200, 20003), 0.3), ((300, 700), 0.02),
+                                            ((777, 40001), 0.05), ((64, 129), 1.0), ((2000, 5000), 0.0005)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_csr_means_are_scipy_bit_for_bit(shape, density, dtype):
+    X = sp.csr_matrix(_expr(*shape, seed=shape[1], dtype=dtype, density=density))
+    np.testing.assert_array_equal(_gpu_means(X), _oracle_means(X))
+    labels = np.array(["n", "t", "u"])[np.random.RandomState(1).randint(0, 3, shape[0])]
+    for pieces in (1, 4):
+        got = _gpu_means(X, labels, ["t", "n"], pieces=pieces)
+        np.testing.assert_array_equal(got, _oracle_means(X, labels, ["t", "n"]))
+
+
+def test_csr_integer_counts_and_long_rows():
+    rs = np.random.RandomState(3)
+    Xi = rs.poisson(0.3, (900, 3000)).astype(np.int64)
+    Xi[5] = rs.poisson(3.0, 3000)  # a row with (nearly) every column stored
+    Xi[17] = 0                      # an empty row
+    X = sp.csr_matrix(Xi)
+    labels = np.array(["n", "t"])[rs.randint(0, 2, 900)]
+    np.testing.assert_array_equal(_gpu_means(X), _oracle_means(X))
+    np.testing.assert_array_equal(_gpu_means(X, labels, ["n", "t"], pieces=3), _oracle_means(X, labels, ["n", "t"]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_csc_means_are_scipy_bit_for_bit(dtype):
+    from infercnvpy_amd import _engine
+
+    rs = np.random.RandomState(8)
+    n, g = 3000, 1500
+    D = _expr(n, g, seed=8, density=0.2)
+    D[:, 7] = 0          # a column without entries
+    D[:, 9] = rs.gamma(0.3, 1.0, n) + 0.1  # a full column: the pairwise tree at its largest
+    D[:5, 11] = 1.0      # few entries
+    D[5:, 11] = 0
+    X = sp.csc_matrix(D.astype(dtype))
+    np_dtype = np.float32 if dtype == np.float32 else np.float64
+    got = _engine.csc_column_means(X, np_dtype=np_dtype, max_entries=200_000)
+    np.testing.assert_array_equal(got, _oracle_means(X))
+    labels = np.array(["n", "t", "u"])[rs.randint(0, 3, n)]
+    groups = np.full(n, -1, np.int32)
+    counts = []
+    for gi, c in enumerate(["u", "n"]):
+        groups[labels == c] = gi
+        counts.append(int((labels == c).sum()))
+    got = _engine.csc_column_means(X, groups, 2, counts, np_dtype=np_dtype)
+    np.testing.assert_array_equal(got, _oracle_means(X, labels, ["u", "n"]))
