@@ -55,15 +55,20 @@ def _reference_groups(obs, reference_key, reference_cat):
     return groups, counts, cats
 
 
-def _means_from_sums(sums, counts, cats, mean_dtype):
-    """R x G means from the float64 per-group column sums of ALL rows, rounded once to the dtype numpy returns."""
-    if cats is None:
-        return (sums / counts).astype(mean_dtype)
-    labels = cats.tolist()
-    if len(set(labels)) != len(labels):  # same label listed twice: rows repeat
-        first = {c: i for i, c in reversed(list(enumerate(labels)))}
-        sums = np.vstack([sums[first[c]] for c in labels])
-    return (sums / counts[:, None]).astype(mean_dtype)
+def _means_from_chains(accs, counts, cats, is_sparse):
+    """R x G means from the reference-order accumulators of the LAST shard (one array of the matrix dtype per group).
+    Dense input: numpy's own last step, ``true_divide(sum, n)`` in that dtype; CSR input: scipy scaled every entry by
+    1 / n before adding, the accumulators are the means."""
+    rows = []
+    for gi, acc in enumerate(accs):
+        n = int(counts if cats is None else counts[gi])
+        rows.append(acc if is_sparse else np.true_divide(acc, n))
+    if cats is not None:
+        labels = cats.tolist()
+        if len(set(labels)) != len(labels):  # same label listed twice: rows repeat
+            first = {c: i for i, c in reversed(list(enumerate(labels)))}
+            rows = [rows[first[c]] for c in labels]
+    return np.vstack(rows)
 
 
 def _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs=None):
@@ -107,7 +112,7 @@ class _Shard:
         self.tm = {}
         self.result = None      # (indptr, indices, data) of the shard's X_cnv
         self.gene_pieces = []
-        self.sums = None        # float64 host [R, G]: this shard's reference partial sums
+        self.accs = None        # host, per group: reference-order accumulators after this shard's rows
 
 
 def infercnv(
@@ -140,10 +145,14 @@ def infercnv(
     four chunks and 50 000 cells (one GPU inside a ``torch.distributed`` job).  ``devices`` (not part of the reference API) names
     the GPUs explicitly; a GPU listed twice carries two shards.  Shard boundaries are multiples of ``chunksize``,
     so the noise threshold -- the standard deviation of each ``chunksize``-cell chunk, reference :449-451 -- never
-    couples two shards and ``X_cnv`` does not depend on the number of GPUs when ``reference`` is given.  When the
-    reference profile is a mean over cells, every shard's float64 column sums come back to the host (R x G x 8
-    bytes per shard), are added in shard order and rounded once: the only exchange between shards (a mean may
-    differ in its last bit from the one-GPU mean: another order of float64 additions).
+    couples two shards and ``X_cnv`` does not depend on the number of GPUs.  When the reference profile is a mean
+    over cells (``reference=None``), it is formed in the reference's own evaluation order -- numpy adds a C-contiguous
+    matrix row by row in the matrix dtype, scipy adds ``x * (1 / n)`` row by row for CSR and reduces CSC columns
+    pairwise (reference :385, :400) -- so the means, and with them ``X_cnv``, equal the reference's bit for bit.  A
+    float32 chain is sequential per column: with several GPUs shard k continues the accumulators of shard k - 1 (R x G
+    values travel through the host); the uploads of all shards still overlap.  Not reproduced: the order numpy uses
+    for a dense matrix that is not C-contiguous (it is treated as C-contiguous) and scipy's order for sparse formats
+    other than CSR / CSC (converted to CSR).
     ``_timings`` (not part of the reference API): a dict that receives the wall-clock seconds of the stages (plan,
     host -> HBM copy, kernels, CSR pack + copy back; per shard under ``"shards"`` when there are several).
 
@@ -180,6 +189,7 @@ def infercnv(
     X = adata.X if layer is None else adata.layers[layer]
     if isinstance(X, np.matrix):
         X = np.asarray(X)
+    X_csc = X if (sp.issparse(X) and X.format == "csc") else None  # scipy reduces CSC columns in another order
     if sp.issparse(X):
         X = X.tocsr()
         if not X.has_canonical_format:  # the kernels expect unique, sorted column indices per row
@@ -239,9 +249,26 @@ def infercnv(
     tm["plan"] = _time.perf_counter() - t_start
     tm["devices"] = list(devs)
 
+    if need_means and X_csc is not None:
+        # CSC input: np.add.reduceat per column over ALL rows of the group -- not separable by row shards; the CSC
+        # arrays go to the first GPU in column blocks (values + row indices, 8 bytes per stored entry)
+        t0 = _time.perf_counter()
+        with torch.cuda.device(devs[0]):
+            cnt = [int(n_obs)] if cats is None else [int(c) for c in counts]
+            means = _engine.csc_column_means(X_csc, groups, n_groups, cnt, np_dtype=mean_dtype)
+        given = _means_from_chains(list(means), counts, cats, True)
+        need_means = False
+        tm["reference_pass"] = _time.perf_counter() - t0
+
     barrier = threading.Barrier(len(shards)) if multi else None
+    chained = [threading.Event() for _ in shards]  # shard k's reference-order accumulators are on the host
     ref_box = {}
     errors = []
+
+    def wait_for(ev):
+        while not ev.wait(0.05):
+            if errors:
+                raise threading.BrokenBarrierError
 
     def per_row_bytes(plan):
         if sp.issparse(X):
@@ -289,25 +316,32 @@ def infercnv(
         try:
             if need_means:
                 t0 = _time.perf_counter()
-                sums = None
+                if slabs:
+                    slab_stream(0)  # the upload starts now, whatever this shard has to wait for
+                accs = [None] * n_groups
+                if s.index > 0:  # continue the chains of the rows before this shard
+                    wait_for(chained[s.index - 1])
+                    accs = [torch.from_numpy(a).cuda() for a in shards[s.index - 1].accs]
                 for i, (s0, _) in enumerate(slabs):
                     ss = slab_stream(i)
                     for r0, r1 in ss.pieces():
-                        rg = None if groups is None else groups[s.g0 + s0 + r0: s.g0 + s0 + r1]
-                        sums = _engine.column_sums(ss.dm, rg, n_groups, sums, r0, r1)
+                        for gi in range(n_groups):
+                            rows, n_g = None, counts
+                            if groups is not None:
+                                rows = np.nonzero(groups[s.g0 + s0 + r0: s.g0 + s0 + r1] == gi)[0]
+                                n_g = counts[gi]
+                            accs[gi] = _engine.column_chain(ss.dm, accs[gi], rows, n_g, r0, r1)
                     ss = None
-                s.sums = (sums.cpu().numpy() if sums is not None else np.zeros((n_groups, n_vars)))
+                s.accs = [(a.cpu().numpy() if a is not None else np.zeros(n_vars, dtype=mean_dtype)) for a in accs]
+                chained[s.index].set()
                 if multi:
-                    barrier.wait()  # every shard's sums are on the host
+                    barrier.wait()  # every shard's accumulators are on the host
                     if s.index == 0:
-                        total = shards[0].sums.copy()
-                        for other in shards[1:]:  # fixed order: the means do not depend on thread timing
-                            total += other.sums
-                        ref_box["ref"] = _means_from_sums(total, counts, cats, mean_dtype)
+                        ref_box["ref"] = _means_from_chains(shards[-1].accs, counts, cats, sp.issparse(X))
                     barrier.wait()
                     ref = ref_box["ref"]
                 else:
-                    ref = _means_from_sums(s.sums, counts, cats, mean_dtype)
+                    ref = _means_from_chains(s.accs, counts, cats, sp.issparse(X))
                 s.tm["reference_pass"] = _time.perf_counter() - t0
             else:
                 ref = given

@@ -32,12 +32,11 @@ def diagnose(T, seed, sd):
         ref = (X.mean(axis=0) + rng.normal(0, 0.05, X.shape[1])).astype(mean_dtype)
         api["reference"] = ref
     elif ref_kind == "none":
-        ref = (X.sum(axis=0, dtype=np.float64) / X.shape[0]).astype(mean_dtype)
+        ref = T._oracle_means(Xin)
     else:
         cats = ["a"] if ref_kind == "cat1" else ["b", "c"]
         api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
-        ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in cats]).astype(
-            mean_dtype)
+        ref = T._oracle_means(Xin, labels, cats)
     tm = {}
     _, res, _ = cnv.tl.infercnv(ad, inplace=False, _timings=tm, **api)
     _, e_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, **kw)

@@ -61,14 +61,13 @@ def one_case(seed):
     X[rows[4]] = 1e6
     special["huge"] = int(rows[4])
     X[rows[5], : G // 2] = 0
+    Xin = sp.csr_matrix(X) if fmt == "csr" else X
     if ref_kind == "none":
-        ref = (X.sum(axis=0, dtype=np.float64) / n).astype(np.float32)
+        ref = T._oracle_means(Xin)  # the reference's own mean of the matrix as stored
     elif ref_kind in ("cat1", "cat2"):
         cats = ["a"] if ref_kind == "cat1" else ["b", "c"]
         api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
-        ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in cats]).astype(
-            np.float32)
-    Xin = sp.csr_matrix(X) if fmt == "csr" else X
+        ref = T._oracle_means(Xin, labels, cats)
     var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
     ad = SimpleAnnData(Xin, obs=pd.DataFrame({"group": labels}), var=var)
     tm = {}

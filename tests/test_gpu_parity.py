@@ -83,29 +83,24 @@ def test_sparse_float32_goldens_take_the_stored_entries_kernel(name, monkeypatch
     np.testing.assert_allclose(a, b, rtol=0, atol=2.5e-7)
 
 
-def _exact_means(g):
-    """Correctly rounded per-group means, in the dtype numpy would return (what the GPU path produces)."""
-    X = g.X_dense
-    out_dtype = np.float32 if X.dtype == np.float32 else np.float64
-    key = g.kwargs.get("reference_key")
-    if key is None:
-        return (X.sum(axis=0, dtype=np.float64) / X.shape[0]).astype(out_dtype)
-    cats = g.kwargs["reference_cat"]
-    cats = [cats] if isinstance(cats, str) else cats
-    return np.vstack([X[g.obs == c].sum(axis=0, dtype=np.float64) / (g.obs == c).sum() for c in cats]).astype(out_dtype)
+def _oracle_means(X, labels=None, cats=None):
+    """The reference's own means (np.mean(X, axis=0) of the matrix AS STORED -- dense, CSR and CSC are three different
+    evaluation orders, reference :385, :400), through the oracle's restatement of _get_reference."""
+    from oracle import infercnv_oracle as O
+
+    if cats is not None and isinstance(cats, str):
+        cats = [cats]
+    return np.asarray(O.reference_profile(X, labels, cats, None, X.shape[1]))
 
 
 @pytest.mark.parametrize("name", MEAN_ON_GPU_CASES)
 def test_golden_reference_mean_on_gpu(name):
-    """Cases where the reference profile is computed from the matrix (reference :385, :400).
-
-    The GPU accumulates column sums in float64 and rounds the mean once to the dtype numpy returns;
-    numpy accumulates float32 matrices in float32 and scipy.sparse computes sum(x * (1/n)), so the
-    reference's own mean can be off by an ulp (and its dense and CSR paths disagree with each
-    other).  (a) With the correctly rounded means passed explicitly the oracle must be matched
-    exactly; (b) against the captured reference output only entries within that ulp of the noise
-    threshold may differ.  Integer matrices with several reference categories truncate the centred
-    values (reference :428), which amplifies the scipy ulp to whole units: (b) is skipped there."""
+    """Cases where the reference profile is computed from the matrix (reference :385, :400): the reference's DEFAULT
+    call.  The GPU forms the means in numpy's / scipy's own evaluation order (sequential float32 chains per column for
+    dense and CSR input, np.add.reduceat per column for CSC: icv_colchain / icv_colmean_csc), so every case -- the
+    integer CSR matrix with two categories included, where a last-bit difference of a mean is amplified to whole units
+    by the truncation of reference :428 -- must reproduce the captured reference output: identical zero pattern (no
+    threshold flips), values to float32 storage."""
     import infercnvpy_amd as cnv
     from oracle import infercnv_oracle as O
 
@@ -113,18 +108,38 @@ def test_golden_reference_mean_on_gpu(name):
     chr_pos, res, _ = cnv.tl.infercnv(_adata(g), inplace=False, **g.api_kwargs())
     assert {k: int(v) for k, v in chr_pos.items()} == g.chr_pos
     got = res.toarray()
-    # (a)
+    # (a) the captured reference output
+    np.testing.assert_array_equal(got == 0, g.out == 0)
+    np.testing.assert_allclose(got, g.out, rtol=0, atol=ATOL_TIGHT)
+    # (b) the oracle with ITS means of the matrix as stored
     kw = {k: v for k, v in g.array_kwargs().items() if k not in ("obs_col", "reference_cat")}
-    _, exp, _, _ = O.infercnv(g.X, g.chromosome, g.start, reference=_exact_means(g), **kw)
+    ref = _oracle_means(g.X, g.obs, g.kwargs.get("reference_cat") if g.kwargs.get("reference_key") else None)
+    _, exp, _, _ = O.infercnv(g.X, g.chromosome, g.start, reference=ref, **kw)
     exp = exp.toarray()
     np.testing.assert_array_equal(got == 0, exp == 0)
     np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
-    # (b)
-    if name == "m_csr_i64_r2":
-        return
-    flipped = (got == 0) != (g.out == 0)
-    assert flipped.mean() <= 2e-3, f"{flipped.sum()} threshold flips"
-    np.testing.assert_allclose(got[~flipped], g.out[~flipped], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("fmt", ["dense", "csr"])
+def test_reference_mean_goldens_bit_for_bit(fmt):
+    """refmean_dense / refmean_csr: `_get_reference` of the reference itself on a float32 matrix (all cells; two
+    categories), captured in the build container: the GPU's means are array_equal."""
+    from infercnvpy_amd import _engine
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"refmean_{fmt}.npz"), allow_pickle=False)
+    X, labels = z["X"], z["obs"]
+    Xin = sp.csr_matrix(X) if fmt == "csr" else X
+    dm = _engine.to_device_matrix(Xin)
+    acc = _engine.column_chain(dm, None, None, X.shape[0])
+    got = _engine.chain_mean(acc, X.shape[0], fmt == "csr").cpu().numpy()
+    assert got.dtype == z["r_all"].dtype
+    np.testing.assert_array_equal(got[None, :], z["r_all"])
+    rows = []
+    for c in ("normalA", "normalB"):
+        sel = np.nonzero(labels == c)[0]
+        acc = _engine.column_chain(dm, None, sel, len(sel))
+        rows.append(_engine.chain_mean(acc, len(sel), fmt == "csr").cpu().numpy())
+    np.testing.assert_array_equal(np.vstack(rows), z["r_cat"])
 
 
 @pytest.mark.parametrize("name", [n for n in case_names() if n.startswith("genevals") or n.startswith("mock4x10")])
@@ -293,22 +308,18 @@ def test_config1_like_step1_direct_form():
     labels = np.array(["Microglia"] * 30 + ["Oligo"] * 25 + ["tumor"] * 128)
     var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
     obs = pd.DataFrame({"cell_type": labels}, index=[f"c{i}" for i in range(183)])
-    ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum()
-                     for c in ("Microglia", "Oligo")]).astype(np.float32)
-    o_pos, o_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, step=1)
-    exp = o_res.toarray()
-    assert exp.shape[1] == sum(g - 99 for g in genes)
-    first = None
     for wrap in (np.asarray, sp.csr_matrix, sp.csc_matrix):
+        # the means are those of the matrix as stored: numpy (dense), scipy CSR and scipy CSC add in three orders
+        ref = _oracle_means(wrap(X), labels, ["Microglia", "Oligo"])
+        o_pos, o_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, step=1)
+        exp = o_res.toarray()
+        assert exp.shape[1] == sum(g - 99 for g in genes)
         ad = SimpleAnnData(wrap(X), obs=obs.copy(), var=var)
         cnv.tl.infercnv(ad, reference_key="cell_type", reference_cat=["Microglia", "Oligo"], step=1)
         got = ad.obsm["X_cnv"].toarray()
         assert {k: int(x) for k, x in ad.uns["cnv"]["chr_pos"].items()} == {k: int(x) for k, x in o_pos.items()}
         np.testing.assert_array_equal(got == 0, exp == 0)
         np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
-        if first is None:
-            first = got
-        np.testing.assert_array_equal(got, first)
 
 
 @pytest.mark.parametrize("fmt", ["dense", "csr"])
@@ -993,12 +1004,11 @@ def _check_sweep_case(seed, sd, extras=False):
         ref = (X.mean(axis=0) + rng.normal(0, 0.05, X.shape[1])).astype(mean_dtype)
         api["reference"] = ref
     elif ref_kind == "none":
-        ref = (X.sum(axis=0, dtype=np.float64) / X.shape[0]).astype(mean_dtype)  # correctly rounded mean
+        ref = _oracle_means(Xin)  # the reference's own mean of the matrix as stored (dense / CSR / CSC orders)
     else:
         cats = ["a"] if ref_kind == "cat1" else ["b", "c"]
         api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
-        ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in cats]).astype(
-            mean_dtype)
+        ref = _oracle_means(Xin, labels, cats)
     tm = {}
     gene_values = bool(extras and rng.rand() < 0.33)
     if extras and rng.rand() < 0.33:
@@ -1155,8 +1165,8 @@ def test_gene_sets_larger_than_lds_split_by_chromosome_group(dtype, genes_per_ch
     ad = SimpleAnnData(sp.csr_matrix(X) if fmt == "csr" else X, obs=pd.DataFrame({"group": labels}), var=var)
     gvals = dtype == np.float64 and fmt == "dense"
     mean_dtype = np.float32 if dtype == np.float32 else np.float64
-    ref = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in ("a", "b")]).astype(
-        mean_dtype)
+    ref = _oracle_means(ad.X, labels, ["a", "b"])
+    assert ref.dtype == mean_dtype
     chr_pos, res, gv = cnv.tl.infercnv(ad, reference_key="group", reference_cat=["a", "b"], chunksize=10,
                                        inplace=False, calculate_gene_values=gvals)
     e_pos, e_res, e_gv, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref, chunksize=10,

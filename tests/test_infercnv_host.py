@@ -58,24 +58,65 @@ def test_resolve_devices():
     assert T._resolve_devices(None, None, 200, t8, n_obs=4000) == [3]
 
 
-def test_means_from_shard_sums_equal_the_reference_semantics():
+def _chain_dense(X, rows, acc):
+    """CPU restatement of icv_colchain on a dense matrix: one sequential chain per column, in the matrix dtype."""
+    for r in rows:
+        acc = acc + X[r]
+    return acc
+
+
+def _chain_csr(S, rows, scale, acc):
+    """... on a CSR matrix: fl(x * scale) added row after row (scipy: (X * (1 / n)).sum(axis=0) = ones @ X)."""
+    for r in rows:
+        a, b = S.indptr[r], S.indptr[r + 1]
+        acc[S.indices[a:b]] = acc[S.indices[a:b]] + S.data[a:b] * scale
+    return acc
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64])
+def test_means_from_shard_chains_equal_the_reference_bit_for_bit(dtype):
+    """The evaluation order the GPU path reproduces (csrc/icv_kernel_chain.hpp), restated with plain loops on the CPU
+    and chained over three row shards as tl.infercnv chains them, against the oracle's reference_profile = the numpy /
+    scipy calls of the reference (:385, :400): array_equal, dense and CSR, all cells and categories (one listed twice)."""
+    import scipy.sparse as sp
+
+    from oracle import infercnv_oracle as O
+
     rng = np.random.RandomState(0)
-    X = rng.gamma(0.3, 1.0, size=(230, 40)).astype(np.float32)
+    X = rng.gamma(0.3, 1.0, size=(230, 40))
+    X[X < 0.5] = 0
+    X = (X * 3).astype(dtype)
+    acc_dtype = np.float32 if dtype == np.float32 else np.float64
     labels = np.array(["a", "b", "c"])[rng.randint(0, 3, 230)]
     obs = pd.DataFrame({"g": labels})
-    # all-cell mean
     bounds = shard_bounds(230, 3, 50)
-    total = sum(X[a:b].sum(axis=0, dtype=np.float64)[None, :] for a, b in bounds)
-    ref = T._means_from_sums(total, 230.0, None, np.float32)
-    np.testing.assert_array_equal(ref, (X.sum(axis=0, dtype=np.float64) / 230).astype(np.float32)[None, :])
+    S = sp.csr_matrix(X)
+    # all-cell mean
+    acc = np.zeros(40, acc_dtype)
+    acc_s = np.zeros(40, acc_dtype)
+    for a, b in bounds:  # shard k continues shard k - 1's accumulators
+        acc = _chain_dense(X.astype(acc_dtype), range(a, b), acc)
+        acc_s = _chain_csr(S.astype(acc_dtype), range(a, b), acc_dtype(1.0 / 230), acc_s)
+    ref = T._means_from_chains([acc], 230.0, None, False)
+    np.testing.assert_array_equal(ref, np.asarray(O.reference_profile(X, None, None, None, 40)))
+    ref = T._means_from_chains([acc_s], 230.0, None, True)
+    np.testing.assert_array_equal(ref, np.asarray(O.reference_profile(S, None, None, None, 40)))
+    assert ref.dtype == acc_dtype
     # per category, a category listed twice repeats its row (np.isin semantics of the reference)
     groups, counts, cats = T._reference_groups(obs, "g", ["b", "a", "b"])
     assert counts.tolist() == [(labels == "b").sum(), (labels == "a").sum(), (labels == "b").sum()]
     assert set(np.unique(groups)) == {-1, 0, 1}  # the second "b" never owns rows
-    sums = np.vstack([X[groups == k].sum(axis=0, dtype=np.float64) for k in range(3)])
-    ref = T._means_from_sums(sums, counts, cats, np.float64)
-    exp = np.vstack([X[labels == c].sum(axis=0, dtype=np.float64) / (labels == c).sum() for c in ["b", "a", "b"]])
-    np.testing.assert_array_equal(ref, exp)
+    accs = [np.zeros(40, acc_dtype) for _ in range(3)]
+    accs_s = [np.zeros(40, acc_dtype) for _ in range(3)]
+    for a, b in bounds:
+        for gi in range(3):
+            rows = a + np.nonzero(groups[a:b] == gi)[0]
+            accs[gi] = _chain_dense(X.astype(acc_dtype), rows, accs[gi])
+            accs_s[gi] = _chain_csr(S.astype(acc_dtype), rows, acc_dtype(1.0 / counts[gi]), accs_s[gi])
+    ref = T._means_from_chains(accs, counts, cats, False)
+    np.testing.assert_array_equal(ref, np.asarray(O.reference_profile(X, labels, ["b", "a", "b"], None, 40)))
+    ref = T._means_from_chains(accs_s, counts, cats, True)
+    np.testing.assert_array_equal(ref, np.asarray(O.reference_profile(S, labels, ["b", "a", "b"], None, 40)))
     groups, counts, cats = T._reference_groups(obs, "g", "c")
     assert counts.tolist() == [(labels == "c").sum()] and (groups >= 0).sum() == counts[0]
     with pytest.raises(ValueError):
@@ -99,3 +140,55 @@ def test_concat_csr_is_vstack():
     np.testing.assert_array_equal(got.indptr, exp.indptr)
     np.testing.assert_array_equal(got.indices, exp.indices)
     np.testing.assert_array_equal(got.data, exp.data)
+
+
+def _numpy_pairwise(a):
+    """numpy's pairwise summation (8 accumulators up to 128 elements, halves rounded down to multiples of 8 above),
+    restated: what k_colpair_csc walks on the GPU."""
+    n = len(a)
+    if n < 8:
+        res = a.dtype.type(0)
+        for v in a:
+            res = res + v
+        return res
+    if n <= 128:
+        r = [a[k] for k in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for k in range(8):
+                r[k] = r[k] + a[i + k]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res = res + a[i]
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return _numpy_pairwise(a[:n2]) + _numpy_pairwise(a[n2:])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_csc_mean_is_first_entry_plus_numpy_pairwise_of_the_rest(dtype):
+    """scipy reduces a CSC matrix over axis 0 with np.add.reduceat per column (after scaling by 1 / n): the order
+    icv_colmean_csc restates, here in plain Python against the oracle (= scipy) on columns of 0 .. 3000 entries."""
+    from oracle import infercnv_oracle as O
+
+    rng = np.random.RandomState(1)
+    n, g = 3000, 24
+    X = rng.gamma(0.3, 1.0, size=(n, g)).astype(dtype)
+    for c, dens in enumerate(np.linspace(0, 1, g)):
+        X[rng.rand(n) >= dens, c] = 0
+    X[:, -1] = rng.gamma(0.3, 1.0, n) + 0.1
+    S = sp.csc_matrix(X)
+    labels = np.array(["a", "b"])[rng.randint(0, 2, n)]
+    for sel, cats in ((np.ones(n, bool), None), (labels == "b", ["b"])):
+        inv = dtype(1.0 / sel.sum())
+        out = np.zeros(g, dtype)
+        for c in range(g):
+            a, b = S.indptr[c], S.indptr[c + 1]
+            p = (S.data[a:b] * inv)[sel[S.indices[a:b]]]
+            if len(p):
+                out[c] = p[0] + _numpy_pairwise(p[1:]) if len(p) > 1 else p[0]
+        exp = np.asarray(O.reference_profile(S, labels if cats else None, cats, None, g))[0]
+        np.testing.assert_array_equal(out, exp)
