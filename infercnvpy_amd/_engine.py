@@ -377,6 +377,50 @@ def threshold_mask(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc
     return PackedRows(res.out, mask, counts, res.thr)
 
 
+class PackedCsr:
+    """X_cnv of a row range as device CSR: ``indptr`` (rows + 1 int64, from 0), ``indices`` (int32) / ``data`` (float64)
+    buffers of which the first ``indptr[-1]`` entries are valid."""
+
+    def __init__(self, indptr, indices, data, n_cols, thr=None):
+        self.indptr, self.indices, self.data, self.n_cols, self.thr = indptr, indices, data, n_cols, thr
+
+    @property
+    def n_rows(self):
+        return self.indptr.shape[0] - 1
+
+    def nnz(self):
+        """Number of stored entries (reads one value back: synchronises the current stream)."""
+        return int(self.indptr[-1].item())
+
+    def to_scipy(self):
+        """Host ``scipy.sparse.csr_matrix`` (float64), as the reference returns."""
+        ip = self.indptr.cpu().numpy()
+        n = int(ip[-1])
+        return sp.csr_matrix((self.data[:n].cpu().numpy(), self.indices[:n].cpu().numpy(), ip),
+                             shape=(self.n_rows, self.n_cols))
+
+
+def threshold_pack(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_clip, chunksize, row_phase=0,
+                   flags=0, row0=0, row1=None, capacity=None):
+    """Step 5b + ``csr_matrix(x_res)`` in one pass (``icv_threshold_pack``): the un-thresholded ``res.out`` of
+    :func:`run_hot_path` (``apply=False``) -> :class:`PackedCsr` on the device.  ``capacity`` (entries) defaults to the
+    worst case rows x windows; nothing is read back, the call is asynchronous."""
+    torch = _torch()
+    lib = _lib.load()
+    rows = res.out.shape[0]
+    W = plan.n_windows
+    cap = rows * W if capacity is None else int(capacity)
+    indptr = torch.empty(rows + 1, dtype=torch.int64, device="cuda")
+    indices = torch.empty(max(cap, 1), dtype=torch.int32, device="cuda")
+    data = torch.empty(max(cap, 1), dtype=torch.float64, device="cuda")
+    m = dm.c_struct(row0, row1)
+    _lib.check(lib.icv_threshold_pack(
+        plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(res.out),
+        res.out.stride(0), _ptr(res.cell_median), _ptr(res.thr), int(chunksize), int(row_phase), _ptr(indptr),
+        _ptr(indices), _ptr(data), cap, _stream_ptr(torch)))
+    return PackedCsr(indptr, indices, data, W, res.thr)
+
+
 _PAGE = 4096
 
 
@@ -469,18 +513,21 @@ class _PinnedRing:
 class CsrDrain:
     """CSR pack + copy back of finished pieces on a side stream while the caller computes the next ones.
 
-    ``submit(part)`` (a :class:`PackedRows`, consecutive row ranges in order) returns at once; a helper thread waits
-    for the piece on its own stream, forms the row offsets, packs indices / float64 values on the device and copies
-    them into the final host arrays (sized from the first piece's density, grown if that was too small).
-    ``finish()`` returns the scipy CSR matrix of all rows."""
+    ``submit(part)`` (a :class:`PackedCsr` -- the piece packed on the device by ``icv_threshold_pack`` -- or a
+    :class:`PackedRows` mask for the two-step form; consecutive row ranges in order) returns at once, or blocks while
+    ``max_pending`` pieces are still queued (a packed piece holds a worst-case buffer).  A helper thread waits for the
+    piece on its own stream, reads the row offsets back and copies the packed entries into the final host arrays (sized
+    from the first piece's density, grown if that was too small).  ``finish()`` returns the scipy CSR matrix of all
+    rows."""
 
-    def __init__(self, n_rows, n_cols):
+    def __init__(self, n_rows, n_cols, max_pending=2):
         import queue
         import threading
 
         torch = _torch()
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self._q = queue.Queue()
+        self._slots = threading.Semaphore(max_pending)
         self._stream = torch.cuda.Stream()
         self._err = None
         self._cancel = threading.Event()
@@ -533,35 +580,54 @@ class CsrDrain:
                             return
                         if self._cancel.is_set():  # a failed call: drop what is queued, keep draining to the sentinel
                             del item
+                            self._slots.release()
                             continue
                         part, ev = item
                         t0 = time.perf_counter()
                         self._stream.wait_event(ev)
-                        n = part.counts.shape[0]
-                        ip = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
-                        torch.cumsum(part.counts, 0, out=ip[1:])
-                        ip_h = ip.cpu().numpy()
-                        nnz = int(ip_h[-1])
+                        if isinstance(part, PackedCsr):
+                            n = part.n_rows
+                            ip, idx_d, dat_d = part.indptr, part.indices, part.data
+                            ip_h = ip.cpu().numpy()
+                            nnz = int(ip_h[-1])
+                            if nnz > idx_d.shape[0]:
+                                raise RuntimeError(f"icv_threshold_pack: {nnz} entries for a capacity of {idx_d.shape[0]}")
+                            held = (ip, idx_d, dat_d)
+                        else:
+                            n = part.counts.shape[0]
+                            ip = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+                            torch.cumsum(part.counts, 0, out=ip[1:])
+                            ip_h = ip.cpu().numpy()
+                            nnz = int(ip_h[-1])
+                            idx_d = dat_d = None
+                            held = (part.out, part.mask, part.counts)
+                            if nnz:
+                                idx_d = torch.empty(nnz, dtype=torch.int32, device="cuda")
+                                dat_d = torch.empty(nnz, dtype=torch.float64, device="cuda")
+                                _lib.check(lib.icv_csr_fill_masked(
+                                    _ptr(part.out), n, self.n_cols, part.out.stride(0), _ptr(part.mask), _ptr(ip),
+                                    _ptr(idx_d), _ptr(dat_d), self._stream.cuda_stream))
                         reserve(nnz, self.rows_done + n)
                         if nnz:
-                            idx_d = torch.empty(nnz, dtype=torch.int32, device="cuda")
-                            dat_d = torch.empty(nnz, dtype=torch.float64, device="cuda")
-                            _lib.check(lib.icv_csr_fill_masked(
-                                _ptr(part.out), n, self.n_cols, part.out.stride(0), _ptr(part.mask), _ptr(ip), _ptr(idx_d),
-                                _ptr(dat_d), self._stream.cuda_stream))
                             o = self.nnz
                             if ring is not None:
-                                self._pending += ring.download(idx_d, self.indices_h[o:o + nnz], self._stream)
-                                self._pending += ring.download(dat_d, self.data_h[o:o + nnz], self._stream)
+                                self._pending += ring.download(idx_d[:nnz], self.indices_h[o:o + nnz], self._stream)
+                                self._pending += ring.download(dat_d[:nnz], self.data_h[o:o + nnz], self._stream)
                             else:
-                                torch.from_numpy(self.indices_h[o:o + nnz]).copy_(idx_d)
-                                torch.from_numpy(self.data_h[o:o + nnz]).copy_(dat_d)
-                            # (freed in stream order: the allocator reuses the blocks behind the copies enqueued above)
-                            del idx_d, dat_d
+                                torch.from_numpy(self.indices_h[o:o + nnz]).copy_(idx_d[:nnz])
+                                torch.from_numpy(self.data_h[o:o + nnz]).copy_(dat_d[:nnz])
+                        # the piece's buffers were allocated on the CONSUMER's stream and are read here on the drain's
+                        # (fill kernel, asynchronous copies): the caching allocator must not hand them out before this
+                        # stream is done with them
+                        for t in held:
+                            if t is not None:
+                                t.record_stream(self._stream)
+                        del idx_d, dat_d, held
                         self.indptr_h[self.rows_done + 1:self.rows_done + n + 1] = ip_h[1:] + self.nnz
                         self.rows_done += n
                         self.nnz += nnz
                         del part, item, ip
+                        self._slots.release()
                         self.busy_seconds += time.perf_counter() - t0
             except BaseException as e:  # surfaced in finish()
                 self._err = e
@@ -573,6 +639,7 @@ class CsrDrain:
                     try:
                         if self._q.get(timeout=60) is None:
                             return
+                        self._slots.release()
                     except queue.Empty:
                         return
 
@@ -581,6 +648,9 @@ class CsrDrain:
 
     def submit(self, part):
         torch = _torch()
+        while not self._slots.acquire(timeout=0.05):  # back-pressure: at most max_pending pieces wait for the drain
+            if self._err is not None:
+                raise self._err
         if self._err is not None:
             raise self._err
         ev = torch.cuda.Event()

@@ -1363,6 +1363,52 @@ int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
     return ICV_OK;
 }
 
+int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                       int32_t flags, const float* out, int64_t ldo, const double* cell_median, const double* thr,
+                       int64_t chunksize, int64_t row_phase, int64_t* indptr, int32_t* indices, double* data,
+                       int64_t capacity, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
+    if (!cell_median || !indptr || !indices || !data || capacity < 0 ||
+        (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize)))
+        return fail(ICV_ERR_INVALID, "bad threshold_pack arguments");
+    if (pl->p.W > 320 * 64) return fail(ICV_ERR_UNSUPPORTED, "icv_threshold_pack: more than 20480 windows");
+    if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
+    icv::KParams K;
+    const icv::Layout* lay;
+    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, const_cast<float*>(out), ldo,
+                          const_cast<double*>(cell_median), nullptr, K, lay)))
+        return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (K.n_rows < 1) {
+        HIP_TRY(hipMemsetAsync(indptr, 0, sizeof(int64_t), st));
+        return ICV_OK;
+    }
+    if (K.n_rows > 0xffffffffll) return fail(ICV_ERR_UNSUPPORTED, "icv_threshold_pack: more than 2^32 rows per call");
+    // look-back workspace: one status word per row + the ticket counter, zeroed in stream order
+    AsyncBuf ws;
+    HIP_TRY(ws.alloc((size_t)(K.n_rows + 1) * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ws.p, 0, (size_t)(K.n_rows + 1) * sizeof(unsigned long long), st));
+    auto* status = ws.as<unsigned long long>();
+    auto* ticket = reinterpret_cast<unsigned int*>(status + K.n_rows);
+    const int64_t cs = thr ? chunksize : 1;
+    dim3 grid((unsigned)K.n_rows), block(256);
+#define ICV_PACK(TT, CC) \
+    hipLaunchKernelGGL((icv::k_thr_pack<TT, CC>), grid, block, 0, st, K, thr, cs, row_phase, ticket, status, indptr, indices, data, capacity)
+    if (m->dtype == ICV_F32) {
+        if (m->format == ICV_DENSE) ICV_PACK(float, false);
+        else ICV_PACK(float, true);
+    } else {
+        if (m->format == ICV_DENSE) ICV_PACK(double, false);
+        else ICV_PACK(double, true);
+    }
+#undef ICV_PACK
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
 int icv_csr_fill_masked(const float* x, int64_t n_rows, int32_t n_cols, int64_t ld, const uint64_t* mask,
                         const int64_t* indptr, int32_t* indices, double* data, void* stream) {
     if (!x || !mask || !indptr || !indices || !data || n_cols < 0 || ld < n_cols)

@@ -957,6 +957,151 @@ __global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double*
     if (threadIdx.x == 0) row_nnz[cell] = (int64_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3] - dropped);
 }
 
+// Step 5b + `csr_matrix(x_res)` (reference :449-455) in ONE pass over x_res: the decision of k_thr_mask, the row's kept
+// count, the row's offset in the packed output from a decoupled look-back over the rows before it, and the entries
+// (int32 column, float64 value) written straight from the row -- x_res is read from HBM once (the packing re-reads the
+// row from L2, 7 KB a row), no mask array, no separate scan, no second kernel.
+//   status[r]: 64-bit word per row {2-bit flag, 62-bit value}: 1 = the row's own count, 2 = the inclusive prefix of rows
+//   0..r (one relaxed agent-scope 8-byte store: value and flag cannot tear); rows are taken in the order of a ticket
+//   counter, so every predecessor of a waiting row is running or done.  `ticket` and `status` are zeroed by the caller.
+//   indptr[0 .. n_rows] (relative to `nnz0`, the entries of earlier pieces), indices / data of capacity `cap` entries:
+//   an entry beyond `cap` is dropped (the caller sizes for the worst case or checks indptr[n_rows]).
+constexpr unsigned long long kPackAgg = 1ull << 62, kPackPfx = 2ull << 62, kPackVal = (1ull << 62) - 1;
+template <typename T, bool CSR>
+__global__ void __launch_bounds__(256) k_thr_pack(const KParams P, const double* thr, int64_t chunksize,
+                                                  int64_t row_phase, unsigned int* ticket, unsigned long long* status,
+                                                  int64_t* indptr, int32_t* indices, double* data, int64_t cap) {
+    constexpr int kMaxWords = 320;  // 20 480 windows
+    __shared__ int tie_n, cell_s;
+    __shared__ int tie_j[32];
+    __shared__ double vals[kTieBuf];
+    __shared__ unsigned long long mwords[kMaxWords];
+    __shared__ int woff[kMaxWords];
+    __shared__ long long base_s;
+    if (threadIdx.x == 0) {
+        cell_s = (int)atomicAdd(ticket, 1u);
+        tie_n = 0;
+    }
+    __syncthreads();
+    const int64_t cell = cell_s;
+    const bool has_thr = thr != nullptr;
+    const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
+    const float thf = (float)th;
+    const float* orow = P.out + cell * P.ldo;
+    const int n_words = (P.W + 63) >> 6;
+    for (int j0 = 0; j0 < P.W; j0 += 4 * 256) {
+        float yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256 + (int)threadIdx.x;
+            yv[u] = j < P.W ? __builtin_nontemporal_load(orow + j) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256 + (int)threadIdx.x;
+            bool keep = false;
+            if (j < P.W) {
+                const float y = yv[u];
+                keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
+                if (has_thr) {
+                    const int cmp = thr_compare(fabsf(y), thf);
+                    if (cmp < 0) keep = false;
+                    else if (cmp == 0 && keep) {  // float32 cannot decide: exact float64 recomputation below
+                        const int idx = atomicAdd(&tie_n, 1);
+                        if (idx < 32) {
+                            tie_j[idx] = j;
+                        } else {  // > 32 ties in one row: resolve serially
+                            const int st = P.w_start[j];
+                            const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                                              P.cell_median[cell];
+                            if (fabs(yd) < th) keep = false;
+                        }
+                    }
+                }
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if ((threadIdx.x & 63) == 0 && j < P.W) mwords[j >> 6] = m;
+        }
+    }
+    __syncthreads();  // mask words and the tie list are complete
+    const int nt = tie_n < 32 ? tie_n : 32;
+    for (int i = 0; i < nt; ++i) {  // rare (about one window in 1e7): the block recomputes it together
+        const int j = tie_j[i];
+        const int st = P.w_start[j], ln = P.w_len[j];
+        const int len = ln > 0 ? ln : -ln;
+        bool drop = false;
+        if (len <= kTieBuf) {
+            for (int k = threadIdx.x; k < len; k += 256) vals[k] = value_at<T, CSR>(P, cell, st + k);
+            __syncthreads();
+            if (threadIdx.x == 0)
+                drop = fabs(window_canonical(P, j, [&](int k) { return vals[k]; }) - P.cell_median[cell]) < th;
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            drop = fabs(window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                        P.cell_median[cell]) < th;
+        }
+        if (threadIdx.x == 0 && drop) mwords[j >> 6] &= ~(1ull << (j & 63));
+    }
+    if (nt) __syncthreads();
+    // ---- wavefront 0: offsets of the mask words inside the row, the row's count, the look-back ----------------------
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int run = 0;
+        for (int w0 = 0; w0 < n_words; w0 += 64) {
+            const int cnt = w0 + lane < n_words ? __popcll(mwords[w0 + lane]) : 0;
+            const int incl = wave_scan_dpp(cnt);
+            if (w0 + lane < n_words) woff[w0 + lane] = run + incl - cnt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+        }
+        const unsigned long long mine = (unsigned long long)run;
+        unsigned long long excl = 0;
+        if (cell > 0) {
+            if (lane == 0)
+                __hip_atomic_store(status + cell, kPackAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look back 64 rows at a time: lane l reads row cell - 1 - l (of this window); sum the counts up to and
+            // including the nearest row that already knows its prefix
+            int64_t hi = cell - 1;
+            while (true) {
+                const int64_t r = hi - lane;
+                unsigned long long sv;
+                do {  // every row of the window has started (tickets are handed out in order): it publishes soon
+                    sv = r >= 0 ? __hip_atomic_load(status + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPackPfx;
+                } while (__builtin_amdgcn_ballot_w64((sv >> 62) == 0) != 0);
+                const unsigned long long pfx = __builtin_amdgcn_ballot_w64((sv >> 62) == 2);
+                const int first = pfx ? __builtin_ctzll(pfx) : 64;  // nearest row with a prefix
+                unsigned long long part = lane <= first ? (sv & kPackVal) : 0;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const unsigned plo = (unsigned)__shfl_xor((int)(unsigned)part, o), phi = (unsigned)__shfl_xor((int)(unsigned)(part >> 32), o);
+                    part += ((unsigned long long)phi << 32) | plo;
+                }
+                excl += part;
+                if (pfx) break;
+                hi -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(status + cell, kPackPfx | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            base_s = (long long)excl;
+            if (cell == 0) indptr[0] = 0;
+            indptr[cell + 1] = (int64_t)(excl + mine);
+        }
+    }
+    __syncthreads();
+    // ---- pack: the row again (L2), entries in window order --------------------------------------------------------
+    const int64_t base = base_s;
+    for (int j = threadIdx.x; j < P.W; j += 256) {
+        const unsigned long long m = mwords[j >> 6];
+        if ((m >> (j & 63)) & 1ull) {
+            const int64_t pos = base + woff[j >> 6] + __popcll(m & ((1ull << (j & 63)) - 1ull));
+            if (pos < cap) {
+                indices[pos] = j;
+                data[pos] = (double)orow[j];
+            }
+        }
+    }
+}
+
 // x_res = window - median (float32), per-cell moments and median, from float64 windows resident in HBM (the
 // last step of the chromosome-group fallback; same DPP reduction tree as the smoothing kernels)
 __global__ void __launch_bounds__(256) k_win_finish(const double* win, int64_t n_rows, int W, const double* med,

@@ -167,9 +167,9 @@ def infercnv(
     vectors; expected well below one entry per 10^9).
 
     Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
-    while the pieces that have landed are smoothed (reference means: summed); X_cnv is packed to CSR on the
-    GPU from the un-thresholded result and a keep-mask (x_res is never rewritten) and only the packed arrays
-    cross PCIe on the way back.
+    while the pieces that have landed are smoothed (reference means: chained); the noise threshold and the CSR
+    packing of X_cnv are one pass over the un-thresholded result on the GPU (x_res is read once and never
+    rewritten) and only the packed arrays cross PCIe on the way back.
     """
     tm = _timings if _timings is not None else {}
     t_start = _time.perf_counter()
@@ -286,14 +286,16 @@ def infercnv(
         plan = plan0 if s.index == 0 else GenePlan(var_chrom, var_start, **plan_kw)
         n_rows = s.g1 - s.g0
         Xs = X if (s.g0 == 0 and s.g1 == n_obs) else X[s.g0:s.g1]  # slicing a CSR matrix copies it
-        # row slabs (multiples of chunksize) sized to fit this shard's share of the GPU's free HBM
-        free_b, _ = torch.cuda.mem_get_info()
+        # pieces of a slab: a few chunks each (~2 GB of input), copied by a helper thread while earlier ones compute
         per_row = per_row_bytes(plan)
-        slab_rows = int((0.45 * free_b / s.share) // per_row)
+        piece_rows = max(chunksize, int(2e9 // max(per_row, 1)) // chunksize * chunksize)
+        # row slabs (multiples of chunksize) sized to fit this shard's share of the GPU's free HBM, next to the packed
+        # results of the pieces on their way back (worst case 12 bytes per window, three pieces at a time)
+        free_b, _ = torch.cuda.mem_get_info()
+        packed = 3 * min(piece_rows, max(n_rows, 1)) * plan.n_windows * 12
+        slab_rows = int(max(0.45 * free_b / s.share - packed, 0) // per_row)
         slab_rows = max(chunksize, slab_rows // chunksize * chunksize)
         slabs = [(r, min(n_rows, r + slab_rows)) for r in range(0, max(n_rows, 1), slab_rows)] if n_rows else []
-        # pieces of a slab: a few chunks each (~2 GB of input), copied by a helper thread while earlier ones compute
-        piece_rows = max(chunksize, int(2e9 // max(per_row, 1)) // chunksize * chunksize)
         t_h2d = [0.0]
         streams = {}
         drain = None
@@ -366,8 +368,11 @@ def infercnv(
                     res = _engine.run_hot_path(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                                dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
                                                row0=r0, row1=r1, apply=False)
-                    drain.submit(_engine.threshold_mask(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
-                                                        chunksize=chunksize, flags=flags, row0=r0, row1=r1))
+                    # step 5b + csr_matrix(x_res) in one pass over x_res (icv_threshold_pack); very long window lists
+                    # (> 20 480) keep the two-step form (keep-mask, then the fill on the drain's stream)
+                    pack = _engine.threshold_pack if plan.n_windows <= 20480 else _engine.threshold_mask
+                    drain.submit(pack(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                                      flags=flags, row0=r0, row1=r1))
                     if res.thr is not None:
                         thrs.append(res.thr)
                     del res

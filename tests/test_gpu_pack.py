@@ -1,0 +1,76 @@
+"""GPU tests (``-m gpu``) of ``icv_threshold_pack``: step 5b and ``csr_matrix(x_res)`` (reference tl/_infercnv.py:449-455)
+in one pass with a decoupled look-back over the rows, against the two-step form (keep-mask + prefix sum + fill) and
+against the in-place threshold: identical CSR arrays, run after run."""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_step(torch, _engine, _lib, plan, dm, ref, res, chunksize, lfc_clip=3.0):
+    import ctypes as C
+
+    lib = _lib.load()
+    part = _engine.threshold_mask(plan, dm, ref, None, res, lfc_clip=lfc_clip, chunksize=chunksize)
+    n = part.counts.shape[0]
+    ip = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(part.counts, 0, out=ip[1:])
+    nnz = int(ip[-1].item())
+    idx = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
+    dat = torch.empty(max(nnz, 1), dtype=torch.float64, device="cuda")
+    if nnz:
+        _lib.check(lib.icv_csr_fill_masked(_engine._ptr(part.out), n, plan.n_windows, part.out.stride(0),
+                                           _engine._ptr(part.mask), _engine._ptr(ip), _engine._ptr(idx),
+                                           _engine._ptr(dat), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return ip.cpu().numpy(), idx[:nnz].cpu().numpy(), dat[:nnz].cpu().numpy()
+
+
+@pytest.mark.parametrize("fmt,dtype,genes,window,step,dyn,n", [
+    ("dense", np.float32, cases.GENES_PER_CHROM_20K, 100, 10, 1.5, 7003),
+    ("csr", np.float32, cases.GENES_PER_CHROM_20K, 250, 10, 1.5, 3001),
+    ("dense", np.float64, [700, 320, 150, 100, 60], 100, 10, 0.5, 1234),
+    ("csr", np.float64, [700, 320, 150, 100, 60], 101, 7, None, 999),
+    ("dense", np.float32, cases.GENES_PER_CHROM_20K, 100, 1, 1.5, 300),     # 17 822 windows: 279 mask words
+    ("dense", np.float32, [130, 40], 100, 10, 3.0, 5000),                   # a handful of windows, most rows empty
+])
+def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
+    from infercnvpy_amd import _engine, _lib
+    from infercnvpy_amd._plan import GenePlan
+
+    torch = _engine._torch()
+    v = cases.synthetic_var(genes)
+    X = cases.synthetic_expr(n, len(v["names"]), seed=n, dtype=dtype)
+    ref_h = X.mean(axis=0).astype(dtype)
+    dm = _engine.to_device_matrix(sp.csr_matrix(X) if fmt == "csr" else X)
+    ref = torch.from_numpy(ref_h).cuda()
+    plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=step)
+    chunksize = 500
+    try:
+        res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=dyn, chunksize=chunksize, apply=False)
+        ip2, ix2, dv2 = _two_step(torch, _engine, _lib, plan, dm, ref, res, chunksize)
+        for rep in range(3):  # the look-back must give the same arrays whatever order the rows finish in
+            pk = _engine.threshold_pack(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+            ip = pk.indptr.cpu().numpy()
+            nnz = int(ip[-1])
+            np.testing.assert_array_equal(ip, ip2)
+            np.testing.assert_array_equal(pk.indices[:nnz].cpu().numpy(), ix2)
+            np.testing.assert_array_equal(pk.data[:nnz].cpu().numpy(), dv2)
+        # ... and the in-place threshold of the same x_res, packed by scipy
+        res_a = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=dyn, chunksize=chunksize, apply=True)
+        exp = sp.csr_matrix(res_a.out.cpu().numpy().astype(np.float64))
+        got = pk.to_scipy()
+        assert got.shape == exp.shape
+        np.testing.assert_array_equal(got.indptr, exp.indptr)
+        np.testing.assert_array_equal(got.indices, exp.indices)
+        np.testing.assert_array_equal(got.data, exp.data)
+        # a capacity that is too small drops the overflow but still reports the count
+        if nnz > 10:
+            small = _engine.threshold_pack(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize, capacity=nnz // 2)
+            assert small.nnz() == nnz
+            np.testing.assert_array_equal(small.indices[: nnz // 2].cpu().numpy(), ix2[: nnz // 2])
+    finally:
+        plan.close()
