@@ -8,11 +8,17 @@ With N > 1 and no WORLD_SIZE in the environment the script re-executes itself as
 GPU, backend nccl = RCCL over xGMI); it exits non-zero if the box has fewer than N GPUs.  Started by a launcher
 (WORLD_SIZE set) it checks that WORLD_SIZE == --gpus.
 
-One "step" = one pass of the whole hot path over one batch of synthetic cells that is already resident in HBM:
-reference mean (float64 column sums, + ONE RCCL all-reduce of [G + 1] float64 when N > 1) -> fused centre / clip /
-pyramid-smooth / median kernel -> per-chunk std -> threshold.
-  N = 1   BASELINE config 2: dense fp32 100 000 cells x 20 000 genes (chr1..22, random var order), window 100,
-          step 10, chunksize 5000.
+One "step" = one pass of the whole hot path over one batch of synthetic cells that is already resident in HBM.
+  N = 1   ONE CALL OF THE PUBLIC FUNCTION, cnv.tl.infercnv(adata) with the reference's default arguments
+          (reference=None: the all-cell mean is part of the step), on BASELINE config 2: dense fp32 100 000 cells x
+          20 000 genes (chr1..22, random var order) as a CUDA tensor in adata.X, window 100, step 10, chunksize 5000.
+          Inside: reference-order column means (k_colchain, bit-equal to np.mean) -> fused centre / clip /
+          pyramid-smooth / median kernel -> per-chunk std -> noise threshold + CSR packing of X_cnv (k_thr_mask,
+          k_row_offsets, k_csr_fill_masked; reference _infercnv.py:449-455 is inside the chunk kernel) -> X_cnv as
+          device CSR float64.
+          The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
+  N > 1   one process per GPU over the rows of config 3: float64 column sums + ONE RCCL all-reduce of [G + 1] float64
+          -> the same smoothing kernel -> per-chunk std -> in-place threshold (dist.run_shard).
   N > 1   BASELINE config 3: 1 000 000 cells x 20 000 genes in total, row shards aligned to the 5000-cell chunks
           (dist.shard_bounds; 125 000 cells per GPU at N = 8): strong scaling.  Every 5000-cell chunk is generated
           from its own seed, so the data do not depend on N.
@@ -26,10 +32,12 @@ Prints ONE JSON line on rank 0: value = cells/s of the whole job (HBM-resident i
                  N = 1: dense 200 000 x 20 000 and the config-4 CSR.  N > 1: ONE call with devices=[0..N-1] (the
                  multi-GPU path of the public API: row shards, one uploader + CSR drain per GPU), 100 000 dense
                  cells per GPU, while the other ranks wait at a barrier with their HBM released.
-  extra        - (N = 1) the other BASELINE configurations, HBM resident, each with its own roofline: config 4 (CSR
-                 window 250), CSR window 100, config 3's 1 M cells on one GPU, the product-path variant of the step
-                 (thresholds as a keep-mask + device-side CSR pack instead of the in-place threshold), config 5
-                 (distances + Ward at 100 000 x 5 000).
+  stages       - (N = 1) the step's kernels timed one by one with events on the launch stream (engine-level calls that
+                 mirror the public function), each with its own roofline: k_colchain, smoothing + thresholds, threshold + CSR pack
+  extra        - (N = 1) the other BASELINE configurations, HBM resident, through the same public call, each with its
+                 own roofline: config 4 (CSR window 250), CSR window 100, config 3's 1 M cells on one GPU, the round-3
+                 form of the step (float64 column sums + in-place threshold, no CSR), config 5 (distances + Ward at
+                 200 000 x 5 000 when HBM allows).
 
 ``--dry-run-one-gpu`` (never a measurement: prints "dry_run": true): all N ranks share cuda:0 and the collectives
 go through gloo -- exercises the launcher, the sharding and the N > 1 code paths on a one-GPU box.
@@ -149,11 +157,47 @@ def _cpu_pool_rate(workers, window, step, cells_per_worker, reps):
     return n / max(busy), n, max(busy), wall
 
 
-def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2):
+def _cpu_chunk_worker(args):
+    """One 5000-cell chunk as the reference's process pool runs it (one task = one chunk, tl/_infercnv.py:120-135)."""
+    import numpy as np
+
+    import cases
+    from oracle import infercnv_oracle as O
+
+    seed, n_cells, window, step = args
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    X = cases.synthetic_expr(n_cells, 20000, seed=seed)
+    ref = X.mean(axis=0, dtype=np.float64).astype(np.float32)[None, :]
+    t0 = time.perf_counter()
+    O.infercnv_chunk(X, v["chromosome"], v["start"], ref, 3, window, step, 1.5)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2, slice_cells=100_000, chunk=CHUNK):
+    from concurrent.futures import ProcessPoolExecutor
+
     logical = os.cpu_count() or 1
     physical = min(_physical_cores(), logical)
+    # SURVEY §8(d): the reference's structure -- ProcessPoolExecutor over 5000-row chunks of a 100 000-cell slice (20
+    # tasks), one worker per physical core; every worker builds its own chunk (the matrix is not pickled through the
+    # pool), the clock runs over the slowest chunk's compute time and, separately, over the wall time of the pool
+    n_tasks = slice_cells // chunk
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=min(physical, n_tasks)) as pool:
+        busy = list(pool.map(_cpu_chunk_worker, [(300 + i, chunk, window, step) for i in range(n_tasks)]))
+    wall = time.perf_counter() - t0
+    spec = {
+        "value": slice_cells / max(busy), "unit": "cells/s", "cores": min(physical, n_tasks), "kind": "port",
+        "wall_cells_per_s": slice_cells / wall, "per_process_cells_per_s": chunk / (sum(busy) / len(busy)),
+        "sample": f"SURVEY 8(d): {n_tasks} chunks of {chunk} cells (a {slice_cells}-cell slice of config 2: dense fp32 x "
+                  f"20000 genes, window {window} step {step}) through ProcessPoolExecutor(max_workers={min(physical, n_tasks)} "
+                  f"of {physical} physical cores), oracle chunk kernel (per-row np.convolve as the reference); slowest "
+                  f"chunk {max(busy):.1f} s, mean {sum(busy) / len(busy):.1f} s, pool wall {wall:.1f} s incl. start-up and "
+                  f"building the chunks",
+    }
     rate_l, n_l, busy_l, wall_l = _cpu_pool_rate(logical, window, step, cells_per_worker, reps)
-    out = {
+    out = dict(spec)
+    out["oversubscribed"] = {
         "value": rate_l, "unit": "cells/s", "cores": logical, "kind": "port",
         "per_process_cells_per_s": rate_l / logical,
         "sample": f"{logical} processes (one per logical CPU) x {reps} x {cells_per_worker}-cell chunks ({n_l} cells x "
@@ -164,13 +208,6 @@ def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2):
                   f"pass streams ~0.5 GB through numpy temporaries), so this is the whole-box rate, not cores x the "
                   f"single-core rate",
     }
-    if physical < logical:
-        rate_p, n_p, busy_p, wall_p = _cpu_pool_rate(physical, window, step, cells_per_worker, reps)
-        out["physical_cores"] = {
-            "value": rate_p, "cores": physical, "per_process_cells_per_s": rate_p / physical,
-            "sample": f"{physical} processes (one per physical core), same chunks: {n_p} cells, slowest worker "
-                      f"{busy_p:.1f} s, {wall_p:.1f} s wall",
-        }
     return out
 
 
@@ -350,65 +387,89 @@ def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksiz
     return dt, roof
 
 
-def product_path_step(torch, _engine, plan, dm, n_local, chunksize, steps=5):
-    """The public path's variant of the step (reference :449-455 inside the chunk kernel): thresholds formed, x_res
-    left as it is, keep-mask + per-row counts (k_thr_mask), row offsets, indices / float64 values packed on the
-    device (k_csr_fill_masked).  Per-kernel milliseconds from events on the launch stream."""
-    import ctypes as C
+def api_step(torch, _engine, ad, steps, warmup, fmt, window, step, nnz_row=G, traffic_key=None, **kw):
+    """Time `steps` calls of cnv.tl.infercnv(ad) on the HBM-resident matrix in ad.X; returns (seconds, roofline of the
+    smoothing kernel from the library's own events, X_cnv entry count)."""
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd.tl import _infercnv as T
 
-    from infercnvpy_amd import _lib
+    for _ in range(max(warmup, 1)):
+        cnv.tl.infercnv(ad, window_size=window, step=step, **kw)
+    torch.cuda.synchronize()
+    plan = T._cached_plan(ad.var["chromosome"].to_numpy(), ad.var["start"].to_numpy(), window, step,
+                          kw.get("exclude_chromosomes", ("chrX", "chrY")), torch.cuda.current_device())
+    W, n_local = plan.n_windows, ad.X.shape[0]
+    _engine.profile_begin(plan)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cnv.tl.infercnv(ad, window_size=window, step=step, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    smooth_ms = [r.smooth_ms for r in _engine.profile_collect(plan)]
+    assert len(smooth_ms) == steps, (len(smooth_ms), steps)
+    # SURVEY §8(d): dense 4*G + 4*W = 87 208 B/cell at window 100 / step 10; CSR 8*nnz_row + 8 + 4*W
+    bytes_per_cell = (4 * G + 4 * W) if fmt == "dense" else (8 * nnz_row + 8 + 4 * W)
+    avg = sum(smooth_ms) / len(smooth_ms)
+    achieved = bytes_per_cell * n_local / (avg * 1e-3) / 1e9
+    roof = {
+        "kernel": kernel_label(fmt, window, step), "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": pmc_traffic(traffic_key, n_local) if traffic_key else None,
+        "bytes_per_cell": bytes_per_cell, "kernel_ms": avg, "kernel_ms_min_max": [min(smooth_ms), max(smooth_ms)],
+        "cells_per_launch": n_local,
+    }
+    return dt, roof, ad.obsm["X_cnv"].nnz()
 
-    lib = _lib.load()
+
+def _roof(bytes_, ms, extra=None):
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "bytes_per_launch": bytes_, "kernel_ms": ms}
+    r.update(extra or {})
+    return r
+
+
+def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, iters=10):
+    """The kernels of the public call one by one (engine-level calls as tl.infercnv makes them, events on the launch
+    stream): reference-order means, smoothing + chunk thresholds, threshold + CSR pack; each with its roofline."""
     W = plan.n_windows
-    ref = (_engine.column_sums(dm)[0] / n_local).float()
-    out = _engine.alloc_out(n_local, W)
-    cap = None
-    ms = {"smooth_and_thresholds": [], "k_thr_mask": [], "row_offsets_cumsum": [], "k_csr_fill_masked": []}
+    ms = {"k_colchain": [], "smooth_and_thresholds": [], "threshold_and_csr_pack": []}
     nnz = 0
-    for it in range(steps + 1):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    is_csr = fmt == "csr"
+    for it in range(iters + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        res = _engine.run_hot_path(plan, dm, ref, chunksize=chunksize, out=out, apply=False)
+        acc = _engine.column_chain(dm, None, None, n_local)
+        ref = _engine.chain_mean(acc, n_local, is_csr)
         ev[1].record()
-        part = _engine.threshold_mask(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+        res = _engine.run_hot_path(plan, dm, ref, chunksize=chunksize, apply=False)
         ev[2].record()
-        ip = torch.zeros(n_local + 1, dtype=torch.int64, device="cuda")
-        torch.cumsum(part.counts, 0, out=ip[1:])
+        pk = _engine.threshold_csr(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
         ev[3].record()
-        if cap is None:  # sized once (a host round trip, outside the timed iterations)
-            nnz = int(ip[-1].item())
-            cap = (torch.empty(nnz, dtype=torch.int32, device="cuda"), torch.empty(nnz, dtype=torch.float64, device="cuda"))
-            continue
-        _lib.check(lib.icv_csr_fill_masked(_engine._ptr(part.out), n_local, W, part.out.stride(0), _engine._ptr(part.mask),
-                                           _engine._ptr(ip), _engine._ptr(cap[0]), _engine._ptr(cap[1]),
-                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ev[4].record()
         torch.cuda.synchronize()
-        for k, (a, b) in zip(ms, ((0, 1), (1, 2), (2, 3), (3, 4))):
+        if it == 0:
+            nnz = pk.nnz()
+            continue
+        for k, (a, b) in zip(ms, ((0, 1), (1, 2), (2, 3))):
             ms[k].append(ev[a].elapsed_time(ev[b]))
+        del res, pk
     avg = {k: sum(v) / len(v) for k, v in ms.items()}
-    total = sum(avg.values())
-    n_words = (W + 63) // 64
-    mask_bytes = (4 * W + 8 * n_words + 8) * n_local
-    fill_bytes = (4 * W + 8 * n_words + 8) * n_local + 12 * nnz
+    in_bytes = (4 * G if not is_csr else 8 * nnz_row + 8) * n_local
     return {
-        "workload": f"dense fp32 {n_local} x {G}, window 100: icv_infercnv_run(NO_APPLY) + icv_threshold_mask + "
-                    f"row offsets + icv_csr_fill_masked (X_cnv as CSR float64 in HBM; reference _infercnv.py:449-455)",
-        "ms_per_step": total, "cells_per_s": n_local / (total * 1e-3), "kernel_ms": avg, "x_cnv_nnz": nnz,
-        "roofline_k_thr_mask": {"bound": "hbm", "achieved": mask_bytes / (avg["k_thr_mask"] * 1e-3) / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": mask_bytes / (avg["k_thr_mask"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "bytes_per_launch": mask_bytes},
-        "roofline_k_csr_fill_masked": {"bound": "hbm", "achieved": fill_bytes / (avg["k_csr_fill_masked"] * 1e-3) / 1e9,
-                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": fill_bytes / (avg["k_csr_fill_masked"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       "bytes_per_launch": fill_bytes},
-        "note": "reference-mean pass excluded (shown in the main line); k_thr_mask reads x_res once, "
-                "k_csr_fill_masked reads it once more and writes 12 B per kept entry",
+        "kernel_ms": avg, "sum_ms": sum(avg.values()), "x_cnv_nnz": nnz,
+        "roofline_k_colchain": _roof(in_bytes, avg["k_colchain"], {
+            "note": "one pass over the matrix; CSR: + k_csr_tile_bounds (column indices once more, 4 B per tile and row)"}),
+        "roofline_threshold_and_csr_pack": _roof((4 * W + 8) * n_local + 12 * nnz, avg["threshold_and_csr_pack"], {
+            "kernels": "k_thr_mask + k_row_offsets + k_csr_fill_masked",
+            "note": "algorithmic bytes: x_res once (4 W per cell) + 12 B per kept entry + 8 B row offset; the two "
+                    "kernels read x_res twice (the second time partly from the Infinity Cache)"}),
     }
 
 
-def config5_leg(torch, _engine, n=100_000, d=5000, clusters=30):
+def config5_leg(torch, _engine, n=None, d=5000, clusters=30):
+    if n is None:  # BASELINE config 5 is 200 000 x 5 000: 240 GB of distances with the Ward rounds' spare columns
+        free_b, _ = torch.cuda.mem_get_info()
+        n = 200_000 if free_b >= 250e9 else 100_000
     gen = torch.Generator(device="cuda").manual_seed(n)
     centres = torch.randn((clusters, d), device="cuda", generator=gen) * 0.3
     lab = torch.randint(0, clusters, (n,), device="cuda", generator=gen)
@@ -416,28 +477,44 @@ def config5_leg(torch, _engine, n=100_000, d=5000, clusters=30):
     _engine.pairwise_sqeuclidean(x[:256].contiguous())  # warm-up
     d2 = torch.empty((n, (n + (n + 1) // 2 + 3) // 4 * 4), dtype=torch.float32, device="cuda")[:, :n]
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     _engine.pairwise_sqeuclidean(x, out=d2)
+    e1.record()
     torch.cuda.synchronize()
     t_pd = time.perf_counter() - t0
+    t_ev = e0.elapsed_time(e1) * 1e-3  # on the stream: centring (3 small kernels) + k_gram_mfma, no allocation waits
     t0 = time.perf_counter()
     _, rounds = _engine.ward_linkage(d2, spare=True)
     t_w = time.perf_counter() - t0
-    tf = 1.0 * n * (n + 128) * d / t_pd / 1e12  # executed flops: tiles on / above the diagonal only
+    tf = 1.0 * n * (n + 128) * d / t_ev / 1e12  # executed flops: tiles on / above the diagonal only
     del d2, x
     torch.cuda.empty_cache()
     return {
-        "workload": f"BASELINE config 5 on one GPU at half size: X_cnv-like {n} x {d} fp32 -> squared Euclidean "
-                    f"distances (fp32 MFMA, upper-triangle tiles + mirrored copy) + Ward linkage",
-        "pdist_s": t_pd, "ward_s": t_w, "ward_rounds": rounds,
-        "roofline": {"kernel": "k_gram_mfma<DIST,SYM> (incl. centring, norms, allocation of its temporaries)",
+        "workload": f"BASELINE config 5 on one GPU{' at half size' if n < 200_000 else ' at full size'}: X_cnv-like "
+                    f"{n} x {d} fp32 -> squared Euclidean distances (fp32 MFMA, upper-triangle tiles + mirrored copy) "
+                    f"+ Ward linkage",
+        "pdist_s": t_pd, "pdist_stream_s": t_ev, "ward_s": t_w, "ward_rounds": rounds,
+        "roofline": {"kernel": "k_gram_mfma<DIST,SYM> (stream time of the call: + the three centring / norm kernels, "
+                               "< 1 %; the per-kernel split is profiles/r04_config5_rocprofv3_kernel_stats.csv)",
                      "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None},
     }
 
 
-def extra_legs(torch, icd, _engine, GenePlan, cases, which):
+def _var_frame(cases):
+    import pandas as pd
+
     v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    return v, pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+
+
+def extra_legs(torch, icd, _engine, GenePlan, cases, which):
+    from infercnvpy_amd._compat import SimpleAnnData
+    from infercnvpy_amd.tl import _infercnv as T
+
+    v, var = _var_frame(cases)
     extra = {}
 
     def leg(name, fn):
@@ -451,47 +528,51 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
             extra[name] = {"error": repr(e)}
         torch.cuda.empty_cache()
 
+    def api_leg(ad, cells, fmt, window, label, steps, traffic_key, nnz_row=G):
+        dt, roof, nnz = api_step(torch, _engine, ad, steps, 2, fmt, window, 10, nnz_row=nnz_row, traffic_key=traffic_key)
+        plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), window, 10, ("chrX", "chrY"),
+                              torch.cuda.current_device())
+        dm = T._resident_matrix(ad.X, torch)
+        st = stage_times(torch, _engine, plan, dm, cells, CHUNK, fmt, nnz_row=nnz_row, iters=3)
+        return {"workload": label + "; one cnv.tl.infercnv(adata) call per step on the resident matrix, "
+                                    "reference = all-cell mean (in the step), X_cnv as device CSR",
+                "ms_per_step": dt / steps * 1e3, "cells_per_s": cells / (dt / steps), "steps": steps,
+                "nnz_per_cell": nnz_row, "x_cnv_nnz": nnz, "roofline": roof, "stages": st}
+
     def csr_leg(cells, window, label, traffic_key):
         ip, ix, dv = synth_csr_on_device(torch, cells, G, 0.07, seed=3)
         dm = _engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(cells, G))
-        plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
-        nnz_row = dv.numel() / cells
-        dt, roof = hbm_step(torch, icd, _engine, plan, dm, cells, "csr", window, 10, CHUNK, steps=5, warmup=2,
-                            nnz_row=nnz_row, traffic_key=traffic_key)
-        plan.close()
-        return {"workload": label, "ms_per_step": dt / 5 * 1e3, "cells_per_s": cells / (dt / 5), "steps": 5,
-                "nnz_per_cell": nnz_row, "roofline": roof}
+        return api_leg(SimpleAnnData(dm, var=var), cells, "csr", window, label, 5, traffic_key, dv.numel() / cells)
 
     leg("config4_csr_w250", lambda: csr_leg(
-        500_000, 250, "BASELINE config 4: CSR fp32 500000 x 20000, density 0.07, window 250, step 10, HBM resident, "
-                      "reference = all-cell mean (in the step)", "csr_w250"))
+        500_000, 250, "BASELINE config 4: CSR fp32 500000 x 20000, density 0.07, window 250, step 10, HBM resident",
+        "csr_w250"))
     leg("csr_w100", lambda: csr_leg(
         200_000, 100, "CSR fp32 200000 x 20000, density 0.07, window 100 (default arguments on 10x-style input), "
-                      "HBM resident, reference mean in the step", "csr_w100"))
+                      "HBM resident", "csr_w100"))
 
     def one_million():
         X = synth_rows(torch, 0, CONFIG3_CELLS, G)
-        dm = _engine.DeviceMatrix(dense=X)
-        plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
-        dt, roof = hbm_step(torch, icd, _engine, plan, dm, CONFIG3_CELLS, "dense", 100, 10, CHUNK, steps=3, warmup=1,
-                            traffic_key="dense_w100")
-        plan.close()
-        return {"workload": "BASELINE config 3's matrix on ONE GPU: dense fp32 1000000 x 20000 (80 GB resident), "
-                            "window 100 (the size north_star quotes its targets on)",
-                "ms_per_step": dt / 3 * 1e3, "cells_per_s": CONFIG3_CELLS / (dt / 3), "steps": 3, "roofline": roof}
+        return api_leg(SimpleAnnData(X, var=var), CONFIG3_CELLS, "dense", 100,
+                       "BASELINE config 3's matrix on ONE GPU: dense fp32 1000000 x 20000 (80 GB resident), window 100 "
+                       "(the size north_star quotes its targets on)", 3, "dense_w100")
 
     leg("config3_cells_on_one_gpu", one_million)
 
-    def product():
+    def in_place():
         X = synth_rows(torch, 0, CONFIG2_CELLS, G)
         dm = _engine.DeviceMatrix(dense=X)
         plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
-        r = product_path_step(torch, _engine, plan, dm, CONFIG2_CELLS, CHUNK)
+        dt, roof = hbm_step(torch, icd, _engine, plan, dm, CONFIG2_CELLS, "dense", 100, 10, CHUNK, steps=50, warmup=3,
+                            traffic_key="dense_w100")
         plan.close()
-        return r
+        return {"workload": "the round-3 form of the config-2 step (engine-level calls, not the public function): "
+                            "float64 column sums (correctly rounded mean, NOT the reference's own float32 order) + "
+                            "smoothing + chunk thresholds + IN-PLACE threshold of the dense x_res, no CSR",
+                "ms_per_step": dt / 50 * 1e3, "cells_per_s": CONFIG2_CELLS / (dt / 50), "steps": 50, "roofline": roof}
 
-    leg("product_path_csr_pack", product)
-    leg("config5_100k", lambda: config5_leg(torch, _engine))
+    leg("in_place_threshold_step", in_place)
+    leg("config5", lambda: config5_leg(torch, _engine))
     return extra
 
 
@@ -522,6 +603,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--extra", default="", help="comma-separated subset of the extra legs (default: all)")
     ap.add_argument("--no-refmean", action="store_true", help="exclude the reference-mean pass from the step")
+    ap.add_argument("--engine-step", action="store_true",
+                    help="N = 1: time the engine-level step of N > 1 (float64 sums + in-place threshold) instead of "
+                         "the public call")
     ap.add_argument("--dry-run-one-gpu", action="store_true",
                     help="NOT a measurement: all ranks on cuda:0, collectives through gloo (prints \"dry_run\": true)")
     args = ap.parse_args()
@@ -601,9 +685,28 @@ def main():
     elif args.format == "csr" and args.step == 10 and args.window in (100, 250) and abs(args.density - 0.07) < 1e-9:
         traffic_key = f"csr_w{args.window}"
 
-    dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
-                        args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
-                        no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key)
+    stages = None
+    if n_gpus == 1 and not args.engine_step:
+        # the headline: ONE call of the public function per step on the resident matrix (reference=None: the default)
+        from infercnvpy_amd._compat import SimpleAnnData
+        from infercnvpy_amd.tl import _infercnv as T
+
+        _, var = _var_frame(cases)
+        ad = SimpleAnnData(X if args.format == "dense" else dm, var=var)
+        kw = dict(chunksize=args.chunksize)
+        if args.no_refmean:
+            kw["reference"] = (_engine.column_sums(dm)[0] / n_local).float().cpu().numpy()
+        dt, roof, nnz_out = api_step(torch, _engine, ad, args.steps, args.warmup, args.format, args.window, args.step,
+                                     nnz_row=nnz_row, traffic_key=traffic_key, **kw)
+        api_plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), args.window, args.step,
+                                  ("chrX", "chrY"), torch.cuda.current_device())
+        stages = stage_times(torch, _engine, api_plan, dm, n_local, args.chunksize, args.format, nnz_row=nnz_row)
+        stages["x_cnv_nnz_public_call"] = nnz_out
+        ad = None
+    else:
+        dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
+                            args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
+                            no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -631,7 +734,7 @@ def main():
         name = ("custom (not a BASELINE configuration): " +
                 ("dense fp32" if args.format == "dense" else f"CSR fp32 density {args.density}"))
     result = {
-        "metric": f"cells/sec through the tl.infercnv hot path (window={args.window}), input resident in HBM",
+        "metric": f"cells/sec through tl.infercnv (window={args.window}), input resident in HBM",
         "value": value,
         "unit": "cells/s",
         "n_gpus": n_gpus,
@@ -650,7 +753,11 @@ def main():
             "workload": f"{name} {n_total} cells x {G} genes (chr1..22, random var order), "
                         f"window {args.window}, step {args.step}, chunksize {args.chunksize}, lfc_clip 3, "
                         f"dynamic_threshold 1.5, reference = all-cell mean"
-                        + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)"),
+                        + (" (precomputed, excluded from the step)" if args.no_refmean else " (in the step)")
+                        + ("; step = one cnv.tl.infercnv(adata) call, adata.X a CUDA tensor, X_cnv returned as device "
+                           "CSR float64 (reference-order means, smoothing, noise threshold + CSR pack)"
+                           if stages is not None else
+                           "; step = float64 column sums (+ all-reduce) + smoothing + in-place threshold (dist.run_shard)"),
             "io_dtype": "f32 matrix in, f32 x_res out",
             "cells_total": n_total,
             "cells_per_gpu": [b - a for a, b in bounds],
@@ -660,11 +767,13 @@ def main():
             "parallelism": f"{n_gpus} rank(s) (torch.distributed world size "
                            f"{dist.get_world_size() if dist is not None else 1}, backend "
                            f"{('gloo, ALL RANKS ON cuda:0 (dry run)' if dry else 'nccl/RCCL') if dist is not None else 'none'}), "
-                           f"row shards aligned to the chunks, one all-reduce of the [G+1] float64 reference sums per "
-                           f"step, no other collective",
+                           + ("row shards aligned to the chunks, one all-reduce of the [G+1] float64 reference sums per "
+                              "step, no other collective" if n_gpus > 1 else "one GPU, no collective"),
         },
         "roofline": roof,
     }
+    if stages is not None:
+        result["stages"] = stages
     if dry:
         result["dry_run"] = True
         result["dry_run_note"] = ("all ranks share ONE GPU and the collectives go through gloo and the host: code-path "

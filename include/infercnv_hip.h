@@ -252,14 +252,16 @@ int icv_threshold_mask(icv_plan_t plan, const icv_matrix *m, const void *ref_lo,
                        int64_t *row_nnz, void *stream);
 int icv_csr_fill_masked(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const uint64_t *mask,
                         const int64_t *indptr, int32_t *indices, double *data, void *stream);
+/* the prefix sum between the two: indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r] (device arrays) */
+int icv_row_offsets(const int64_t *row_nnz, int64_t n_rows, int64_t *indptr, void *stream);
 
 /* Step 5b and the packing in ONE pass (what the public path and bench.py's headline run): the decision of
- * icv_threshold_mask, the rows' offsets from a decoupled look-back over the rows (no mask array, no prefix-sum call,
+ * icv_threshold_mask, the rows' offsets from a two-level decoupled look-back over the rows (no mask array, no prefix-sum call,
  * no second kernel) and the kept entries written from the row: x_res is read from HBM once.  `indptr` n_rows + 1
  * offsets starting at 0; `indices` / `data` hold `capacity` entries (n_rows * n_windows can never overflow; entries
  * past the capacity are dropped, indptr[n_rows] still tells how many there are).  Deterministic: the output does not
  * depend on the order in which the rows finish.  At most 20 480 windows (ICV_ERR_UNSUPPORTED beyond: use the
- * two-step form).  Needs 8 * (n_rows + 1) bytes of temporary device memory (stream-ordered). */
+ * two-step form).  Needs less than n_rows bytes of temporary device memory (stream-ordered). */
 int icv_threshold_pack(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi, double lfc_clip,
                        int32_t flags, const float *out, int64_t ldo, const double *cell_median, const double *thr,
                        int64_t chunksize, int64_t row_phase, int64_t *indptr, int32_t *indices, double *data,

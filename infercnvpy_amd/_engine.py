@@ -388,6 +388,10 @@ class PackedCsr:
     def n_rows(self):
         return self.indptr.shape[0] - 1
 
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_cols)
+
     def nnz(self):
         """Number of stored entries (reads one value back: synchronises the current stream)."""
         return int(self.indptr[-1].item())
@@ -400,11 +404,40 @@ class PackedCsr:
                              shape=(self.n_rows, self.n_cols))
 
 
+def threshold_csr(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_clip, chunksize, row_phase=0,
+                  flags=0, row0=0, row1=None, capacity=None, single_pass=False):
+    """Step 5b + ``csr_matrix(x_res)`` (reference :449-455) on the device without a host round trip: the un-thresholded
+    ``res.out`` of :func:`run_hot_path` (``apply=False``) -> :class:`PackedCsr`.  ``capacity`` (entries) defaults to the
+    worst case rows x windows; nothing is read back, the call is asynchronous.
+
+    Default: keep-mask + row counts (``icv_threshold_mask``, rows in reverse: the tail of x_res is still in the Infinity
+    Cache), ``icv_row_offsets``, ``icv_csr_fill_masked`` -- 0.5 ms per 100 000 cells.  ``single_pass=True``:
+    ``icv_threshold_pack`` (one kernel with a decoupled look-back; 0.7 ms: its scattered 4- / 8-byte stores and the
+    16-row tickets cost more than the second read of x_res they save -- profiles/r04_pack_experiments.txt)."""
+    torch = _torch()
+    lib = _lib.load()
+    rows = res.out.shape[0]
+    W = plan.n_windows
+    if single_pass and W <= 20480:
+        return threshold_pack(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                              row_phase=row_phase, flags=flags, row0=row0, row1=row1, capacity=capacity)
+    part = threshold_mask(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize, row_phase=row_phase,
+                          flags=flags, row0=row0, row1=row1)
+    cap = rows * W if capacity is None else int(capacity)
+    indptr = torch.empty(rows + 1, dtype=torch.int64, device="cuda")
+    indices = torch.empty(max(cap, 1), dtype=torch.int32, device="cuda")
+    data = torch.empty(max(cap, 1), dtype=torch.float64, device="cuda")
+    st = _stream_ptr(torch)
+    _lib.check(lib.icv_row_offsets(_ptr(part.counts), rows, _ptr(indptr), st))
+    if rows:
+        _lib.check(lib.icv_csr_fill_masked(_ptr(part.out), rows, W, part.out.stride(0), _ptr(part.mask), _ptr(indptr),
+                                           _ptr(indices), _ptr(data), st))
+    return PackedCsr(indptr, indices, data, W, res.thr)
+
+
 def threshold_pack(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_clip, chunksize, row_phase=0,
                    flags=0, row0=0, row1=None, capacity=None):
-    """Step 5b + ``csr_matrix(x_res)`` in one pass (``icv_threshold_pack``): the un-thresholded ``res.out`` of
-    :func:`run_hot_path` (``apply=False``) -> :class:`PackedCsr` on the device.  ``capacity`` (entries) defaults to the
-    worst case rows x windows; nothing is read back, the call is asynchronous."""
+    """The single-pass form (``icv_threshold_pack``, at most 20 480 windows): see :func:`threshold_csr`."""
     torch = _torch()
     lib = _lib.load()
     rows = res.out.shape[0]
@@ -419,6 +452,38 @@ def threshold_pack(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc
         res.out.stride(0), _ptr(res.cell_median), _ptr(res.thr), int(chunksize), int(row_phase), _ptr(indptr),
         _ptr(indices), _ptr(data), cap, _stream_ptr(torch)))
     return PackedCsr(indptr, indices, data, W, res.thr)
+
+
+def fill_from_mask(part, n_cols):
+    """Two-step packing of a :class:`PackedRows` keep-mask (window lists too long for ``icv_threshold_pack``):
+    prefix sum, read-back of the count, ``icv_csr_fill_masked`` -> :class:`PackedCsr`."""
+    torch = _torch()
+    lib = _lib.load()
+    n = part.counts.shape[0]
+    ip = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(part.counts, 0, out=ip[1:])
+    nnz = int(ip[-1].item())
+    idx = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
+    dat = torch.empty(max(nnz, 1), dtype=torch.float64, device="cuda")
+    if nnz:
+        _lib.check(lib.icv_csr_fill_masked(_ptr(part.out), n, n_cols, part.out.stride(0), _ptr(part.mask), _ptr(ip),
+                                           _ptr(idx), _ptr(dat), _stream_ptr(torch)))
+    return PackedCsr(ip, idx, dat, n_cols, part.thr)
+
+
+def concat_packed(parts):
+    """Row-wise concatenation of device CSR pieces (reads each piece's entry count back)."""
+    torch = _torch()
+    ips, idx, dat, thr, off = [parts[0].indptr[:1]], [], [], [], 0
+    for p in parts:
+        n = p.nnz()
+        ips.append(p.indptr[1:] + off)
+        idx.append(p.indices[:n])
+        dat.append(p.data[:n])
+        if p.thr is not None:
+            thr.append(p.thr)
+        off += n
+    return PackedCsr(torch.cat(ips), torch.cat(idx), torch.cat(dat), parts[0].n_cols, torch.cat(thr) if thr else None)
 
 
 _PAGE = 4096

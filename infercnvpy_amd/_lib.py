@@ -29,7 +29,7 @@ EXPORTS = (
     "icv_plan_last_kernel", "icv_plan_se_tables",
     "icv_colsum", "icv_colchain", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
-    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_threshold_pack", "icv_corr_iqr",
+    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_threshold_pack", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
     "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_gather", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
     "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_last_error", "icv_version",
@@ -106,6 +106,7 @@ def load():
     lib.icv_csr_fill.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp]
     lib.icv_threshold_mask.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp, vp, vp]
     lib.icv_threshold_pack.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp, vp, vp, i64, vp]
+    lib.icv_row_offsets.argtypes = [vp, i64, vp, vp]
     lib.icv_csr_fill_masked.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, vp]
     lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]

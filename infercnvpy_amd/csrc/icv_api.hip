@@ -140,7 +140,24 @@ struct AsyncBuf {
     }
     hipError_t alloc(size_t bytes, hipStream_t s) {
         st = s;
+        keep_pool();
         return hipMallocAsync(&p, bytes ? bytes : 16, s);
+    }
+    // The device's default memory pool gives everything back to the driver whenever the stream is synchronised (release
+    // threshold 0), and the next temporary is a real allocation again: milliseconds of an idle GPU in front of a
+    // 0.2 ms kernel for every caller that synchronises between calls.  Keep up to 2 GB of temporaries pooled (once
+    // per device and process).
+    static void keep_pool() {
+        static std::atomic<unsigned long long> done{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return;
+        const unsigned long long bit = 1ull << dev;
+        if (done.fetch_or(bit) & bit) return;
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = 2ull << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
     }
     template <typename T>
     T* as() const { return static_cast<T*>(p); }
@@ -1374,6 +1391,10 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
         (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize)))
         return fail(ICV_ERR_INVALID, "bad threshold_pack arguments");
     if (pl->p.W > 320 * 64) return fail(ICV_ERR_UNSUPPORTED, "icv_threshold_pack: more than 20480 windows");
+    // rows per workgroup (= per look-back ticket): as many as keep their mask words in the workgroup's LDS, at most 16
+    const int n_words = (pl->p.W + 63) / 64;
+    int rpw = icv::kPackWords / n_words;
+    rpw = rpw < 1 ? 1 : (rpw > icv::kPackMaxRows ? icv::kPackMaxRows : rpw);
     if ((rc = ensure_device(pl))) return rc;
     PLAN_ENTER(stream);
     icv::KParams K;
@@ -1387,16 +1408,20 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
         return ICV_OK;
     }
     if (K.n_rows > 0xffffffffll) return fail(ICV_ERR_UNSUPPORTED, "icv_threshold_pack: more than 2^32 rows per call");
-    // look-back workspace: one status word per row + the ticket counter, zeroed in stream order
+    // look-back workspace: one status word per ticket, two per group of 64 tickets, the ticket counter; zeroed in
+    // stream order
+    const int64_t n_tickets = (K.n_rows + rpw - 1) / rpw, n_groups = (n_tickets + 63) / 64;
     AsyncBuf ws;
-    HIP_TRY(ws.alloc((size_t)(K.n_rows + 1) * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(ws.p, 0, (size_t)(K.n_rows + 1) * sizeof(unsigned long long), st));
+    HIP_TRY(ws.alloc((size_t)(n_tickets + 2 * n_groups + 1) * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ws.p, 0, (size_t)(n_tickets + 2 * n_groups + 1) * sizeof(unsigned long long), st));
     auto* status = ws.as<unsigned long long>();
-    auto* ticket = reinterpret_cast<unsigned int*>(status + K.n_rows);
+    auto* gstat = status + n_tickets;
+    auto* gacc = gstat + n_groups;
+    auto* ticket = reinterpret_cast<unsigned int*>(gacc + n_groups);
     const int64_t cs = thr ? chunksize : 1;
-    dim3 grid((unsigned)K.n_rows), block(256);
+    dim3 grid((unsigned)n_tickets), block(256);
 #define ICV_PACK(TT, CC) \
-    hipLaunchKernelGGL((icv::k_thr_pack<TT, CC>), grid, block, 0, st, K, thr, cs, row_phase, ticket, status, indptr, indices, data, capacity)
+    hipLaunchKernelGGL((icv::k_thr_pack<TT, CC>), grid, block, 0, st, K, thr, cs, row_phase, rpw, ticket, status, gstat, gacc, indptr, indices, data, capacity)
     if (m->dtype == ICV_F32) {
         if (m->format == ICV_DENSE) ICV_PACK(float, false);
         else ICV_PACK(float, true);
@@ -1405,6 +1430,14 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
         else ICV_PACK(double, true);
     }
 #undef ICV_PACK
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_row_offsets(const int64_t* row_nnz, int64_t n_rows, int64_t* indptr, void* stream) {
+    if (!row_nnz || !indptr || n_rows < 0) return fail(ICV_ERR_INVALID, "bad row_offsets arguments");
+    hipLaunchKernelGGL(icv::k_row_offsets, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), row_nnz, n_rows,
+                       indptr);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

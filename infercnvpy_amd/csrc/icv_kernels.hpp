@@ -883,7 +883,9 @@ __global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double*
     __shared__ int tie_n, cnt[4];
     __shared__ int tie_j[32];
     __shared__ double vals[kTieBuf];
-    const int64_t cell = blockIdx.x;
+    // last rows first: the smoothing kernel has just written x_res, its tail is still in the Infinity Cache (and this
+    // pass leaves the HEAD there for k_csr_fill_masked, which walks forward)
+    const int64_t cell = (int64_t)gridDim.x - 1 - blockIdx.x;
     const bool has_thr = thr != nullptr;
     const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
     const float thf = (float)th;
@@ -957,146 +959,212 @@ __global__ void __launch_bounds__(256) k_thr_mask(const KParams P, const double*
     if (threadIdx.x == 0) row_nnz[cell] = (int64_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3] - dropped);
 }
 
-// Step 5b + `csr_matrix(x_res)` (reference :449-455) in ONE pass over x_res: the decision of k_thr_mask, the row's kept
-// count, the row's offset in the packed output from a decoupled look-back over the rows before it, and the entries
-// (int32 column, float64 value) written straight from the row -- x_res is read from HBM once (the packing re-reads the
-// row from L2, 7 KB a row), no mask array, no separate scan, no second kernel.
-//   status[r]: 64-bit word per row {2-bit flag, 62-bit value}: 1 = the row's own count, 2 = the inclusive prefix of rows
-//   0..r (one relaxed agent-scope 8-byte store: value and flag cannot tear); rows are taken in the order of a ticket
-//   counter, so every predecessor of a waiting row is running or done.  `ticket` and `status` are zeroed by the caller.
-//   indptr[0 .. n_rows] (relative to `nnz0`, the entries of earlier pieces), indices / data of capacity `cap` entries:
-//   an entry beyond `cap` is dropped (the caller sizes for the worst case or checks indptr[n_rows]).
+// Step 5b + `csr_matrix(x_res)` (reference :449-455) in ONE pass over x_res: the decision of k_thr_mask, the rows' kept
+// counts, their offsets in the packed output from a decoupled look-back, and the entries (int32 column, float64 value)
+// written straight from the rows -- x_res is read from HBM once (the packing re-reads the workgroup's rows from L2),
+// no mask array in HBM, no separate scan, no second kernel.
+//   A workgroup takes `rpw` consecutive rows per ticket (ticket counter: every predecessor of a waiting workgroup is
+//   running or done).  status[t]: 64-bit word per ticket {2-bit flag, 62-bit value}: 1 = the ticket's own
+//   count, 2 = the inclusive prefix of tickets 0..t (one relaxed agent-scope 8-byte store: value and flag cannot tear).
+//   The look-back examines 64 predecessors per step and waits only for those nearer than the nearest known prefix; a
+//   step covers 64 x rpw rows.  `ticket` and `status` are zeroed by the caller.
+//   indptr[0 .. n_rows] from 0; indices / data of capacity `cap` entries: an entry beyond `cap` is dropped (the caller
+//   sizes for the worst case or checks indptr[n_rows]).  The output does not depend on the order of completion.
 constexpr unsigned long long kPackAgg = 1ull << 62, kPackPfx = 2ull << 62, kPackVal = (1ull << 62) - 1;
+constexpr int kPackWords = 1024;  // mask words per workgroup in LDS: rpw * ceil(W / 64) <= 1024
+constexpr int kPackMaxRows = 16;
+
+// 64-bit add across the lanes of a wavefront (every lane gets the total)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// Wavefront 0 of a pack workgroup: offsets of the mask words inside their rows, the rows' bases (row_base[0..n_here]) and
+// the ticket's offset in the packed output from a TWO-LEVEL decoupled look-back.  Tickets form groups of 64:
+//   status[t]  = kPackAgg | count of ticket t              (read by the later tickets of the same group)
+//   gacc[g]   += (1 << 56) + count, one atomic per ticket: the ticket that completes the group publishes
+//   gstat[g]   = kPackAgg | count of group g, later kPackPfx | entries of groups 0..g (by the group's last ticket)
+// so a ticket needs ONE load for its own group and one per 64 groups (4096 tickets) behind it, however many workgroups
+// are in flight (a flat look-back walked ~28 windows of 64 tickets at 1800 resident workgroups: a third of the kernel).
+__device__ __forceinline__ void pack_lookback(int lane, int64_t tk, int64_t n_tickets, int n_here, int n_words,
+                                              const unsigned long long* mwords, int* woff, long long* row_base,
+                                              unsigned long long* status, unsigned long long* gstat,
+                                              unsigned long long* gacc, int64_t* indptr) {
+    long long run_rows = 0;
+    for (int rr = 0; rr < n_here; ++rr) {
+        int run = 0;
+        for (int w0 = 0; w0 < n_words; w0 += 64) {
+            const int cnt = w0 + lane < n_words ? __popcll(mwords[rr * n_words + w0 + lane]) : 0;
+            const int incl = wave_scan_dpp(cnt);
+            if (w0 + lane < n_words) woff[rr * n_words + w0 + lane] = run + incl - cnt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) row_base[rr] = run_rows;
+        run_rows += run;
+    }
+    const unsigned long long mine = (unsigned long long)run_rows;
+    unsigned long long excl = 0;
+#if !(defined(ICV_DEV_EXPERIMENTS) && defined(ICV_PACK_EXP_NOLOOKBACK))  // (experiment: wrong offsets on purpose)
+    const int64_t g = tk >> 6;
+    const int i = (int)(tk & 63);
+    const int in_group = (int)((n_tickets - g * 64) < 64 ? (n_tickets - g * 64) : 64);
+    if (lane == 0) {
+        __hip_atomic_store(status + tk, kPackAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long old =
+            __hip_atomic_fetch_add(gacc + g, (1ull << 56) + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(old >> 56) + 1 == in_group && i != in_group - 1)  // (the group's last ticket publishes the prefix itself)
+            __hip_atomic_store(gstat + g, kPackAgg | ((old & ((1ull << 56) - 1)) + mine), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // own group: the counts of the tickets before this one
+    unsigned long long sv = kPackAgg;
+    while (true) {
+        if (lane < i) sv = __hip_atomic_load(status + g * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_ballot_w64((sv >> 62) == 0) == 0) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    excl = wave_sum_u64(lane < i ? (sv & kPackVal) : 0ull);
+    // the groups before: 64 per step, up to and including the nearest one whose prefix is known
+    int64_t hi = g - 1;
+    while (hi >= 0) {
+        const int64_t r = hi - lane;
+        unsigned long long gv, pfx;
+        int first;
+        while (true) {
+            gv = r >= 0 ? __hip_atomic_load(gstat + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPackPfx;
+            pfx = __builtin_amdgcn_ballot_w64((gv >> 62) == 2);
+            first = pfx ? __builtin_ctzll(pfx) : 64;
+            if (__builtin_amdgcn_ballot_w64(lane < first && (gv >> 62) == 0) == 0) break;
+            __builtin_amdgcn_s_sleep(8);  // pollers cost the streaming workgroups bandwidth: back off
+        }
+        excl += wave_sum_u64(lane <= first ? (gv & kPackVal) : 0ull);
+        if (pfx) break;
+        hi -= 64;
+    }
+    if (lane == 0 && i == in_group - 1)
+        __hip_atomic_store(gstat + g, kPackPfx | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    if (lane == 0) {
+        row_base[n_here] = run_rows;
+        if (tk == 0) indptr[0] = 0;
+    }
+    if (lane <= n_here) row_base[lane] += (long long)excl;  // (lane 0's writes above: same wavefront, in order)
+}
+
+// (Measured and dropped, profiles/r04_pack_experiments.txt: the 16 rows kept in registers between the decision and the
+// packing -- 211 VGPRs, two workgroups per CU; one wavefront per row with 16-byte loads and four ballots per 256
+// windows -- 140 VGPRs; non-temporal loads of x_res, which push the packing's second read out of L2.)
 template <typename T, bool CSR>
 __global__ void __launch_bounds__(256) k_thr_pack(const KParams P, const double* thr, int64_t chunksize,
-                                                  int64_t row_phase, unsigned int* ticket, unsigned long long* status,
-                                                  int64_t* indptr, int32_t* indices, double* data, int64_t cap) {
-    constexpr int kMaxWords = 320;  // 20 480 windows
-    __shared__ int tie_n, cell_s;
-    __shared__ int tie_j[32];
-    __shared__ double vals[kTieBuf];
-    __shared__ unsigned long long mwords[kMaxWords];
-    __shared__ int woff[kMaxWords];
-    __shared__ long long base_s;
-    if (threadIdx.x == 0) {
-        cell_s = (int)atomicAdd(ticket, 1u);
-        tie_n = 0;
-    }
+                                                  int64_t row_phase, int rpw, unsigned int* ticket,
+                                                  unsigned long long* status, unsigned long long* gstat,
+                                                  unsigned long long* gacc, int64_t* indptr, int32_t* indices,
+                                                  double* data, int64_t cap) {
+    __shared__ int ticket_s;
+    __shared__ unsigned long long mwords[kPackWords], twords[kPackWords];
+    __shared__ int woff[kPackWords];
+    __shared__ long long row_base[kPackMaxRows + 1];
+    if (threadIdx.x == 0) ticket_s = (int)atomicAdd(ticket, 1u);
     __syncthreads();
-    const int64_t cell = cell_s;
+    const int64_t tk = ticket_s;
+    const int64_t cell0 = tk * rpw;
+    const int n_here = (int)((P.n_rows - cell0) < rpw ? (P.n_rows - cell0) : rpw);
     const bool has_thr = thr != nullptr;
-    const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
-    const float thf = (float)th;
-    const float* orow = P.out + cell * P.ldo;
     const int n_words = (P.W + 63) >> 6;
-    for (int j0 = 0; j0 < P.W; j0 += 4 * 256) {
-        float yv[4];
+    // ---- decide: float32 decides; a value within one ulp of the threshold is kept for now and flagged in a second mask
+    // (twords) for the exact float64 recomputation after the pass: the streaming body is a compare and two ballots.
+    // The first eight windows per thread of the NEXT row are requested before the current row is decided.
+    float nxt[8];
+    const auto request = [&](int rr) {
+        const float* orow = P.out + (cell0 + (rr < n_here ? rr : 0)) * P.ldo;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * 256 + (int)threadIdx.x;
-            yv[u] = j < P.W ? __builtin_nontemporal_load(orow + j) : 0.0f;
+        for (int u = 0; u < 8; ++u) {
+            const int j = u * 256 + (int)threadIdx.x;
+            nxt[u] = (rr < n_here && j < P.W) ? orow[j] : 0.0f;
         }
+    };
+    request(0);
+    for (int rr = 0; rr < n_here; ++rr) {
+        const int64_t cell = cell0 + rr;
+        const float thf = has_thr ? (float)thr[(cell + row_phase) / chunksize] : 0.0f;
+        const float* orow = P.out + cell * P.ldo;
+        for (int j0 = 0; j0 < P.W; j0 += 8 * 256) {
+            float yv[8];
+            if (j0 == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u * 256 + (int)threadIdx.x;
-            bool keep = false;
-            if (j < P.W) {
+                for (int u = 0; u < 8; ++u) yv[u] = nxt[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u * 256 + (int)threadIdx.x;
+                    yv[u] = j < P.W ? orow[j] : 0.0f;
+                }
+            }
+            if (j0 + 8 * 256 >= P.W) request(rr + 1);  // (in flight while this batch is decided)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * 256 + (int)threadIdx.x;
                 const float y = yv[u];
-                keep = y != 0.0f;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
+                bool keep = y != 0.0f && j < P.W;  // NaN: kept (stored explicitly, like csr_matrix(x_res))
+                bool tie = false;
                 if (has_thr) {
                     const int cmp = thr_compare(fabsf(y), thf);
                     if (cmp < 0) keep = false;
-                    else if (cmp == 0 && keep) {  // float32 cannot decide: exact float64 recomputation below
-                        const int idx = atomicAdd(&tie_n, 1);
-                        if (idx < 32) {
-                            tie_j[idx] = j;
-                        } else {  // > 32 ties in one row: resolve serially
-                            const int st = P.w_start[j];
-                            const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
-                                              P.cell_median[cell];
-                            if (fabs(yd) < th) keep = false;
-                        }
-                    }
+                    tie = cmp == 0 && keep;
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(keep), tm = __builtin_amdgcn_ballot_w64(tie);
+                if ((threadIdx.x & 63) == 0 && j < P.W) {
+                    mwords[rr * n_words + (j >> 6)] = m;
+                    twords[rr * n_words + (j >> 6)] = tm;
                 }
             }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-            if ((threadIdx.x & 63) == 0 && j < P.W) mwords[j >> 6] = m;
         }
     }
-    __syncthreads();  // mask words and the tie list are complete
-    const int nt = tie_n < 32 ? tie_n : 32;
-    for (int i = 0; i < nt; ++i) {  // rare (about one window in 1e7): the block recomputes it together
-        const int j = tie_j[i];
-        const int st = P.w_start[j], ln = P.w_len[j];
-        const int len = ln > 0 ? ln : -ln;
-        bool drop = false;
-        if (len <= kTieBuf) {
-            for (int k = threadIdx.x; k < len; k += 256) vals[k] = value_at<T, CSR>(P, cell, st + k);
-            __syncthreads();
-            if (threadIdx.x == 0)
-                drop = fabs(window_canonical(P, j, [&](int k) { return vals[k]; }) - P.cell_median[cell]) < th;
-            __syncthreads();
-        } else if (threadIdx.x == 0) {
-            drop = fabs(window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
-                        P.cell_median[cell]) < th;
-        }
-        if (threadIdx.x == 0 && drop) mwords[j >> 6] &= ~(1ull << (j & 63));
-    }
-    if (nt) __syncthreads();
-    // ---- wavefront 0: offsets of the mask words inside the row, the row's count, the look-back ----------------------
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int run = 0;
-        for (int w0 = 0; w0 < n_words; w0 += 64) {
-            const int cnt = w0 + lane < n_words ? __popcll(mwords[w0 + lane]) : 0;
-            const int incl = wave_scan_dpp(cnt);
-            if (w0 + lane < n_words) woff[w0 + lane] = run + incl - cnt;
-            run += __builtin_amdgcn_readlane(incl, 63);
-        }
-        const unsigned long long mine = (unsigned long long)run;
-        unsigned long long excl = 0;
-        if (cell > 0) {
-            if (lane == 0)
-                __hip_atomic_store(status + cell, kPackAgg | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // look back 64 rows at a time: lane l reads row cell - 1 - l (of this window); sum the counts up to and
-            // including the nearest row that already knows its prefix
-            int64_t hi = cell - 1;
-            while (true) {
-                const int64_t r = hi - lane;
-                unsigned long long sv;
-                do {  // every row of the window has started (tickets are handed out in order): it publishes soon
-                    sv = r >= 0 ? __hip_atomic_load(status + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPackPfx;
-                } while (__builtin_amdgcn_ballot_w64((sv >> 62) == 0) != 0);
-                const unsigned long long pfx = __builtin_amdgcn_ballot_w64((sv >> 62) == 2);
-                const int first = pfx ? __builtin_ctzll(pfx) : 64;  // nearest row with a prefix
-                unsigned long long part = lane <= first ? (sv & kPackVal) : 0;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const unsigned plo = (unsigned)__shfl_xor((int)(unsigned)part, o), phi = (unsigned)__shfl_xor((int)(unsigned)(part >> 32), o);
-                    part += ((unsigned long long)phi << 32) | plo;
-                }
-                excl += part;
-                if (pfx) break;
-                hi -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(status + cell, kPackPfx | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            base_s = (long long)excl;
-            if (cell == 0) indptr[0] = 0;
-            indptr[cell + 1] = (int64_t)(excl + mine);
+    __syncthreads();  // the mask words of the workgroup's rows are complete
+    // ---- ties (about one window in 1e7): each recomputed in float64 by the thread that finds it (one thread per word) ----
+    for (int w = threadIdx.x; w < n_here * n_words; w += 256) {
+        unsigned long long tm = twords[w];
+        while (tm) {
+            const int bit = __builtin_ctzll(tm);
+            tm &= tm - 1;
+            const int rr = w / n_words, j = (w - rr * n_words) * 64 + bit;
+            const int64_t cell = cell0 + rr;
+            const double th = thr[(cell + row_phase) / chunksize];
+            const int st = P.w_start[j];
+            const double yd = window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, cell, st + k); }) -
+                              P.cell_median[cell];
+            if (fabs(yd) < th) mwords[w] &= ~(1ull << bit);
         }
     }
     __syncthreads();
-    // ---- pack: the row again (L2), entries in window order --------------------------------------------------------
-    const int64_t base = base_s;
-    for (int j = threadIdx.x; j < P.W; j += 256) {
-        const unsigned long long m = mwords[j >> 6];
-        if ((m >> (j & 63)) & 1ull) {
-            const int64_t pos = base + woff[j >> 6] + __popcll(m & ((1ull << (j & 63)) - 1ull));
-            if (pos < cap) {
-                indices[pos] = j;
-                data[pos] = (double)orow[j];
+    if (threadIdx.x < 64)
+        pack_lookback(threadIdx.x, tk, (P.n_rows + rpw - 1) / rpw, n_here, n_words, mwords, woff, row_base, status, gstat,
+                      gacc, indptr);
+    __syncthreads();
+    // ---- pack: the rows again (L2), entries in window order ----------------------------------------------------------
+    if ((int)threadIdx.x < n_here) indptr[cell0 + threadIdx.x + 1] = row_base[threadIdx.x + 1];
+    const int lane = threadIdx.x & 63;
+    for (int rr = 0; rr < n_here; ++rr) {
+        const float* orow = P.out + (cell0 + rr) * P.ldo;
+        const int64_t base = row_base[rr];
+        for (int j = threadIdx.x; j < P.W; j += 256) {
+            const unsigned long long m = mwords[rr * n_words + (j >> 6)];
+            if ((m >> lane) & 1ull) {
+                const int64_t pos = base + woff[rr * n_words + (j >> 6)] +
+                                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_PACK_EXP_NOSTORE)
+                if (pos < 0) {
+#else
+                if (pos < cap) {
+#endif
+                    indices[pos] = j;
+                    data[pos] = (double)orow[j];
+                }
             }
         }
     }
@@ -1518,6 +1586,49 @@ __global__ void __launch_bounds__(256) k_csr_row_abs_sum(const T* data, const in
     for (int64_t k = indptr[row] + (threadIdx.x & 63); k < e; k += 64) acc += fabs((double)data[k]);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
+}
+
+// indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r]: ONE 1024-thread workgroup (the counts of a piece are a
+// few hundred KB: the scan is a ~10 us epilogue of the mask pass, not worth a multi-workgroup scheme)
+__global__ void __launch_bounds__(1024) k_row_offsets(const int64_t* __restrict__ row_nnz, int64_t n_rows,
+                                                      int64_t* __restrict__ indptr) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) {
+        carry_s = 0;
+        indptr[0] = 0;
+    }
+    __syncthreads();
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 4096) {  // four consecutive counts per thread
+        long long v[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = r0 + 4 * t + k;
+            v[k] = r < n_rows ? row_nnz[r] : 0;
+            s += v[k];
+        }
+        long long incl = s;  // inclusive scan of the threads' sums over the wavefront
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned lo = (unsigned)__shfl_up((int)(unsigned)incl, o), hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)incl >> 32), o);
+            if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        long long before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        long long run = before + incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t r = r0 + 4 * t + k;
+            run += v[k];
+            if (r < n_rows) indptr[r + 1] = run;
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = run;
+        __syncthreads();
+    }
 }
 
 // pack the kept entries (bit mask of k_thr_mask) of the dense float32 result: one wavefront per row.  The row's mask

@@ -15,6 +15,7 @@ row order (``vstack``, :137).
 from __future__ import annotations
 
 import logging
+import sys
 import threading
 import time as _time
 from collections.abc import Sequence
@@ -115,6 +116,130 @@ class _Shard:
         self.accs = None        # host, per group: reference-order accumulators after this shard's rows
 
 
+_PLAN_CACHE = {}
+_PLAN_CACHE_LOCK = threading.Lock()
+_PLAN_CACHE_MAX = 8
+
+
+def _cached_plan(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
+    """GenePlan for calls on HBM-resident matrices, kept between calls: planning the gene order costs ~9 ms of host time
+    at 20 000 genes, three times the GPU time of 100 000 cells.  Keyed by the CONTENT of the annotation (an object
+    column by the identity of its immutable string objects, which the cache entry keeps alive), the window geometry
+    and the device; the eight most recent plans are kept."""
+    chrom, start = np.asarray(var_chrom), np.asarray(var_start)
+    excl = None if exclude_chromosomes is None else tuple(exclude_chromosomes)
+    key = (chrom.dtype.str, chrom.tobytes(), start.dtype.str, start.tobytes(), int(window_size), int(step), excl,
+           int(device))
+    with _PLAN_CACHE_LOCK:
+        ent = _PLAN_CACHE.pop(key, None)
+        if ent is None:
+            ent = (GenePlan(chrom, start, window_size=window_size, step=step, exclude_chromosomes=exclude_chromosomes),
+                   chrom)
+        _PLAN_CACHE[key] = ent  # most recently used last
+        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))[0].close()
+        return ent[0]
+
+
+def _clear_plan_cache():
+    with _PLAN_CACHE_LOCK:
+        while _PLAN_CACHE:
+            _PLAN_CACHE.popitem()[1][0].close()
+
+
+def _resident_matrix(X, torch):
+    """``adata.X`` that already lives in HBM: a CUDA ``torch.Tensor`` (cells x genes, float32 / float64) or an
+    ``infercnvpy_amd.DeviceMatrix`` (dense or CSR device arrays); None for host data."""
+    if isinstance(X, _engine.DeviceMatrix):
+        return X
+    if torch is not None and isinstance(X, torch.Tensor) and X.is_cuda:
+        if X.dim() != 2 or X.dtype not in (torch.float32, torch.float64):
+            raise ValueError("a device matrix must be a 2-D float32 / float64 tensor")
+        return _engine.DeviceMatrix(dense=X if X.stride(1) == 1 else X.contiguous())
+    return None
+
+
+def _infercnv_resident(adata, dm, *, reference_key, reference_cat, reference, lfc_clip, window_size, step,
+                       dynamic_threshold, exclude_chromosomes, chunksize, inplace, key_added, calculate_gene_values, tm):
+    """The call on a matrix that is resident in HBM (no host copies, no synchronisation): reference means as chains on
+    the device, one smoothing launch, threshold + CSR pack in one pass; ``X_cnv`` stays on the device as a
+    :class:`infercnvpy_amd.PackedCsr` (``.to_scipy()`` for the host matrix)."""
+    torch = _engine._torch()
+    t_start = _time.perf_counter()
+    dev = dm._keep[0].device.index
+    n_obs, n_vars = dm.shape
+    with torch.cuda.device(dev):
+        plan = _cached_plan(adata.var["chromosome"].to_numpy(), adata.var["start"].to_numpy(), window_size, step,
+                            exclude_chromosomes, dev)
+        if plan.n_without_position:
+            log.warning(f"Skipped {plan.n_without_position} genes because they don't have a genomic position annotated. ")
+        is_csr = dm.format == _lib.ICV_CSR
+        np_dtype = np.float32 if dm.dtype == torch.float32 else np.float64
+        flags = 0
+        if reference is not None:
+            given = np.asarray(reference)
+            if given.ndim == 1:
+                given = given[np.newaxis, :]
+            if given.shape[1] != n_vars:
+                raise ValueError("Reference must match the number of genes in AnnData. ")
+            if np.result_type(np_dtype, given.dtype) != np_dtype:
+                raise ValueError("a device-resident matrix needs a reference of its own (or a narrower) dtype: "
+                                 "numpy would promote the subtraction (pass the matrix as float64)")
+            ref = torch.from_numpy(np.ascontiguousarray(given.astype(np_dtype))).cuda()
+        else:
+            groups = cats = None
+            if reference_key is None or reference_cat is None:
+                log.warning("Using mean of all cells as reference. For better results, provide either "
+                            "`reference`, or both `reference_key` and `reference_cat`. ")
+                counts = [n_obs]
+            else:
+                groups, counts, cats = _reference_groups(adata.obs, reference_key, reference_cat)
+            rows = []
+            for gi, n_g in enumerate(counts):
+                sel = None if groups is None else np.nonzero(groups == gi)[0]
+                acc = _engine.column_chain(dm, None, sel, int(n_g))
+                rows.append(_engine.chain_mean(acc, int(n_g), is_csr))
+            if cats is not None:
+                labels = cats.tolist()
+                first = {c: i for i, c in reversed(list(enumerate(labels)))}
+                rows = [rows[first[c]] for c in labels]
+            ref = torch.stack(rows)
+        if ref.shape[0] == 1:
+            ref_lo, ref_hi = ref[0].contiguous(), None
+        else:
+            ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
+        # pieces of whole chunks whose result buffers (4 + 12 bytes per window, worst case) fit next to the matrix
+        free_b, _ = torch.cuda.mem_get_info()
+        per_row = 16 * plan.n_windows + 64 + (8 * (2 * n_vars + plan.n_windows) if calculate_gene_values else 0)
+        piece = max(chunksize, int(0.4 * free_b // per_row) // chunksize * chunksize)
+        parts, genes = [], []
+        for r0 in range(0, max(n_obs, 1), piece):
+            r1 = min(n_obs, r0 + piece)
+            res = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, dynamic_threshold=dynamic_threshold,
+                                       chunksize=chunksize, flags=flags, row0=r0, row1=r1, apply=False)
+            parts.append(_engine.threshold_csr(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                                               flags=flags, row0=r0, row1=r1))
+            if calculate_gene_values:
+                if r0 != 0 or r1 != n_obs:
+                    raise NotImplementedError("calculate_gene_values on a device matrix that needs several pieces")
+                genes.append(_engine.gene_values(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr,
+                                                 chunksize=chunksize, flags=flags))
+            del res
+        x_cnv = parts[0] if len(parts) == 1 else _engine.concat_packed(parts)
+        tm["kernel"] = plan.last_kernel()
+        tm["devices"] = [dev]
+        tm["total"] = _time.perf_counter() - t_start  # host time only: nothing has been waited for
+        chr_pos = dict(plan.chr_pos)
+    per_gene = genes[0] if genes else None
+    if inplace:
+        adata.obsm[f"X_{key_added}"] = x_cnv
+        adata.uns[key_added] = {"chr_pos": chr_pos}
+        if calculate_gene_values:
+            adata.layers[f"gene_values_{key_added}"] = per_gene
+        return None
+    return chr_pos, x_cnv, per_gene
+
+
 def infercnv(
     adata,
     *,
@@ -166,9 +291,15 @@ def infercnv(
     entry within ~1e-12 of the threshold may fall on the other side than in the reference (none in the golden
     vectors; expected well below one entry per 10^9).
 
+    A matrix that already lives in HBM -- ``adata.X`` (or the layer) a CUDA ``torch.Tensor`` or an
+    ``infercnvpy_amd.DeviceMatrix`` (dense or CSR device arrays) -- is processed in place on its GPU: nothing is copied
+    from or to the host, the call returns without waiting for the GPU, and ``obsm["X_cnv"]`` is an
+    ``infercnvpy_amd.PackedCsr`` (device CSR; ``.to_scipy()`` gives the reference's host matrix, bit-identical to the
+    host-input call).  ``n_jobs`` / ``devices`` do not apply to it.
+
     Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
     while the pieces that have landed are smoothed (reference means: chained); the noise threshold and the CSR
-    packing of X_cnv are one pass over the un-thresholded result on the GPU (x_res is read once and never
+    packing of X_cnv run on the GPU from the un-thresholded result and a keep-mask (x_res is never
     rewritten) and only the packed arrays cross PCIe on the way back.
     """
     tm = _timings if _timings is not None else {}
@@ -179,6 +310,15 @@ def infercnv(
         raise ValueError(
             "Genomic positions not found. There need to be `chromosome`, `start`, and `end` columns in `adata.var`. ")
     _lib.load()  # fail loudly before doing any work if the HIP extension is missing
+
+    X0 = adata.X if layer is None else adata.layers[layer]
+    dm0 = _resident_matrix(X0, sys.modules.get("torch"))
+    if dm0 is not None:
+        return _infercnv_resident(
+            adata, dm0, reference_key=reference_key, reference_cat=reference_cat, reference=reference,
+            lfc_clip=lfc_clip, window_size=window_size, step=step, dynamic_threshold=dynamic_threshold,
+            exclude_chromosomes=exclude_chromosomes, chunksize=int(chunksize), inplace=inplace, key_added=key_added,
+            calculate_gene_values=calculate_gene_values, tm=tm)
 
     var_chrom, var_start = adata.var["chromosome"].to_numpy(), adata.var["start"].to_numpy()
     plan_kw = dict(window_size=window_size, step=step, exclude_chromosomes=exclude_chromosomes)
@@ -368,11 +508,10 @@ def infercnv(
                     res = _engine.run_hot_path(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                                dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
                                                row0=r0, row1=r1, apply=False)
-                    # step 5b + csr_matrix(x_res) in one pass over x_res (icv_threshold_pack); very long window lists
-                    # (> 20 480) keep the two-step form (keep-mask, then the fill on the drain's stream)
-                    pack = _engine.threshold_pack if plan.n_windows <= 20480 else _engine.threshold_mask
-                    drain.submit(pack(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
-                                      flags=flags, row0=r0, row1=r1))
+                    # step 5b + csr_matrix(x_res) on the device (keep-mask, row offsets, fill); only the row offsets
+                    # and the packed entries are read back by the drain
+                    drain.submit(_engine.threshold_csr(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
+                                                       chunksize=chunksize, flags=flags, row0=r0, row1=r1))
                     if res.thr is not None:
                         thrs.append(res.thr)
                     del res

@@ -1,6 +1,7 @@
-"""GPU tests (``-m gpu``) of ``icv_threshold_pack``: step 5b and ``csr_matrix(x_res)`` (reference tl/_infercnv.py:449-455)
-in one pass with a decoupled look-back over the rows, against the two-step form (keep-mask + prefix sum + fill) and
-against the in-place threshold: identical CSR arrays, run after run."""
+"""GPU tests (``-m gpu``) of the device-side CSR packing of X_cnv: step 5b and ``csr_matrix(x_res)`` (reference
+tl/_infercnv.py:449-455) as keep-mask + ``icv_row_offsets`` + fill (the public path's default) and in one pass with a
+decoupled look-back over the rows (``icv_threshold_pack``), against each other, against a torch prefix sum and against
+the in-place threshold: identical CSR arrays, run after run."""
 import numpy as np
 import pandas as pd
 import pytest
@@ -59,6 +60,11 @@ def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
             np.testing.assert_array_equal(ip, ip2)
             np.testing.assert_array_equal(pk.indices[:nnz].cpu().numpy(), ix2)
             np.testing.assert_array_equal(pk.data[:nnz].cpu().numpy(), dv2)
+        # the default of the public path: mask + icv_row_offsets + fill, nothing read back
+        pk = _engine.threshold_csr(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+        np.testing.assert_array_equal(pk.indptr.cpu().numpy(), ip2)
+        np.testing.assert_array_equal(pk.indices[:nnz].cpu().numpy(), ix2)
+        np.testing.assert_array_equal(pk.data[:nnz].cpu().numpy(), dv2)
         # ... and the in-place threshold of the same x_res, packed by scipy
         res_a = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=dyn, chunksize=chunksize, apply=True)
         exp = sp.csr_matrix(res_a.out.cpu().numpy().astype(np.float64))
