@@ -234,13 +234,16 @@ class SlabStream:
     ``dm`` is the DeviceMatrix of the whole slab (valid row ranges: the pieces yielded so far).
     """
 
-    def __init__(self, X, tdtype, piece_rows):
+    def __init__(self, X, tdtype, piece_rows, row0=0, row1=None):
+        """Rows [row0, row1) of the host matrix ``X`` (the parent's arrays are read in place: slicing a scipy CSR
+        matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded)."""
         import queue
         import threading
 
         torch = _torch()
         np_dtype = np.float32 if tdtype == torch.float32 else np.float64
-        self.n_rows = X.shape[0]
+        row1 = X.shape[0] if row1 is None else row1
+        self.n_rows = row1 - row0
         self.bounds = [(r, min(self.n_rows, r + piece_rows)) for r in range(0, self.n_rows, piece_rows)]
         self._landed = 0
         device = torch.cuda.current_device()  # the helper threads start on device 0 otherwise
@@ -251,32 +254,36 @@ class SlabStream:
         # busy where one thread alternating between them does not (measured with cold pages and a device -> host
         # copy beside them: 54 against 39 GB/s, tools/exp_h2d_csr.py)
         if sp.issparse(X):
-            indptr64 = np.ascontiguousarray(X.indptr.astype(np.int64, copy=False))
+            base = int(X.indptr[row0])  # the slab's entries are [base, base + nnz) of the parent's arrays
+            indptr64 = np.ascontiguousarray(X.indptr[row0:row1 + 1].astype(np.int64)) - base
             nnz = int(indptr64[-1])
             d_indices = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
             d_data = torch.empty(max(nnz, 1), dtype=tdtype, device="cuda")
             d_indptr = torch.from_numpy(indptr64).cuda()
-            self.dm = DeviceMatrix(indptr=d_indptr, indices=d_indices, data=d_data, shape=X.shape,
+            self.dm = DeviceMatrix(indptr=d_indptr, indices=d_indices, data=d_data, shape=(self.n_rows, X.shape[1]),
                                    indptr_host=indptr64)
             idx_h, dat_h = X.indices, X.data
 
             def copy_indices(r0, r1):
                 k0, k1 = int(indptr64[r0]), int(indptr64[r1])
                 if k1 > k0:
-                    d_indices[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(idx_h[k0:k1].astype(np.int32, copy=False))))
+                    d_indices[k0:k1].copy_(torch.from_numpy(
+                        np.ascontiguousarray(idx_h[base + k0:base + k1].astype(np.int32, copy=False))))
 
             def copy_data(r0, r1):
                 k0, k1 = int(indptr64[r0]), int(indptr64[r1])
                 if k1 > k0:
-                    d_data[k0:k1].copy_(torch.from_numpy(np.ascontiguousarray(dat_h[k0:k1].astype(np_dtype, copy=False))))
+                    d_data[k0:k1].copy_(torch.from_numpy(
+                        np.ascontiguousarray(dat_h[base + k0:base + k1].astype(np_dtype, copy=False))))
 
             copiers = [copy_indices, copy_data]
         else:
-            dense = torch.empty(X.shape, dtype=tdtype, device="cuda")
+            dense = torch.empty((self.n_rows, X.shape[1]), dtype=tdtype, device="cuda")
             self.dm = DeviceMatrix(dense=dense)
 
             def copy_piece(r0, r1):
-                dense[r0:r1].copy_(torch.from_numpy(np.ascontiguousarray(X[r0:r1].astype(np_dtype, copy=False))))
+                dense[r0:r1].copy_(torch.from_numpy(
+                    np.ascontiguousarray(X[row0 + r0:row0 + r1].astype(np_dtype, copy=False))))
 
             copiers = [copy_piece]
 
@@ -525,15 +532,29 @@ class _PinnedRing:
 
     @classmethod
     def get(cls, torch):
+        import atexit
         import threading
 
         if cls._lock is None:
             cls._lock = threading.Lock()
+            atexit.register(cls.release_all)
         dev = torch.cuda.current_device()
         with cls._lock:
             if dev not in cls._rings:
                 cls._rings[dev] = cls(torch)
             return cls._rings[dev]
+
+    @classmethod
+    def release_all(cls):
+        """Drop every GPU's ring (128 MB of pinned host memory and three helper threads each); the next drain builds a
+        new one.  Registered with atexit; ``infercnvpy_amd._engine.release_pinned_buffers()`` for long-lived processes."""
+        if cls._lock is None:
+            return
+        with cls._lock:
+            rings, cls._rings = cls._rings, {}
+        for r in rings.values():
+            r.pool.shutdown(wait=True)
+            r.slots, r.views = [], []
 
     def __init__(self, torch, n_slots=8, slot_bytes=16 << 20, n_threads=3):
         import queue
@@ -573,6 +594,11 @@ class _PinnedRing:
                 ev.record(stream)
             futs.append(self.pool.submit(self._land, i, ev, dst_b[a:a + n], n))
         return futs
+
+
+def release_pinned_buffers():
+    """Free the pinned staging rings of the device -> host copies (128 MB per GPU used so far, kept between calls)."""
+    _PinnedRing.release_all()
 
 
 class CsrDrain:

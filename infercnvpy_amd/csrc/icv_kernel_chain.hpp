@@ -103,9 +103,13 @@ __device__ __forceinline__ void chain_wait_vmcnt(int n) {
                  : [p] "v"(PX), ICV_CH_IN(CX))
 #define ICV_CH_ADDS(OP, AX, CX) asm volatile(ICV_CH_AD10(OP) : [a] "+v"(AX) : ICV_CH_IN(CX))
 
-template <typename T, int NL, int RR>
+// FLAGS = false: a workgroup barrier hands every round over (the loaders of k_colchain run in lock step with it).
+// FLAGS = true (k_colchain_csr): ready[slot] == k + 1 says round k is in its slot, *consumed = k + 1 gives it back --
+// LDS words polled with workgroup-scope acquire loads, so that the producers work ahead of each other.
+template <typename T, int NL, int RR, bool FLAGS = false>
 __device__ __forceinline__ void chain_rounds(const unsigned char* smem, int n_slots, int64_t n_rounds, int64_t n_sel,
-                                             int lane, typename ChainLane<T>::type& a) {
+                                             int lane, typename ChainLane<T>::type& a, int* ready = nullptr,
+                                             int* consumed = nullptr) {
     typedef typename ChainLane<T>::type lane_t;
     constexpr int RB = 128 * NL, SLOT = RR * RB;
     constexpr int NCH = RR / 10;
@@ -113,8 +117,13 @@ __device__ __forceinline__ void chain_rounds(const unsigned char* smem, int n_sl
     int slot_i = 0;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)lane * 8u;
     for (int64_t k = 0; k < n_rounds; ++k) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");  // the slot was written by the loaders' DMA: read it after the barrier
+        if constexpr (FLAGS) {
+            while (__hip_atomic_load(ready + slot_i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (int)(k + 1))
+                __builtin_amdgcn_s_sleep(1);
+        } else {
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("" ::: "memory");  // the slot was written by other wavefronts (DMA / ds_write): read it now
         const unsigned p0 = lds0 + (unsigned)slot_i * (unsigned)SLOT;
         const lane_t* slot = reinterpret_cast<const lane_t*>(smem + (size_t)slot_i * SLOT) + lane;
         slot_i = slot_i + 1 == n_slots ? 0 : slot_i + 1;
@@ -151,6 +160,10 @@ __device__ __forceinline__ void chain_rounds(const unsigned char* smem, int n_sl
 #undef ICV_CH_BODY
         } else {
             for (int i = 0; i < (int)left; ++i) chain_add(a, slot[i * (RB / 8)]);
+        }
+        if constexpr (FLAGS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the round's reads have returned)
+            if (lane == 0) __hip_atomic_store(consumed, (int)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -298,18 +311,21 @@ struct ChainLaunch {
 // CSR input: the same chain over slices of the tile rebuilt in LDS
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kCcRows = 60;       // rows per round (one loader wavefront, lane = row; a multiple of the chain's ten)
-constexpr int kCcBlock = 64;      // rows per block of the bounds table
+constexpr int kCcBlock = 32;      // rows per block of the bounds table
 
-// bounds[(blk * (n_tiles + 1) + t) * 64 + r] = number of entries of selected row blk * 64 + r in the tiles before t
+// bounds[(blk * (n_tiles + 1) + t) * 32 + r] = number of entries of selected row blk * 32 + r in the tiles before t
 // (t = 0 .. n_tiles; the row's entries of tile t are [bounds[t], bounds[t + 1]) from the row's start): one pass over the
 // column indices, rows' columns ascending (canonical CSR).  line_tile[l] = tile of cache line l of a row.
-// grid = ceil(n_sel / 64) workgroups of four wavefronts; a wavefront takes one row at a time.
+// grid = ceil(n_sel / 32) workgroups of four wavefronts; a wavefront takes one row at a time.
 template <bool LIST>
 __global__ void __launch_bounds__(256) k_csr_tile_bounds(const int64_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ indices,
                                                          const int32_t* __restrict__ sel, int64_t n_sel,
                                                          const uint16_t* __restrict__ line_tile, int esz_shift,
                                                          int n_tiles, uint32_t* __restrict__ bounds) {
+    // (measured and dropped: the block's table staged in LDS and written out coalesced -- 64 KB of LDS leave two
+    // workgroups per CU and the pass is bound by the latency of its dependent loads: 3.9 instead of 2.4 ms per 500 000
+    // rows; four chunks of 64 entries in flight per wavefront instead)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* blk = bounds + (int64_t)blockIdx.x * (n_tiles + 1) * kCcBlock;
     for (int r = wave; r < kCcBlock; r += 4) {
@@ -319,24 +335,37 @@ __global__ void __launch_bounds__(256) k_csr_tile_bounds(const int64_t* __restri
         const int64_t e0 = indptr[row];
         const int64_t len = indptr[row + 1] - e0;
         int carry = -1;  // tile of the entry before this chunk
-        for (int64_t base = 0; base <= len; base += 64) {
-            const int64_t pos = base + lane;
-            int T = n_tiles;  // pos == len: the terminator closes every remaining tile at `len`
-            if (pos < len) T = line_tile[((unsigned)indices[e0 + pos] << esz_shift) >> 7];
-            int P = __shfl_up(T, 1);
-            if (lane == 0) P = carry;
-            carry = __shfl(T, 63);
-            if (pos <= len)
-                for (int t = P + 1; t <= T; ++t) blk[(int64_t)t * kCcBlock + r] = (uint32_t)pos;
+        for (int64_t base = 0; base <= len; base += 256) {
+            int col[4], T[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                col[u] = pos < len ? indices[e0 + pos] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                // pos == len: the terminator closes every remaining tile at `len`
+                T[u] = pos < len ? (int)line_tile[((unsigned)col[u] << esz_shift) >> 7] : n_tiles;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                int P = __shfl_up(T[u], 1);
+                if (lane == 0) P = carry;
+                carry = __shfl(T[u], 63);
+                if (pos <= len)
+                    for (int t = P + 1; t <= T[u]; ++t) blk[t * kCcBlock + r] = (uint32_t)pos;
+            }
         }
     }
 }
 
 // acc[c] += fl(x * scale) over the stored entries of rows sel[0..n_sel) (nullptr: rows 0..n_sel), rows ascending --
 // scipy's CSR mean(axis=0): sum over rows of x * (1/n) in the matrix dtype.  Tiles and ring as k_colchain (grid =
-// ChainLaunch.grid = n_tiles of the bounds table); 15 loader wavefronts take turns: the owner of round k (60 rows,
-// lane = row) zeroes the slot and writes the rows' entries of the tile's columns (prefetched a turn earlier, their
-// bounds two turns earlier), S - 2 rounds ahead of the chain wavefront.
+// ChainLaunch.grid = n_tiles of the bounds table); 15 loader wavefronts take the rounds in turn: the owner of round k
+// (60 rows, lane = row) zeroes the slot and writes the rows' entries of the tile's columns (prefetched a turn earlier,
+// their bounds two turns earlier) as soon as the chain wavefront has given the slot back.
 template <typename T, bool LIST>
 __global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict__ vals, const int64_t* __restrict__ indptr,
                                                              const int32_t* __restrict__ indices, int64_t n_rows_all,
@@ -355,34 +384,41 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict
     const int nl = (int)((int64_t)(tile + 1) * n_lines / n_tiles) - line0;
     const int c0 = line0 * (128 / (int)sizeof(T));
     const int row_bytes = 128 * nl, slot_bytes = kCcRows * row_bytes;
-    const int n_slots = lds_bytes / slot_bytes;
-    const int lead = n_slots - 2;  // a slot is written this many rounds before the chain reads it
+    const int n_slots = (lds_bytes - 256) / slot_bytes;
     const int64_t n_rounds = (n_sel + kCcRows - 1) / kCcRows;
+    // hand-over words behind the ring: ready[slot] = round in the slot + 1, consumed = rounds the chain is done with
+    int* ready = reinterpret_cast<int*>(smem + (size_t)n_slots * slot_bytes);
+    int* consumed = ready + 32;
+    if (threadIdx.x <= 32) ready[threadIdx.x] = 0;
+    __syncthreads();
 
     if (wave < kChLoaders) {
         const int64_t e_end = indptr[n_rows_all];
-        // stage A: where the lane's row keeps its entries of this tile; stage B: the first K of them
-        int64_t a_e = 0;
-        int a_cnt = 0;
+        // stage A: where the lane's row keeps its entries of this tile -- the three loaded words are kept RAW (the
+        // arithmetic on them belongs to the next turn: written here, the compiler waits for them, and with them for
+        // the eight entry loads issued just before, at the end of every turn: 2 us of exposed latency per round);
+        // stage B: the first K entries
+        int64_t a_rp = 0;
+        uint32_t a_lo = 0, a_hi = 0;
         int64_t b_e = 0;
         int b_cnt = 0;
         int32_t b_idx[K];
         T b_val[K];
         const auto fetch_a = [&](int64_t k) {
             const int64_t i = k * kCcRows + lane;
-            a_cnt = 0;
-            a_e = 0;
+            a_rp = 0;
+            a_lo = a_hi = 0;
             if (k < n_rounds && lane < kCcRows && i < n_sel) {
                 const int64_t row = LIST ? sel[i] : i;
-                const uint32_t* bb = bounds + ((i >> 6) * (n_tiles + 1) + tile) * kCcBlock + (i & 63);
-                const uint32_t lo = bb[0], hi = bb[kCcBlock];
-                a_e = indptr[row] + lo;
-                a_cnt = (int)(hi - lo);
+                const uint32_t* bb = bounds + ((i / kCcBlock) * (n_tiles + 1) + tile) * kCcBlock + (i % kCcBlock);
+                a_lo = bb[0];
+                a_hi = bb[kCcBlock];
+                a_rp = indptr[row];
             }
         };
         const auto fetch_b = [&]() {
-            b_e = a_e;
-            b_cnt = a_cnt;
+            b_e = a_rp + (int64_t)a_lo;
+            b_cnt = (int)(a_hi - a_lo);
             // range-checked 16-byte loads relative to the wavefront's first entry (rows ascend): lanes without entries
             // and reads past the end of the arrays return zeros
             int64_t e_first = b_cnt > 0 ? b_e : e_end;
@@ -419,25 +455,39 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict
         };
         const auto write_slot = [&](int64_t k) {
             unsigned char* slot = smem + (size_t)(k % n_slots) * slot_bytes;
+#if !(defined(ICV_DEV_EXPERIMENTS) && defined(ICV_CC_EXP_NOZERO))
             for (int o = lane * 16; o < slot_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(slot + o) = make_uint4(0, 0, 0, 0);
+#endif
             T* row = reinterpret_cast<T*>(slot + (size_t)lane * row_bytes);
+#if !(defined(ICV_DEV_EXPERIMENTS) && defined(ICV_CC_EXP_NOSCATTER))
 #pragma unroll
             for (int j = 0; j < K; ++j)
                 if (j < b_cnt) row[b_idx[j] - c0] = b_val[j] * scale;
             for (int j = K; j < b_cnt; ++j) row[indices[b_e + j] - c0] = vals[b_e + j] * scale;  // long rows
+#else
+            if (b_cnt == 12345) row[b_idx[0] - c0] = b_val[3] * scale;
+#endif
         };
+        // The producers are NOT in lock step with the chain (a barrier per round serialised their turns: 15 ms for
+        // 500 000 rows, of which the chain needed 3.5): wavefront w fills the slots of rounds w, w + 15, ... as soon as
+        // the chain has given the slot back, up to n_slots rounds ahead of it.
         int64_t mine = wave;  // this wavefront's next round
         fetch_a(mine);
         fetch_b();
         fetch_a(mine + kChLoaders);
-        for (int64_t j = -lead; j < n_rounds; ++j) {
-            if (j + lead == mine && mine < n_rounds) {
-                write_slot(mine);
-                fetch_b();
-                mine += kChLoaders;
-                fetch_a(mine + kChLoaders);
-            }
-            if (j >= 0) __builtin_amdgcn_s_barrier();
+        for (; mine < n_rounds; mine += kChLoaders) {
+            const int need = (int)(mine - n_slots + 1);  // the chain is done with the round that had this slot
+            while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                __builtin_amdgcn_s_sleep(2);
+            write_slot(mine);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slot's ds_writes have completed)
+            if (lane == 0)
+                __hip_atomic_store(ready + (int)(mine % n_slots), (int)(mine + 1), __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+#if !(defined(ICV_DEV_EXPERIMENTS) && defined(ICV_CC_EXP_NOFETCH))
+            fetch_b();
+            fetch_a(mine + 2 * kChLoaders);
+#endif
         }
     } else {
         const int col = lane * 8 < row_bytes ? c0 + lane * CPL : n_cols;
@@ -449,10 +499,10 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict
             a = col < n_cols ? acc[col] : 0.0;
         }
         const int rl = lane * 8 < row_bytes ? lane : 0;
-        if (nl == 1) chain_rounds<T, 1, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
-        else if (nl == 2) chain_rounds<T, 2, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
-        else if (nl == 3) chain_rounds<T, 3, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
-        else chain_rounds<T, 4, kCcRows>(smem, n_slots, n_rounds, n_sel, rl, a);
+        if (nl == 1) chain_rounds<T, 1, kCcRows, true>(smem, n_slots, n_rounds, n_sel, rl, a, ready, consumed);
+        else if (nl == 2) chain_rounds<T, 2, kCcRows, true>(smem, n_slots, n_rounds, n_sel, rl, a, ready, consumed);
+        else if (nl == 3) chain_rounds<T, 3, kCcRows, true>(smem, n_slots, n_rounds, n_sel, rl, a, ready, consumed);
+        else chain_rounds<T, 4, kCcRows, true>(smem, n_slots, n_rounds, n_sel, rl, a, ready, consumed);
         if constexpr (sizeof(T) == 4) {
             if (col < n_cols) acc[col] = a.x;
             if (col + 1 < n_cols) acc[col + 1] = a.y;

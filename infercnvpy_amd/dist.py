@@ -7,7 +7,9 @@ chunk kernel, so the shard unit here is the same row chunk.  Two quantities coup
 * the reference profile when it is a mean over cells (``_get_reference``, :385/:400): every rank
   accumulates float64 column sums of its rows on its GPU and ONE all-reduce (RCCL over xGMI with
   the ``nccl`` backend, ``gloo`` in the CPU tests) of the ``[R, G]`` sums plus ``[R]`` counts
-  gives every rank the same means;
+  gives every rank the same, correctly rounded means (:func:`reference_means`); the reference's OWN
+  bits need its evaluation order, a sequential chain per column: :func:`reference_means_chained`
+  passes the accumulators from rank to rank instead (the ranks take turns);
 * the noise threshold, a population std over each ``chunksize``-row chunk (:449-451): shards are
   aligned to ``chunksize`` by default, so every chunk lives on one rank and no collective is
   needed; for unaligned shards the per-chunk ``(n, sum, sum of squares)`` triples are all-reduced.
@@ -99,6 +101,57 @@ def reference_means(local_sums, local_counts, out_dtype, group=None, device_out=
     if bool((cnt == 0).any()):
         raise ValueError("a reference category has no cells on any rank")
     return (sums / cnt[:, None]).cpu().numpy().astype(out_dtype)
+
+
+def _p2p(tensor, peer, send, group=None):
+    """Blocking send / receive of a device tensor; through the host unless the backend is nccl (RCCL)."""
+    dist = _dist()
+    if tensor.is_cuda and dist.get_backend(group) != "nccl":
+        h = tensor.cpu()
+        (dist.send if send else dist.recv)(h, peer, group=group)
+        if not send:
+            tensor.copy_(h)
+    else:
+        (dist.send if send else dist.recv)(tensor, peer, group=group)
+
+
+def reference_means_chained(dm_local, counts_global, local_rows=None, group=None):
+    """The reference profile in the REFERENCE'S OWN evaluation order over row-sharded ranks (bit-equal to
+    ``np.mean(X, axis=0)`` / scipy's CSR mean of the whole matrix, reference :385, :400): a float32 column sum is a
+    sequential chain, so rank k continues the accumulators of rank k - 1 (``icv_colchain``) and hands them to rank
+    k + 1 -- R x G values point to point -- and the last rank's means are broadcast.  The ranks take turns: the pass
+    costs the sum of the ranks' kernel times (the float64 :func:`reference_means` is the concurrent alternative:
+    correctly rounded, one all-reduce, but not the reference's bits).
+
+    ``dm_local``: this rank's rows (``_engine.DeviceMatrix``); ``counts_global``: rows per category over ALL ranks;
+    ``local_rows``: per category the ascending local row indices (None: one category, all rows).  Returns the
+    ``[R, G]`` means as a device tensor of the matrix dtype, identical on every rank."""
+    import torch
+
+    from . import _engine, _lib
+
+    dist = _dist()
+    rank, size = world()
+    n_groups = len(counts_global)
+    accs = torch.zeros((n_groups, dm_local.shape[1]), dtype=dm_local.dtype, device="cuda")
+    if size > 1 and rank > 0:
+        _p2p(accs, rank - 1, send=False, group=group)
+    for g in range(n_groups):
+        rows = None if local_rows is None else local_rows[g]
+        if dm_local.shape[0] and (rows is None or len(rows)):
+            _engine.column_chain(dm_local, accs[g], rows, int(counts_global[g]))
+    if size > 1 and rank < size - 1:
+        _p2p(accs, rank + 1, send=True, group=group)
+    is_csr = dm_local.format == _lib.ICV_CSR
+    means = torch.stack([_engine.chain_mean(accs[g], int(counts_global[g]), is_csr) for g in range(n_groups)])
+    if size > 1:
+        if means.is_cuda and dist.get_backend(group) != "nccl":
+            h = means.cpu()
+            dist.broadcast(h, size - 1, group=group)
+            means.copy_(h)
+        else:
+            dist.broadcast(means, size - 1, group=group)
+    return means
 
 
 def chunk_moments(cell_stats, global_row0: int, chunksize: int, n_chunks_global: int):

@@ -72,10 +72,17 @@ def _means_from_chains(accs, counts, cats, is_sparse):
     return np.vstack(rows)
 
 
+def _current_first(torch, n_dev):
+    """The visible GPUs, the caller's current device first (a caller that did ``torch.cuda.set_device(3)`` gets GPU 3
+    for ``n_jobs=1`` and GPU 3 among the first for more: ADVICE r3)."""
+    cur = torch.cuda.current_device()
+    return [cur] + [d for d in range(n_dev) if d != cur]
+
+
 def _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs=None):
     """GPU of every row shard.  ``devices`` wins (a device may be listed more than once: several shards share it);
-    else ``n_jobs`` GPUs starting at 0 (``n_jobs=1``: the current device); else all visible GPUs, as far as each
-    gets a few chunks of work.  Never more shards than chunks."""
+    else ``n_jobs`` GPUs, the current device first; else all visible GPUs (current first), as far as each gets a few
+    chunks of work.  Never more shards than chunks."""
     n_dev = torch.cuda.device_count()
     if devices is not None:
         devs = [torch.device(d).index if not isinstance(d, (int, np.integer)) else int(d) for d in devices]
@@ -87,7 +94,7 @@ def _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs=None):
                 raise ValueError(f"devices: GPU {d} requested, {n_dev} visible")
     elif n_jobs is not None and int(n_jobs) >= 1:
         k = min(int(n_jobs), n_dev)
-        devs = [torch.cuda.current_device()] if k == 1 else list(range(k))
+        devs = _current_first(torch, n_dev)[:k]
     else:
         in_group = False
         try:
@@ -100,7 +107,9 @@ def _resolve_devices(n_jobs, devices, n_chunks, torch, n_obs=None):
         k = 1 if in_group else max(1, min(n_dev, n_chunks // _MIN_CHUNKS_PER_DEVICE))
         if n_obs is not None:
             k = max(1, min(k, int(n_obs) // _MIN_ROWS_PER_DEVICE))
-        devs = [torch.cuda.current_device()] if k == 1 else list(range(k))
+        devs = _current_first(torch, n_dev)[:k]
+        if k > 1:
+            log.info(f"tl.infercnv: {n_obs} cells over GPUs {devs} (n_jobs=None: every visible GPU with enough work)")
     return devs[: max(1, n_chunks)]
 
 
@@ -425,7 +434,6 @@ def infercnv(
         t_sh = _time.perf_counter()
         plan = plan0 if s.index == 0 else GenePlan(var_chrom, var_start, **plan_kw)
         n_rows = s.g1 - s.g0
-        Xs = X if (s.g0 == 0 and s.g1 == n_obs) else X[s.g0:s.g1]  # slicing a CSR matrix copies it
         # pieces of a slab: a few chunks each (~2 GB of input), copied by a helper thread while earlier ones compute
         per_row = per_row_bytes(plan)
         piece_rows = max(chunksize, int(2e9 // max(per_row, 1)) // chunksize * chunksize)
@@ -451,8 +459,8 @@ def infercnv(
                 for k in list(streams):
                     retire(k)
                 r0, r1 = slabs[i]
-                rows = Xs if (r0 == 0 and r1 == n_rows) else Xs[r0:r1]
-                streams[i] = _engine.SlabStream(rows, tdtype, piece_rows)
+                # (the parent's arrays are read in place: no host copy of the shard or the slab)
+                streams[i] = _engine.SlabStream(X, tdtype, piece_rows, s.g0 + r0, s.g0 + r1)
             return streams[i]
 
         try:

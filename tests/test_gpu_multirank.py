@@ -179,55 +179,65 @@ def test_sharded_ward_two_processes_one_gpu(world, n, d, in_place):
 # the hot path under a process group with every rank on cuda:0 (collectives: gloo through the host)
 # ----------------------------------------------------------------------------------------------------------------------
 _HP_GENES = [700, 320, 150, 100, 60]
-_HP_N, _HP_CS = 2300, 500
+# geometry -> (genes per chromosome, cells, chunksize); "cfg3" = BASELINE config 3's own geometry (20 000 genes on
+# chr1..22, 5000-cell chunks: k_smooth_x16's chunk-moment partials cross a shard cut when the shards are unaligned)
+_HP_GEOM = {"small": (_HP_GENES, 2300, 500), "cfg3": (cases.GENES_PER_CHROM_20K, 12_500, 5000)}
 
 
-def _hp_inputs(fmt):
+def _hp_inputs(fmt, geom="small"):
     import scipy.sparse as sp
 
-    v = cases.synthetic_var(_HP_GENES, extra=(("chrX", 40), (None, 6)))
+    genes, n, _ = _HP_GEOM[geom]
+    v = cases.synthetic_var(genes, extra=(("chrX", 40), (None, 6)) if geom == "small" else ())
     n_genes = len(v["names"]) - len(v["names"]) % 4
     for key in ("chromosome", "start"):
         v[key] = v[key][:n_genes]
-    X = cases.synthetic_expr(_HP_N, n_genes, seed=51)
+    X = cases.synthetic_expr(n, n_genes, seed=51)
     if fmt == "csr":
         X[X < np.quantile(X, 0.9)] = 0
         X = sp.csr_matrix(X)
-    labels = np.array(["n1", "n2", "t"])[np.random.RandomState(9).randint(0, 3, _HP_N)]
+    labels = np.array(["n1", "n2", "t"])[np.random.RandomState(9).randint(0, 3, n)]
     return v, X, labels
 
 
-def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window):
-    """One rank's share: column sums -> all-reduced means -> run_shard.  Returns (r0, r1, out, thr, ref)."""
+def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window, geom, means):
+    """One rank's share: column sums -> all-reduced means (or chained accumulators) -> run_shard.
+    Returns (r0, r1, out, thr, ref)."""
     import torch
 
-    bounds = icd.shard_bounds(_HP_N, world, _HP_CS, align=align)
+    _, n_all, cs = _HP_GEOM[geom]
+    bounds = icd.shard_bounds(n_all, world, cs, align=align)
     r0, r1 = bounds[rank]
     dm = _engine.to_device_matrix(X[r0:r1], torch.float32)
     ll = labels[r0:r1]
-    if cats is None:
+    if means == "chain":
+        if cats is None:
+            ref = icd.reference_means_chained(dm, [n_all])
+        else:
+            ref = icd.reference_means_chained(dm, [int((labels == c).sum()) for c in cats],
+                                              [np.nonzero(ll == c)[0] for c in cats])
+    elif cats is None:
         sums = _engine.column_sums(dm) if r1 > r0 else torch.zeros((1, X.shape[1]), dtype=torch.float64, device="cuda")
-        counts = [r1 - r0]
+        ref = icd.reference_means(sums, [r1 - r0], "float32", device_out=True).contiguous()
     else:
         grp = np.full(r1 - r0, -1, dtype=np.int32)
         for gi, c in enumerate(cats):
             grp[ll == c] = gi
         sums = _engine.column_sums(dm, grp, len(cats)) if r1 > r0 else \
             torch.zeros((len(cats), X.shape[1]), dtype=torch.float64, device="cuda")
-        counts = [int((ll == c).sum()) for c in cats]
-    ref = icd.reference_means(sums, counts, "float32", device_out=True).contiguous()
+        ref = icd.reference_means(sums, [int((ll == c).sum()) for c in cats], "float32", device_out=True).contiguous()
     ref_lo = ref[0].contiguous() if cats is None else ref.min(dim=0).values.contiguous()
     ref_hi = None if cats is None else ref.max(dim=0).values.contiguous()
     # with and without the partition: both ways every rank must take the same branch
     outs = {}
     for ab in (bounds, None):
-        res = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=_HP_N, chunksize=_HP_CS, all_bounds=ab)
+        res = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=n_all, chunksize=cs, all_bounds=ab)
         torch.cuda.synchronize()
         outs[ab is None] = (res.out.cpu().numpy(), None if res.thr is None else res.thr.cpu().numpy())
     return r0, r1, outs, ref.cpu().numpy()
 
 
-def _hp_worker(rank, world, port, fmt, window, q):
+def _hp_worker(rank, world, port, fmt, window, geom, means, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -239,12 +249,13 @@ def _hp_worker(rank, world, port, fmt, window, q):
         from infercnvpy_amd import _engine, dist as icd
         from infercnvpy_amd._plan import GenePlan
 
-        v, X, labels = _hp_inputs(fmt)
+        v, X, labels = _hp_inputs(fmt, geom)
         plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
         out = {}
         for align in (True, False):
             for cats in (None, ["n1", "n2"]):
-                out[(align, cats is None)] = _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window)
+                out[(align, cats is None)] = _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window,
+                                                     geom, means)
         q.put((rank, "ok", out))
     except Exception:  # pragma: no cover
         import traceback
@@ -254,22 +265,29 @@ def _hp_worker(rank, world, port, fmt, window, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fmt,window", [(2, "dense", 100), (3, "dense", 100), (2, "csr", 100), (3, "csr", 250)])
-def test_hot_path_ranks_on_one_gpu(world, fmt, window):
-    """BASELINE config 3's code path (row shards, ONE all-reduce of the reference sums, chunk-aligned and unaligned
-    thresholds) with 2-3 ranks sharing cuda:0: the concatenated shards equal the single-process run bit for bit
-    whenever the all-reduced means equal the single-process means (they are rounded from float64 sums added in
-    another order), and every rank sees the same means."""
+@pytest.mark.parametrize("world,fmt,window,geom,means", [
+    (2, "dense", 100, "small", "allreduce"), (3, "dense", 100, "small", "allreduce"), (2, "csr", 100, "small", "allreduce"),
+    (3, "csr", 250, "small", "allreduce"), (3, "dense", 100, "small", "chain"), (2, "csr", 250, "small", "chain"),
+    (3, "dense", 100, "cfg3", "allreduce"), (3, "dense", 100, "cfg3", "chain"), (2, "csr", 100, "cfg3", "chain")])
+def test_hot_path_ranks_on_one_gpu(world, fmt, window, geom, means):
+    """BASELINE config 3's code path (row shards, ONE all-reduce of the reference sums -- or the reference-order chains
+    handed from rank to rank --, chunk-aligned and unaligned thresholds) with 2-3 ranks sharing cuda:0, at a small
+    geometry and at config 3's own (20 000 genes, window 100, 5000-cell chunks).  means="chain": every rank holds the
+    reference's own means (array_equal to the oracle = numpy / scipy) and the concatenated shards equal the
+    single-process run bit for bit; means="allreduce": the same whenever the all-reduced means equal the single-process
+    float64-sum means (they are rounded from float64 sums added in another order)."""
     import torch
     import torch.multiprocessing as mp
 
     from infercnvpy_amd import _engine
     from infercnvpy_amd._plan import GenePlan
+    from oracle import infercnv_oracle as O
 
+    _, n_all, cs = _HP_GEOM[geom]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_hp_worker, args=(r, world, port, fmt, window, q)) for r in range(world)]
+    procs = [ctx.Process(target=_hp_worker, args=(r, world, port, fmt, window, geom, means, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
@@ -278,27 +296,33 @@ def test_hot_path_ranks_on_one_gpu(world, fmt, window):
     for rank, status, _ in results:
         assert status == "ok", f"rank {rank}: {status}"
 
-    v, X, labels = _hp_inputs(fmt)
+    v, X, labels = _hp_inputs(fmt, geom)
     plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
     dm = _engine.to_device_matrix(X, torch.float32)
     for (align, allmean), _ in results[0][2].items():
-        if allmean:
-            ref = (_engine.column_sums(dm) / _HP_N).float()
-            ref_lo, ref_hi = ref[0].contiguous(), None
+        cats = None if allmean else ["n1", "n2"]
+        if means == "chain":
+            ref_np = np.asarray(O.reference_profile(X, labels if cats else None, cats, None, X.shape[1]))
+            ref = torch.from_numpy(np.ascontiguousarray(ref_np)).cuda()
+        elif allmean:
+            ref = (_engine.column_sums(dm) / n_all).float()
         else:
-            grp = np.full(_HP_N, -1, dtype=np.int32)
+            grp = np.full(n_all, -1, dtype=np.int32)
             for gi, c in enumerate(["n1", "n2"]):
                 grp[labels == c] = gi
             cnt = torch.tensor([(labels == "n1").sum(), (labels == "n2").sum()], dtype=torch.float64, device="cuda")
             ref = (_engine.column_sums(dm, grp, 2) / cnt[:, None]).float()
-            ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
-        whole = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, chunksize=_HP_CS)
+        ref_lo = ref[0].contiguous() if allmean else ref.min(dim=0).values.contiguous()
+        ref_hi = None if allmean else ref.max(dim=0).values.contiguous()
+        whole = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, chunksize=cs)
         w_out, w_thr = whole.out.cpu().numpy(), whole.thr.cpu().numpy()
         parts = [results[r][2][(align, allmean)] for r in range(world)]
-        assert parts[0][0] == 0 and parts[-1][1] == _HP_N
+        assert parts[0][0] == 0 and parts[-1][1] == n_all
         for a, b in zip(parts[:-1], parts[1:]):
             assert a[1] == b[0]
             np.testing.assert_array_equal(a[3], b[3])  # all ranks hold the same means
+        if means == "chain":  # the reference's own bits, on every rank
+            np.testing.assert_array_equal(parts[0][3], ref.cpu().numpy())
         np.testing.assert_allclose(parts[0][3], ref.cpu().numpy(), rtol=1e-6, atol=1e-12)
         same_ref = np.array_equal(parts[0][3], ref.cpu().numpy())
         for no_bounds in (False, True):
@@ -315,7 +339,7 @@ def test_hot_path_ranks_on_one_gpu(world, fmt, window):
             # thresholds of the chunks a rank holds
             for p in parts:
                 thr = p[2][no_bounds][1]
-                k0 = p[0] // _HP_CS
+                k0 = p[0] // cs
                 if p[1] > p[0]:
                     np.testing.assert_allclose(thr, w_thr[k0:k0 + len(thr)], rtol=1e-6 if not same_ref else 1e-11)
 

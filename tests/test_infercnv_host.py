@@ -42,19 +42,19 @@ def test_resolve_devices():
         T._resolve_devices(None, [8], 10, t8)
     with pytest.raises(ValueError):
         T._resolve_devices(None, [], 10, t8)
-    # n_jobs = the reference's worker count: k GPUs, capped by what exists; 1 = the current device
-    assert T._resolve_devices(4, None, 100, t8) == [0, 1, 2, 3]
-    assert T._resolve_devices(64, None, 100, t8) == list(range(8))
+    # n_jobs = the reference's worker count: k GPUs, the caller's current device first, capped by what exists
+    assert T._resolve_devices(4, None, 100, t8) == [3, 0, 1, 2]
+    assert T._resolve_devices(64, None, 100, t8) == [3, 0, 1, 2, 4, 5, 6, 7]
     assert T._resolve_devices(1, None, 100, t8) == [3]
     assert T._resolve_devices(4, None, 100, _FakeTorch(1)) == [0]
     # None: every GPU that gets at least four chunks
-    assert T._resolve_devices(None, None, 200, t8) == list(range(8))
-    assert T._resolve_devices(None, None, 9, t8) == [0, 1]
+    assert T._resolve_devices(None, None, 200, t8) == [3, 0, 1, 2, 4, 5, 6, 7]
+    assert T._resolve_devices(None, None, 9, t8) == [3, 0]
     assert T._resolve_devices(None, None, 3, t8) == [3]
     assert T._resolve_devices(None, None, 0, t8) == [3]
     # ... and 50 000 cells
-    assert T._resolve_devices(None, None, 200, t8, n_obs=1_000_000) == list(range(8))
-    assert T._resolve_devices(None, None, 200, t8, n_obs=120_000) == [0, 1]
+    assert T._resolve_devices(None, None, 200, t8, n_obs=1_000_000) == [3, 0, 1, 2, 4, 5, 6, 7]
+    assert T._resolve_devices(None, None, 200, t8, n_obs=120_000) == [3, 0]
     assert T._resolve_devices(None, None, 200, t8, n_obs=4000) == [3]
 
 
