@@ -371,6 +371,10 @@ int icv_csr_row_abs_sum(const void *data, int32_t dtype, const int64_t *indptr, 
 /* ---- misc --------------------------------------------------------------------------------- */
 const char *icv_last_error(void);
 int icv_version(void);
+/* The developer knobs (environment variables ICV_FORCE_GENERIC, ICV_NO_X16, ICV_NO_SD, ICV_WGS_PER_CU, ICV_WARD_IN_PLACE,
+ * ICV_WARD_COMPACT_X, ICV_PHASE_PROFILE: kernel routes / geometries for A/B timing and kernel-against-kernel tests) are
+ * read once, at the first dispatch; a process that changes them afterwards calls this to have them read again. */
+void icv_developer_knobs_reload(void);
 /* number of visible HIP devices (0 without a GPU); never fails */
 int icv_device_count(void);
 

@@ -33,7 +33,7 @@ EXPORTS = (
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
     "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_gather", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
     "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_last_error", "icv_version",
-    "icv_device_count",
+    "icv_device_count", "icv_developer_knobs_reload",
 )
 
 
@@ -126,11 +126,13 @@ def load():
     lib.icv_ward_finish.argtypes = [vp, vp, P(i32)]
     lib.icv_row_abs_sum.argtypes = [vp, i64, i32, i64, vp, vp]
     lib.icv_csr_row_abs_sum.argtypes = [vp, i32, vp, i64, vp, vp]
+    lib.icv_developer_knobs_reload.restype = None
+    lib.icv_developer_knobs_reload.argtypes = []
     lib.icv_last_error.restype = C.c_char_p
     lib.icv_last_error.argtypes = []
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("icv_plan_destroy", "icv_ward_destroy", "icv_last_error"):
+        if name not in ("icv_plan_destroy", "icv_ward_destroy", "icv_last_error", "icv_developer_knobs_reload"):
             fn.restype = C.c_int
     _lib = lib
     return lib

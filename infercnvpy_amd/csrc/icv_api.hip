@@ -43,6 +43,38 @@ int fail(int code, const std::string& msg) {
                                          hipGetErrorString(e_) + ")");                         \
     } while (0)
 
+// Developer knobs (environment variables that force a kernel route / geometry for A/B timing and for the tests that
+// compare the kernels with each other).  They are read ONCE, at the first dispatch, not on every call (a
+// getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
+// changes them calls icv_developer_knobs_reload().
+struct Knobs {
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place;
+    int wgs_per_cu;        // 0 = not set
+    double ward_compact_x; // 0 = not set
+    void load() {
+        force_generic = std::getenv("ICV_FORCE_GENERIC") != nullptr;
+        no_x16 = std::getenv("ICV_NO_X16") != nullptr;
+        no_sd = std::getenv("ICV_NO_SD") != nullptr;
+        phase_profile = std::getenv("ICV_PHASE_PROFILE") != nullptr;
+        ward_in_place = std::getenv("ICV_WARD_IN_PLACE") != nullptr;
+        const char* e = std::getenv("ICV_WGS_PER_CU");
+        wgs_per_cu = e ? std::atoi(e) : 0;
+        e = std::getenv("ICV_WARD_COMPACT_X");
+        ward_compact_x = e ? std::atof(e) : 0.0;
+    }
+};
+std::mutex g_knobs_mu;
+bool g_knobs_loaded = false;
+Knobs g_knobs;
+const Knobs& knobs() {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    if (!g_knobs_loaded) {
+        g_knobs.load();
+        g_knobs_loaded = true;
+    }
+    return g_knobs;
+}
+
 }  // namespace
 
 struct icv_plan_s {
@@ -91,6 +123,17 @@ struct icv_plan_s {
 };
 
 namespace {
+
+// grid of k_smooth_se (workgroups per CU from its LDS map; ICV_WGS_PER_CU: developer knob for occupancy experiments) --
+// ONE definition for the launch and for the count of per-workgroup partial-moment slots the thresholds read (ADVICE r3:
+// the two used to be computed separately and agreed only while kSeLds gave exactly two workgroups per CU)
+int64_t se_grid(const icv_plan_t pl, int64_t n_rows) {
+    int per_cu = icv::kLdsLimit / icv::kSeLds;
+    if (const int v = knobs().wgs_per_cu)
+        if (v >= 1 && v < per_cu) per_cu = v;
+    int64_t grid = (int64_t)pl->n_cu * per_cu;
+    return grid > n_rows ? n_rows : grid;
+}
 
 // one compute call at a time per plan (the plan owns the per-call workspace); released on scope exit
 struct PlanBusy {
@@ -346,7 +389,7 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
 int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const icv::KParams& K, hipStream_t st,
                int block = icv::NT) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (std::getenv("ICV_PHASE_PROFILE")) {
+    if (knobs().phase_profile) {
         // developer diagnostic: shader cycles per phase, summed over workgroups (thread 0 of each)
         unsigned long long* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, 32 * sizeof(unsigned long long)));
@@ -399,7 +442,7 @@ int run_kernel(void (*kern)(const icv::KParams), int64_t grid, int lds, const ic
 bool x16_applies(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay) {
     const icv::Plan& p = pl->p;
     return lay.fits && m->dtype == ICV_F32 && m->format == ICV_DENSE && p.ws_ok && K.vec_ok && std::isfinite(K.cap) &&
-           !std::getenv("ICV_FORCE_GENERIC") && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16") &&
+           !knobs().force_generic && p.x16_ok && !K.bounded && !knobs().no_x16 &&
            p.step == 10 &&
            ((p.B == 10 && p.window == 100 && p.x16_fine == 4096) || (p.B == 5 && p.window == 250 && p.x16_fine == 1024));
 }
@@ -455,7 +498,7 @@ int launch_hand_back(icv_plan_t pl, const icv::KParams& K, hipStream_t st, bool 
 // entries of |d| <= 2 cap each in S0 (units 2^-k0), sum of j |d| <= B (B - 1) / 2 * 2 cap in S1 (units 2^-k1).  Fewer
 // than 40 bits (a clip value beyond ~100) and the input takes the kernels that build the row in LDS.
 bool se_fraction_bits(const icv::Plan& p, double cap, int* k0, int* k1) {
-    if (!p.se_ok || std::getenv("ICV_NO_SD")) return false;  // ICV_NO_SD: developer knob, the kernels with a row in LDS
+    if (!p.se_ok || knobs().no_sd) return false;  // ICV_NO_SD: developer knob, the kernels with a row in LDS
     int e = 0;
     (void)std::frexp((double)p.B * 2.0 * cap + 1.0, &e);  // < 2^e
     const int a = 51 - e;
@@ -471,7 +514,7 @@ bool se_fraction_bits(const icv::Plan& p, double cap, int* k0, int* k1) {
 // set-up of icv_infercnv_run)
 bool stored_entries_kernel(const icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, const icv::Layout& lay) {
     if (!(lay.fits && m->dtype == ICV_F32 && m->format == ICV_CSR && std::isfinite(K.cap) &&
-          m->csr_end > m->csr_begin && !std::getenv("ICV_FORCE_GENERIC")))
+          m->csr_end > m->csr_begin && !knobs().force_generic))
         return false;
     int k0 = 0, k1 = 0;
     return se_fraction_bits(pl->p, K.cap, &k0, &k1);
@@ -506,13 +549,7 @@ int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t k
                        static_cast<const float*>(pl->d_zrow), pl->d_se_w0, pl->d_se_w1, wt_guard.as<icv::u32x4>(),
                        g_guard.as<double>(), K.sd_r);
     if (int rc = hand_back_workspace(pl, K, st)) return rc;
-    int per_cu = icv::kLdsLimit / icv::kSeLds;
-    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
-        const int v = std::atoi(e);
-        if (v >= 1 && v < per_cu) per_cu = v;
-    }
-    int64_t grid = (int64_t)pl->n_cu * per_cu;
-    if (grid > K.n_rows) grid = K.n_rows;
+    int64_t grid = se_grid(pl, K.n_rows);
     if (grid < 1) {
         if (kernel_done) HIP_TRY(hipEventRecord(kernel_done, st));
         return ICV_OK;
@@ -575,10 +612,8 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     }
     int per_cu = icv::kLdsLimit / lds;
     if (per_cu > 4) per_cu = 4;
-    if (const char* e = std::getenv("ICV_WGS_PER_CU")) {  // developer knob: occupancy experiments
-        const int v = std::atoi(e);
+    if (const int v = knobs().wgs_per_cu)  // developer knob: occupancy experiments
         if (v >= 1 && v < per_cu) per_cu = v;
-    }
     int64_t grid = (int64_t)pl->n_cu * per_cu;
     if (grid > K.n_rows) grid = K.n_rows;
     if (grid < 1) {
@@ -589,7 +624,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     // dense float32, one reference row, window 100 / step 10 or window 250 / step 10 geometry: the 16-wavefront
     // kernel, one 1024-thread workgroup per CU (ICV_NO_X16=1: developer knob, previous generation)
     void (*xk)(const icv::KParams) = nullptr;
-    if (!csr && p.x16_ok && !K.bounded && !std::getenv("ICV_NO_X16")) {
+    if (!csr && p.x16_ok && !K.bounded && !knobs().no_x16) {
         if (p.step != 10)
             xk = nullptr;  // the instantiations below assume step 10 (blocks between adjacent windows)
         else if (p.B == 10 && p.window == 100 && p.x16_fine == 4096)
@@ -731,7 +766,7 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
         pl->last_kernel = ICV_KERNEL_SPLIT;
         return smooth_split(pl, m, K, st);
     }
-    const bool fast_allowed = m->dtype == ICV_F32 && std::isfinite(K.cap) && !std::getenv("ICV_FORCE_GENERIC");
+    const bool fast_allowed = m->dtype == ICV_F32 && std::isfinite(K.cap) && !knobs().force_generic;
     if (fast_allowed && m->format == ICV_DENSE && pl->p.ws_ok && K.vec_ok) {
         const int rc = launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
         if (rc >= 0) {
@@ -868,6 +903,12 @@ extern "C" {
 
 const char* icv_last_error(void) { return g_err.c_str(); }
 int icv_version(void) { return 100; }
+
+void icv_developer_knobs_reload(void) {
+    std::lock_guard<std::mutex> lk(g_knobs_mu);
+    g_knobs.load();
+    g_knobs_loaded = true;
+}
 
 int icv_device_count(void) {
     int n = 0;
@@ -1178,9 +1219,11 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
             pl->hb_stats_cap = m->n_rows;
         }
         K.cell_stats = pl->d_hb_stats;
-        // k_smooth_x16: n_cu workgroups x 16 wavefronts; k_smooth_se: 2 n_cu workgroups x 8 wavefronts
-        const int64_t n_part = (int64_t)pl->n_cu * icv::XWAVE;
-        static_assert(icv::XWAVE == 2 * icv::NWAVE, "one partial-moment slot per wavefront of a CU");
+        // partial-moment slots per chunk: k_smooth_x16: n_cu workgroups x 16 wavefronts; k_smooth_se: its own grid
+        // (se_grid: whatever its LDS map allows per CU) x 8 wavefronts -- sized for the larger of the two
+        const int64_t se_slots = ((int64_t)pl->n_cu * (icv::kLdsLimit / icv::kSeLds)) * icv::NWAVE;
+        const int64_t x16_slots = (int64_t)pl->n_cu * icv::XWAVE;
+        const int64_t n_part = se_slots > x16_slots ? se_slots : x16_slots;
         if ((x16_applies(pl, m, K, *lay) || stored_entries_kernel(pl, m, K, *lay)) &&
             n_chunks * n_part <= (int64_t)(64 << 20) / 16) {
             chunk_mode = true;
@@ -1214,11 +1257,7 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
         // (k_smooth_se); slots of absent workgroups are zero
         int64_t n_slots;
         if (m->format == ICV_CSR) {
-            int64_t gx = 2 * (int64_t)pl->n_cu;
-            if (const char* e = std::getenv("ICV_WGS_PER_CU"))
-                if (std::atoi(e) == 1) gx = pl->n_cu;
-            if (gx > m->n_rows) gx = m->n_rows;
-            n_slots = gx * icv::NWAVE;
+            n_slots = se_grid(pl, m->n_rows) * icv::NWAVE;  // the grid launch_smooth_se used
         } else {
             int64_t gx = pl->n_cu;
             if (gx > m->n_rows) gx = m->n_rows;
@@ -1712,7 +1751,7 @@ int ward_create(int64_t n, const int32_t* sr_local, int32_t n_super, int32_t sup
     w->ld = ld;
     // the caller says whether columns [n, ld) of every row are the rounds' to use (never inferred from the stride: a
     // column slice of a wider buffer has a large stride too); ICV_WARD_IN_PLACE: developer knob, the other layout
-    w->strip = spare && !std::getenv("ICV_WARD_IN_PLACE");
+    w->strip = spare && !knobs().ward_in_place;
     w->cap = w->strip ? (int)std::min<int64_t>(ld, 2 * n) : (int)n;
     const size_t arr = ((size_t)n * 4 + 255) / 256 * 256;
     const size_t parr = ((size_t)w->cap * 4 + 255) / 256 * 256;  // arrays indexed by column position
@@ -1891,11 +1930,8 @@ int ward_pairs(icv_ward_s* w, float* D, int64_t ld, bool all_active, hipStream_t
     }
     {
         // developer knob: compaction threshold (positions per alive column), default 2
-        static const double thr = [] {
-            const char* e = std::getenv("ICV_WARD_COMPACT_X");
-            const double v = e ? std::atof(e) : 2.0;
-            return v >= 1.05 ? v : 2.0;
-        }();
+        const double kx = knobs().ward_compact_x;
+        const double thr = kx >= 1.05 ? kx : 2.0;
         if ((double)w->h.width > thr * (double)w->h.n_live && w->h.width > 4096)
             if (int rc = ward_compact(w, D, ld, st)) return rc;
     }

@@ -28,3 +28,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords and not has_gpu:
             item.add_marker(pytest.mark.skip(reason="no GPU in this container"))
+
+
+@pytest.fixture(autouse=True)
+def _reload_developer_knobs():
+    """The library reads its developer knobs (ICV_FORCE_GENERIC, ICV_NO_SD, ...) once; tests that switch kernels through
+    the environment call ``_lib.load().icv_developer_knobs_reload()`` after changing it, and this fixture re-reads the
+    (restored) environment after every test so that no knob leaks into the next one."""
+    yield
+    try:
+        from infercnvpy_amd import _lib
+
+        if _lib._lib is not None:
+            _lib._lib.icv_developer_knobs_reload()
+    except Exception:
+        pass

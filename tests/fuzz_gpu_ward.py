@@ -42,10 +42,12 @@ def one_case(seed):
     os.environ.pop("ICV_WARD_IN_PLACE", None)
     if seed % 2:
         os.environ["ICV_WARD_IN_PLACE"] = "1"
+    T._knobs()  # (the library reads its developer knobs once)
     try:
         Z = cnv.tl.ward_linkage(X)
     finally:
         os.environ.pop("ICV_WARD_IN_PLACE", None)
+        T._knobs()
     Zs = O.ward_linkage(X)
     assert Z.shape == Zs.shape == (n - 1, 4), desc
     assert is_valid_linkage(Z), desc

@@ -24,6 +24,13 @@ ATOL = 1e-5       # the stated tolerance
 ATOL_TIGHT = 1e-6  # what float32 storage of |x| <= 3 actually allows (ulp(3)/2 = 1.2e-7)
 
 
+def _knobs():
+    """Have the library re-read its developer knobs (they are read once; this test has just changed the environment)."""
+    from infercnvpy_amd import _lib
+
+    _lib.load().icv_developer_knobs_reload()
+
+
 def _adata(g):
     from infercnvpy_amd._compat import SimpleAnnData
 
@@ -75,6 +82,7 @@ def test_sparse_float32_goldens_take_the_stored_entries_kernel(name, monkeypatch
     _, res, _ = cnv.tl.infercnv(_adata(g), inplace=False, _timings=tm, **g.api_kwargs())
     assert tm["kernel"] == _lib.ICV_KERNEL_SD
     monkeypatch.setenv("ICV_NO_SD", "1")
+    _knobs()
     tm2 = {}
     _, res2, _ = cnv.tl.infercnv(_adata(g), inplace=False, _timings=tm2, **g.api_kwargs())
     assert tm2["kernel"] in (_lib.ICV_KERNEL_WS_CSR, _lib.ICV_KERNEL_GENERIC)
@@ -409,10 +417,12 @@ def test_fast_and_generic_kernels_are_bit_identical(monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
+        _knobs()
         res = _engine.run_hot_path(plan, dm, ref, chunksize=300, cell_stats=stats)
         torch.cuda.synchronize()
         for k in env:
             monkeypatch.delenv(k)
+        _knobs()
         return res
 
     for genes, window, step in ((cases.GENES_PER_CHROM_20K, 100, 10), (cases.GENES_PER_CHROM_20K, 250, 10),
@@ -903,8 +913,10 @@ def test_ward_column_layouts_agree(n, d, monkeypatch):
     xd = torch.from_numpy(X).cuda()
     Zs, rs = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, spare=True), spare=True)  # n / 2 spare columns
     monkeypatch.setenv("ICV_WARD_IN_PLACE", "1")
+    _knobs()
     Zi, ri = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, spare=True), spare=True)
     monkeypatch.delenv("ICV_WARD_IN_PLACE")
+    _knobs()
     d2 = torch.empty((n, (n + 3) // 4 * 4), dtype=torch.float32, device="cuda")[:, :n]
     Zn, rn = _engine.ward_linkage(_engine.pairwise_sqeuclidean(xd, out=d2))
     # a column slice of a wider buffer: without the spare flag nothing outside the n x n block is touched

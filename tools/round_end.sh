@@ -1,0 +1,44 @@
+#!/bin/bash
+# Evidence run on the GPU box (one gpurun call): tests, smoke, the default bench line (stages, e2e, extra legs), rocprofv3
+# kernel statistics of the bench step / config 4 / CSR window 100 / config 5, PMC passes (FETCH_SIZE and WRITE_SIZE in
+# separate runs, --kernel-trace only; instruction mix), the N-rank dry run on one GPU.
+#   ROUND=r04 tools/round_end.sh [quick]      -> gpurun_out/${ROUND}final/   (copy what is to be judged into profiles/)
+set -u
+REPO=$PWD
+ROUND=${ROUND:-r04}
+O=$REPO/gpurun_out/${ROUND}final; mkdir -p $O
+export TMPDIR=/tmp
+python -c "import torch; print(torch.cuda.get_device_name(0), torch.cuda.device_count())" > $O/box.txt 2>&1
+if [ "${1:-}" != "quick" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $O/pytest.txt
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee $O/smoke.txt
+fi
+( time timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err ) 2> $O/bench_n1.time; tail -c 300 $O/bench_n1.json; tail -3 $O/bench_n1.time
+timeout 300 python bench.py --gpus 2 --dry-run-one-gpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_dry_run_2ranks_one_gpu.json
+timeout 600 python bench.py --gpus 8 --dry-run-one-gpu --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_dry_run_8ranks_one_gpu.json
+stats() {  # name, bench.py arguments...
+  name=$1; shift
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_s_$name -o bench -- python $REPO/bench.py "$@" > $O/bench_${name}_traced.json 2> $O/rocprof_$name.log)
+  find $O/_s_$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_$name.csv
+  rm -rf $O/_s_$name
+  head -6 $O/kernel_stats_$name.csv | cut -c1-150
+}
+BASE="--no-cpu-baseline --no-e2e --no-extra"
+stats dense_w100 --steps 20 --warmup 3 $BASE
+stats csr_w250 --format csr --cells 500000 --window 250 --steps 5 --warmup 2 $BASE
+stats csr_w100 --format csr --cells 200000 --window 100 --steps 5 --warmup 2 $BASE
+stats config5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --extra config5
+pmc() {  # label, bench.py arguments...
+  label=$1; shift
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+    name=$(echo $grp | cut -d' ' -f1)
+    (cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/_p -o pmc -- python $REPO/bench.py "$@" > $O/pmc_${label}_$name.log 2>&1)
+    f=$(find $O/_p -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && (echo "== $label --pmc $grp"; python $REPO/tools/summarize_pmc.py "$f") | tee -a $O/pmc_summary.txt | head -40
+    rm -rf $O/_p
+  done
+}
+pmc dense_w100_100000_cells --steps 2 --warmup 1 $BASE
+pmc csr_w250_500000_cells --format csr --cells 500000 --window 250 --steps 2 --warmup 1 $BASE
+pmc csr_w100_200000_cells --format csr --cells 200000 --window 100 --steps 2 --warmup 1 $BASE
+find $O -name "*.db" -delete 2>/dev/null
