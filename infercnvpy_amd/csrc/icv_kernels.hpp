@@ -1588,8 +1588,10 @@ __global__ void __launch_bounds__(256) k_csr_row_abs_sum(const T* data, const in
     if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
 }
 
-// indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r]: ONE 1024-thread workgroup (the counts of a piece are a
-// few hundred KB: the scan is a ~10 us epilogue of the mask pass, not worth a multi-workgroup scheme)
+// indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r]: ONE 1024-thread workgroup, 16 consecutive counts per
+// thread and sweep (16 384 rows per sweep: the counts of a piece are a few hundred KB, the scan is a ~15 us epilogue of
+// the mask pass, not worth a multi-workgroup scheme)
+constexpr int kScanPer = 16;
 __global__ void __launch_bounds__(1024) k_row_offsets(const int64_t* __restrict__ row_nnz, int64_t n_rows,
                                                       int64_t* __restrict__ indptr) {
     __shared__ long long wsum[16];
@@ -1600,18 +1602,20 @@ __global__ void __launch_bounds__(1024) k_row_offsets(const int64_t* __restrict_
         indptr[0] = 0;
     }
     __syncthreads();
-    for (int64_t r0 = 0; r0 < n_rows; r0 += 4096) {  // four consecutive counts per thread
-        long long v[4], s = 0;
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 1024 * kScanPer) {
+        long long v[kScanPer], s = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t r = r0 + 4 * t + k;
+        for (int k = 0; k < kScanPer; ++k) {
+            const int64_t r = r0 + (int64_t)kScanPer * t + k;
             v[k] = r < n_rows ? row_nnz[r] : 0;
-            s += v[k];
         }
+#pragma unroll
+        for (int k = 0; k < kScanPer; ++k) s += v[k];
         long long incl = s;  // inclusive scan of the threads' sums over the wavefront
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const unsigned lo = (unsigned)__shfl_up((int)(unsigned)incl, o), hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)incl >> 32), o);
+            const unsigned lo = (unsigned)__shfl_up((int)(unsigned)incl, o);
+            const unsigned hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)incl >> 32), o);
             if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
         }
         if (lane == 63) wsum[wave] = incl;
@@ -1620,8 +1624,8 @@ __global__ void __launch_bounds__(1024) k_row_offsets(const int64_t* __restrict_
         for (int w = 0; w < wave; ++w) before += wsum[w];
         long long run = before + incl - s;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t r = r0 + 4 * t + k;
+        for (int k = 0; k < kScanPer; ++k) {
+            const int64_t r = r0 + (int64_t)kScanPer * t + k;
             run += v[k];
             if (r < n_rows) indptr[r + 1] = run;
         }
