@@ -18,7 +18,8 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           device CSR float64.
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
   N > 1   one process per GPU over the rows of config 3: float64 column sums + ONE RCCL all-reduce of [G + 1] float64
-          -> the same smoothing kernel -> per-chunk std -> in-place threshold (dist.run_shard).
+          -> the same smoothing kernel -> per-chunk std -> noise threshold + CSR pack (dist.run_shard(pack=True)): the
+          public call's work per rank, with the all-reduce in place of the sequential reference-order chains.
   N > 1   BASELINE config 3: 1 000 000 cells x 20 000 genes in total, row shards aligned to the 5000-cell chunks
           (dist.shard_bounds; 125 000 cells per GPU at N = 8): strong scaling.  Every 5000-cell chunk is generated
           from its own seed, so the data do not depend on N.
@@ -333,7 +334,7 @@ def pmc_traffic(key, cells):
 
 
 def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksize, steps, warmup, dist=None,
-             bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None):
+             bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None, pack=False):
     """Time `steps` passes of the hot path over the resident rows of `dm`; returns (seconds, roofline dict)."""
     n_total = n_local if n_total is None else n_total
     W = plan.n_windows
@@ -353,7 +354,7 @@ def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksiz
         # no host synchronisation inside a step: the library records HIP events around the smoothing kernel on
         # the launch stream (icv_profile_begin) and the times are read after the timed region
         return icd.run_shard(plan, dm, ref, global_row0=row0, n_obs_global=n_total, lfc_clip=3.0,
-                             dynamic_threshold=1.5, chunksize=chunksize, all_bounds=bounds, out=out)
+                             dynamic_threshold=1.5, chunksize=chunksize, all_bounds=bounds, out=out, pack=pack)
 
     def fence():
         torch.cuda.synchronize()
@@ -704,9 +705,12 @@ def main():
         stages["x_cnv_nnz_public_call"] = nnz_out
         ad = None
     else:
+        # N > 1: the same per-rank work as the public call (thresholds applied while X_cnv is packed to device CSR), with
+        # the reference means from float64 sums + ONE all-reduce instead of the sequential reference-order chains
         dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
                             args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
-                            no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key)
+                            no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key,
+                            pack=not args.engine_step)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -757,7 +761,9 @@ def main():
                         + ("; step = one cnv.tl.infercnv(adata) call, adata.X a CUDA tensor, X_cnv returned as device "
                            "CSR float64 (reference-order means, smoothing, noise threshold + CSR pack)"
                            if stages is not None else
-                           "; step = float64 column sums (+ all-reduce) + smoothing + in-place threshold (dist.run_shard)"),
+                           "; step = float64 column sums (+ all-reduce) + smoothing + thresholds "
+                           + ("applied while X_cnv is packed to device CSR (dist.run_shard(pack=True))" if not args.engine_step
+                              else "applied in place (dist.run_shard)")),
             "io_dtype": "f32 matrix in, f32 x_res out",
             "cells_total": n_total,
             "cells_per_gpu": [b - a for a, b in bounds],

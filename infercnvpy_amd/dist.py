@@ -220,7 +220,7 @@ def agree_aligned(local_aligned: bool, device="cpu", group=None) -> bool:
 
 
 def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_global=None, lfc_clip=3.0,
-              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None, all_bounds=None, out=None):
+              dynamic_threshold=1.5, chunksize=5000, flags=0, group=None, all_bounds=None, out=None, pack=False):
     """Hot path for this rank's rows of a row-sharded matrix (device resident).
 
     Whether the noise threshold needs communication is a property of the WHOLE partition, and every rank must
@@ -229,7 +229,9 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
     without it the ranks agree through a one-element all-reduce.  Chunk-aligned partitions need no further
     communication; otherwise the smoothing kernel runs first, the chunk moments of ALL ranks (aligned ones
     included) are all-reduced and the thresholds applied.
-    Returns the local :class:`infercnvpy_amd._engine.SmoothResult`.
+    Returns the local :class:`infercnvpy_amd._engine.SmoothResult`; with ``pack=True`` ``(result, PackedCsr)``: the
+    thresholds are applied while ``X_cnv`` is packed to CSR on the device (``_engine.threshold_csr``; ``result.out``
+    stays un-thresholded), as the public call does.
     """
     import ctypes as C
 
@@ -244,8 +246,13 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
         if dynamic_threshold is not None:
             aligned = agree_aligned(aligned, ref_lo.device if hasattr(ref_lo, "device") else "cpu", group)
     if dynamic_threshold is None or aligned:
-        return _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip,
-                                    dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags, out=out)
+        res = _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip,
+                                   dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags, out=out,
+                                   apply=not pack)
+        if not pack:
+            return res
+        return res, _engine.threshold_csr(plan, dm_local, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                                          flags=flags)
     torch = _engine._torch()
     lib = _lib.load()
     res = _engine.run_hot_path(plan, dm_local, ref_lo, ref_hi, lfc_clip=lfc_clip, dynamic_threshold=None,
@@ -254,16 +261,20 @@ def run_shard(plan, dm_local, ref_lo, ref_hi=None, *, global_row0=0, n_obs_globa
                                 float(dynamic_threshold), group)
     if rows == 0:
         res.thr = thr_all[:0]
-        return res
+        return (res, _engine.threshold_csr(plan, dm_local, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                                           flags=flags)) if pack else res
     k0 = global_row0 // chunksize
     k1 = (global_row0 + rows - 1) // chunksize
     thr = thr_all[k0:k1 + 1].contiguous()
+    res.thr = thr
+    if pack:  # the global thresholds decide while the rows are packed
+        return res, _engine.threshold_csr(plan, dm_local, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
+                                          row_phase=int(global_row0 % chunksize), flags=flags)
     m = dm_local.c_struct()
     _lib.check(lib.icv_apply_threshold(
         plan.handle, C.byref(m), _engine._ptr(ref_lo), _engine._ptr(ref_hi), float(lfc_clip), int(flags),
         _engine._ptr(res.out), res.out.stride(0), _engine._ptr(res.cell_median), _engine._ptr(thr), int(chunksize),
         int(global_row0 % chunksize), _engine._stream_ptr(torch)))
-    res.thr = thr
     return res
 
 

@@ -63,11 +63,11 @@ def one_case(seed):
     X[rows[5], : G // 2] = 0
     Xin = sp.csr_matrix(X) if fmt == "csr" else X
     if ref_kind == "none":
-        ref = T._oracle_means(Xin)  # the reference's own mean of the matrix as stored
+        ref = np.asarray(O.reference_profile(Xin, None, None, None, G))  # the reference's own mean of the matrix as stored
     elif ref_kind in ("cat1", "cat2"):
         cats = ["a"] if ref_kind == "cat1" else ["b", "c"]
         api.update(reference_key="group", reference_cat=cats if len(cats) > 1 else cats[0])
-        ref = T._oracle_means(Xin, labels, cats)
+        ref = np.asarray(O.reference_profile(Xin, labels, cats, None, G))
     var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
     ad = SimpleAnnData(Xin, obs=pd.DataFrame({"group": labels}), var=var)
     tm = {}

@@ -234,6 +234,15 @@ def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window, geo
         res = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=n_all, chunksize=cs, all_bounds=ab)
         torch.cuda.synchronize()
         outs[ab is None] = (res.out.cpu().numpy(), None if res.thr is None else res.thr.cpu().numpy())
+    # the same shard with the thresholds applied while X_cnv is packed to device CSR (what bench.py --gpus N times)
+    if r1 > r0:
+        import scipy.sparse as sp
+
+        _, pk = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=n_all, chunksize=cs, all_bounds=bounds,
+                              pack=True)
+        got, exp = pk.to_scipy(), sp.csr_matrix(outs[False][0].astype(np.float64))
+        assert np.array_equal(got.indptr, exp.indptr) and np.array_equal(got.indices, exp.indices)
+        assert np.array_equal(got.data, exp.data)
     return r0, r1, outs, ref.cpu().numpy()
 
 
