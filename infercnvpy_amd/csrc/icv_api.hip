@@ -21,6 +21,7 @@
 #include "icv_kernel_x16.hpp"
 #include "icv_kernel_se.hpp"
 #include "icv_kernel_chain.hpp"
+#include "icv_kernel_pack.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -48,7 +49,7 @@ int fail(int code, const std::string& msg) {
 // getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
-    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place;
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring;
     int wgs_per_cu;        // 0 = not set
     double ward_compact_x; // 0 = not set
     void load() {
@@ -57,6 +58,7 @@ struct Knobs {
         no_sd = std::getenv("ICV_NO_SD") != nullptr;
         phase_profile = std::getenv("ICV_PHASE_PROFILE") != nullptr;
         ward_in_place = std::getenv("ICV_WARD_IN_PLACE") != nullptr;
+        no_mask_ring = std::getenv("ICV_NO_MASK_RING") != nullptr;
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_WARD_COMPACT_X");
@@ -87,6 +89,7 @@ struct icv_plan_s {
     double* d_wdenom = nullptr;
     int32_t* d_pad = nullptr;
     int32_t* d_wpack = nullptr;
+    unsigned* d_tie_n = nullptr;  // k_thr_mask_ring's tie counter + k_thr_mask_ties' done counter (zero between calls)
     int32_t *d_cov_col = nullptr, *d_cov_j0 = nullptr, *d_cov_cnt = nullptr;
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
@@ -238,6 +241,10 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.w_denom.data(), p.w_denom.size() * 8, (void**)&pl->d_wdenom));
     HIP_TRY(up(p.pad_idx.data(), p.pad_idx.size() * 4, (void**)&pl->d_pad));
     HIP_TRY(up(p.w_pack.data(), p.w_pack.size() * 4, (void**)&pl->d_wpack));
+    {
+        const unsigned zeros[2] = {0u, 0u};
+        HIP_TRY(up(zeros, sizeof(zeros), (void**)&pl->d_tie_n));
+    }
     HIP_TRY(up(p.cov_col.data(), p.cov_col.size() * 4, (void**)&pl->d_cov_col));
     HIP_TRY(up(p.cov_j0.data(), p.cov_j0.size() * 4, (void**)&pl->d_cov_j0));
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
@@ -948,6 +955,7 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_wdenom);
         (void)hipFree(pl->d_pad);
         (void)hipFree(pl->d_wpack);
+        (void)hipFree(pl->d_tie_n);
         (void)hipFree(pl->d_cov_col);
         (void)hipFree(pl->d_cov_j0);
         (void)hipFree(pl->d_cov_cnt);
@@ -1403,6 +1411,39 @@ int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
     const int n_words = (pl->p.W + 63) / 64;
     const int64_t cs = thr ? chunksize : 1;
     auto* mk = reinterpret_cast<unsigned long long*>(mask);
+    // streamed form (k_thr_mask_ring: rows through an LDS ring by LDS-DMA, one persistent workgroup per CU) where the
+    // rows are 16-byte aligned and at least 1 KB; else one workgroup per row
+    const icv::PackRing pr(pl->p.W);
+    const bool ring = !knobs().no_mask_ring && pr.ok && (ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
+    if (ring) {
+        const int lds = pr.lds_bytes();
+        const int64_t rounds = (K.n_rows + icv::kPmRows - 1) / icv::kPmRows;
+        const unsigned gx = (unsigned)(rounds < pl->n_cu ? rounds : pl->n_cu);
+        AsyncBuf ties;  // (row, wavefront part) pairs whose windows float32 could not decide
+        if (thr) HIP_TRY(ties.alloc((size_t)K.n_rows * icv::kPmPerRow * sizeof(unsigned long long), st));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_thr_mask_ring),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, icv::kPmLds));  // (per device: every call)
+        hipLaunchKernelGGL(icv::k_thr_mask_ring, dim3(gx), dim3(icv::kPmThreads), lds, st, K, thr, cs, row_phase, mk, n_words,
+                           row_nnz, pl->d_tie_n, ties.as<unsigned long long>());
+        if (thr) {
+            dim3 tg(128), tb(256);
+            const auto* tl = ties.as<unsigned long long>();
+            if (m->dtype == ICV_F32) {
+                if (m->format == ICV_DENSE)
+                    hipLaunchKernelGGL((icv::k_thr_mask_ties<float, false>), tg, tb, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz, pl->d_tie_n, tl);
+                else
+                    hipLaunchKernelGGL((icv::k_thr_mask_ties<float, true>), tg, tb, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz, pl->d_tie_n, tl);
+            } else {
+                if (m->format == ICV_DENSE)
+                    hipLaunchKernelGGL((icv::k_thr_mask_ties<double, false>), tg, tb, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz, pl->d_tie_n, tl);
+                else
+                    hipLaunchKernelGGL((icv::k_thr_mask_ties<double, true>), tg, tb, 0, st, K, thr, cs, row_phase, mk, n_words, row_nnz, pl->d_tie_n, tl);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return ICV_OK;
+    }
     dim3 grid((unsigned)K.n_rows), block(256);
     if (m->dtype == ICV_F32) {
         if (m->format == ICV_DENSE)
@@ -1475,8 +1516,12 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
 
 int icv_row_offsets(const int64_t* row_nnz, int64_t n_rows, int64_t* indptr, void* stream) {
     if (!row_nnz || !indptr || n_rows < 0) return fail(ICV_ERR_INVALID, "bad row_offsets arguments");
-    hipLaunchKernelGGL(icv::k_row_offsets, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), row_nnz, n_rows,
-                       indptr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned nb = (unsigned)((n_rows + icv::kScanBlock - 1) / icv::kScanBlock);
+    AsyncBuf sums;
+    HIP_TRY(sums.alloc((size_t)(nb ? nb : 1) * sizeof(int64_t), st));
+    if (nb > 1) hipLaunchKernelGGL(icv::k_row_block_sums, dim3(nb), dim3(1024), 0, st, row_nnz, n_rows, sums.as<int64_t>());
+    hipLaunchKernelGGL(icv::k_row_offsets, dim3(nb ? nb : 1), dim3(1024), 0, st, row_nnz, n_rows, sums.as<int64_t>(), indptr);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

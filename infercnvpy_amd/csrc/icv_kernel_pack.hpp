@@ -1,0 +1,451 @@
+// Step 5b (noise threshold) as a keep-mask, streamed: k_thr_mask_ring.
+//
+// The round-3 kernel k_thr_mask (one short-lived 256-thread workgroup per row, eight 4-byte loads per thread in flight)
+// reads x_res at 3 TB/s; every variant that gave a wavefront more loads in flight came out slower
+// (profiles/r04_pack_experiments.txt).  What does stream at 6.3 TB/s on this chip is the structure of k_colchain: ONE
+// persistent 1024-thread workgroup per CU whose loader wavefronts copy rows HBM -> LDS with LDS-DMA (no registers, no
+// ds_write, the ring IS the bytes in flight -- and with ~5 us of latency under load a CU needs ~130 KB of them) while the
+// other wavefronts work on the rows that have landed.  Here: rows are packed into the ring at their own length (rounded
+// to 16 bytes), two rows per round, every slot but the one being read in flight; four loader wavefronts share the 1 KB
+// pieces of a round; twelve consumer wavefronts -- six per row, each a contiguous run of mask words -- read the windows
+// from LDS 64 at a time (a ballot IS a mask word), decide them as k_thr_mask does (float32 decides; a window within one
+// ulp of the threshold is flagged and recomputed in float64 from the input, canonical order) and write the row's mask
+// words and kept count.
+#pragma once
+#include <type_traits>
+
+#include "icv_kernel_chain.hpp"
+
+namespace icv {
+
+constexpr int kPmThreads = 1024;
+#ifndef ICV_PM_LOADERS
+#define ICV_PM_LOADERS 4
+#endif
+constexpr int kPmLoaders = ICV_PM_LOADERS;                     // loader wavefronts
+constexpr int kPmConsumers = kPmThreads / 64 - kPmLoaders;     // 12
+#ifndef ICV_PM_ROWS
+#define ICV_PM_ROWS 4
+#endif
+constexpr int kPmRows = ICV_PM_ROWS;                          // rows per round
+constexpr int kPmPerRow = kPmConsumers / kPmRows;              // consumer wavefronts per row
+constexpr int kPmMaxSlots = 16;
+constexpr int kPmMaxPer = 8;                                   // LDS-DMA loads per loader and round, at most
+constexpr int kPmLds = 160 * 1024;
+
+// wait until at most n LDS-DMA loads of this wavefront are outstanding (n wave-uniform, < 64)
+__device__ __forceinline__ void pm_wait_vmcnt(int n) {
+    switch (n) {
+#define ICV_PM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define ICV_PM_W8(B) ICV_PM_W(B) ICV_PM_W(B + 1) ICV_PM_W(B + 2) ICV_PM_W(B + 3) ICV_PM_W(B + 4) ICV_PM_W(B + 5) ICV_PM_W(B + 6) ICV_PM_W(B + 7)
+        ICV_PM_W(1) ICV_PM_W(2) ICV_PM_W(3) ICV_PM_W(4) ICV_PM_W(5) ICV_PM_W(6) ICV_PM_W(7)
+        ICV_PM_W(8) ICV_PM_W(9) ICV_PM_W(10) ICV_PM_W(11) ICV_PM_W(12) ICV_PM_W(13) ICV_PM_W(14) ICV_PM_W(15)
+        ICV_PM_W(16) ICV_PM_W(17) ICV_PM_W(18) ICV_PM_W(19) ICV_PM_W(20) ICV_PM_W(21) ICV_PM_W(22) ICV_PM_W(23)
+        ICV_PM_W(24) ICV_PM_W(25) ICV_PM_W(26) ICV_PM_W(27) ICV_PM_W(28) ICV_PM_W(29) ICV_PM_W(30) ICV_PM_W(31)
+        ICV_PM_W(32) ICV_PM_W(33) ICV_PM_W(34) ICV_PM_W(35) ICV_PM_W(36) ICV_PM_W(37) ICV_PM_W(38) ICV_PM_W(39)
+        ICV_PM_W(40) ICV_PM_W(41) ICV_PM_W(42) ICV_PM_W(43) ICV_PM_W(44) ICV_PM_W(45) ICV_PM_W(46) ICV_PM_W(47)
+        ICV_PM_W(48) ICV_PM_W(49) ICV_PM_W(50) ICV_PM_W(51) ICV_PM_W(52) ICV_PM_W(53) ICV_PM_W(54) ICV_PM_W(55)
+        ICV_PM_W(56) ICV_PM_W(57) ICV_PM_W(58) ICV_PM_W(59) ICV_PM_W(60)
+#undef ICV_PM_W8
+#undef ICV_PM_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// A wave-uniform double through the scalar cache.  gfx9 counts vector loads AND stores in one in-order counter (vmcnt):
+// a wavefront that stores and then waits for a later vector load waits for the store's acknowledgement from memory
+// (several microseconds under load).  The consumers below store a row's mask words every round, so nothing they read
+// may come through the vector memory path: rows come from LDS, the threshold from here.
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // a wave-uniform value into scalar registers
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double scalar_load_f64(const double* p) {
+    p = reinterpret_cast<const double*>(uniform_i64(reinterpret_cast<int64_t>(p)));
+    double v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
+// row count += v by one lane (plain instruction: the compiler's atomic optimiser would wrap a loop over the lanes around it)
+__device__ __forceinline__ void atomic_add_i64_noret(int64_t* p, int64_t v) {
+    p = reinterpret_cast<int64_t*>(uniform_i64(reinterpret_cast<int64_t>(p)));
+    asm volatile("global_atomic_add_x2 %0, %1, %2" ::"v"(0u), "v"(v), "s"(p) : "memory");
+}
+
+// Geometry of the ring for rows of W float32 (host and device agree through this struct)
+struct PackRing {
+    int row_bytes, row_stride, n_ld, per_loader, n_slots;
+    int stage_block, stage_cnt_off;  // per parity: the round's mask words, then its kept counts (one per row and part)
+    bool ok;
+    __host__ __device__ explicit PackRing(int W) {
+        const int n_words = (W + 63) / 64;
+        stage_cnt_off = (kPmRows * n_words * 8 + 15) / 16 * 16;
+        stage_block = stage_cnt_off + (kPmRows * kPmPerRow * 4 + 15) / 16 * 16;
+        row_bytes = W * 4;
+        row_stride = (row_bytes + 15) / 16 * 16;
+        n_ld = (row_bytes + 1023) / 1024;                                       // 1 KB pieces per row
+        per_loader = (kPmRows * n_ld + kPmLoaders - 1) / kPmLoaders;            // LDS-DMA loads per loader and round
+        // the last piece of a slot's last row may write up to 1 KB - 16 past the row: lanes past the row are masked off,
+        // so the ring needs no slack
+        int s = (kPmLds - 2 * stage_block) / (kPmRows * row_stride);
+        if (s > kPmMaxSlots) s = kPmMaxSlots;
+        while (s > 2 && (s - 1) * per_loader > 60) --s;
+        n_slots = s;
+        ok = s >= 2 && (s - 1) * per_loader <= 60 && per_loader <= kPmMaxPer && row_bytes >= 1024 && n_words <= 64 * kPmPerRow;
+    }
+    __host__ __device__ int lds_bytes() const { return n_slots * kPmRows * row_stride + 2 * stage_block;
+    }
+};
+
+// LDS-DMA with a scalar base: 16 bytes per lane from base + off (off per lane, bytes) to lds_base + 16 * lane
+__device__ __forceinline__ void lds_dma16_s(const void* base, unsigned off, unsigned lds_base) {
+    // (the compiler keeps some wave-uniform values in vector registers and does not legalise asm operands)
+    base = reinterpret_cast<const void*>(uniform_i64(reinterpret_cast<int64_t>(base)));
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(base), "s"(lds_base)
+        : "memory");
+}
+
+// One mask word of the consumer loop below: y = the window's bits, lo / span the threshold as patterns (see there).
+// The lane masks come straight from the compares; word T of the wavefront goes to lane T of (mine_lo, mine_hi).
+#define ICV_PM_WORD(T, Y)                                                                                              \
+    {                                                                                                                  \
+        const unsigned d_ = ((Y) & 0x7fffffffu) - lo;                                                                  \
+        const unsigned long long m_ = __builtin_amdgcn_sicmp((int)d_, 0, 39 /* >= */);                                 \
+        tie_any |= __builtin_amdgcn_uicmp(d_, span, 37 /* <= */);                                                      \
+        kept += __builtin_popcountll(m_);                                                                              \
+        asm volatile("v_writelane_b32 %0, %1, " #T : "+v"(mine_lo) : "s"((unsigned)m_));                               \
+        asm volatile("v_writelane_b32 %0, %1, " #T : "+v"(mine_hi) : "s"((unsigned)(m_ >> 32)));                       \
+    }
+
+// mask: n_rows x n_words uint64 (bit j & 63 of word j >> 6 = window j kept), row_nnz: kept windows of the row.
+// tie_n (zero on entry) / tie_list (n_rows * kPmPerRow entries): the (row, wavefront part) pairs with undecided windows.
+// grid = CUs (fewer rounds: fewer workgroups); dynamic LDS = PackRing::lds_bytes().
+// Rows of `out` start on 16-byte boundaries (the caller checks; else the round-3 kernel runs).
+__global__ void __launch_bounds__(kPmThreads) k_thr_mask_ring(const KParams P, const double* thr, int64_t chunksize,
+                                                              int64_t row_phase, unsigned long long* mask, int n_words,
+                                                              int64_t* row_nnz, unsigned* tie_n, unsigned long long* tie_list) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const PackRing g(P.W);
+    const int64_t total_rounds = (P.n_rows + kPmRows - 1) / kPmRows;
+    const int64_t n_mine = total_rounds > blockIdx.x ? (total_rounds - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int slot_bytes = kPmRows * g.row_stride;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const bool has_thr = thr != nullptr;
+    const int64_t stride_rows = (int64_t)gridDim.x * kPmRows;  // rows between two rounds of this workgroup
+    // A SIMD issues one vector AND one scalar instruction per four cycles, shared by the four wavefronts it hosts here:
+    // everything per round is kept incremental (no division, no 64-bit multiply), in both roles.
+
+    if (wave < kPmLoaders) {
+        // ---- loaders: the round's kPmRows * n_ld pieces dealt round robin; every loader issues per_loader loads a round
+        // (a loader short of pieces repeats piece 0 of row 0: same bytes to the same place).  The piece table does not
+        // change from round to round.
+        unsigned p_dst[kPmMaxPer], p_off[kPmMaxPer];
+        int p_row[kPmMaxPer];
+        bool p_on[kPmMaxPer];
+#pragma unroll
+        for (int t = 0; t < kPmMaxPer; ++t) {
+            int q = t * kPmLoaders + wave;
+            if (q >= kPmRows * g.n_ld) q = 0;
+            const int r = q / g.n_ld, piece = q - r * g.n_ld;
+            p_row[t] = r;
+            p_dst[t] = (unsigned)r * (unsigned)g.row_stride + (unsigned)piece * 1024u;
+            p_off[t] = (unsigned)(piece * 64 + lane) * 16u;
+            // the piece that holds the row's last windows may run past W: it stays inside the row's ldo
+            p_on[t] = t < g.per_loader && (int)p_off[t] < g.row_bytes;
+        }
+        const int64_t row_step_bytes = P.ldo * 4;
+        const unsigned char* issue_base = reinterpret_cast<const unsigned char*>(P.out) + (int64_t)blockIdx.x * kPmRows * row_step_bytes;
+        int64_t issue_row0 = (int64_t)blockIdx.x * kPmRows;
+        int issue_slot = 0;
+        const auto issue = [&]() {
+            const unsigned slot_lds = lds0 + (unsigned)issue_slot * (unsigned)slot_bytes;
+            const unsigned char* rb[kPmRows];
+#pragma unroll
+            for (int r = 0; r < kPmRows; ++r)  // (past the last row: row 0 of the round again, never decided)
+                rb[r] = issue_row0 + r < P.n_rows ? issue_base + r * row_step_bytes : issue_base;
+#pragma unroll
+            for (int t = 0; t < kPmMaxPer; ++t) {
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_PM_EXP_NOLOAD)
+                continue;
+#endif
+                if (t < g.per_loader) {  // (uniform)
+                    const unsigned char* base = rb[0];
+#pragma unroll
+                    for (int r = 1; r < kPmRows; ++r) base = p_row[t] == r ? rb[r] : base;
+                    if (p_on[t]) lds_dma16_s(base, p_off[t], slot_lds + p_dst[t]);
+                }
+            }
+            issue_slot = issue_slot + 1 == g.n_slots ? 0 : issue_slot + 1;
+            issue_base += stride_rows * row_step_bytes;
+            issue_row0 += stride_rows;
+        };
+        const int D = g.n_slots - 1;  // rounds in flight
+        for (int64_t k = 0; k < D - 1 && k < n_mine; ++k) issue();
+        for (int64_t k = 0; k < n_mine; ++k) {
+            if (k + D - 1 < n_mine) {
+                issue();
+                pm_wait_vmcnt((D - 1) * g.per_loader);  // round k has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();  // (the consumers' last hand-over, see there)
+    } else {
+        // ---- consumers: wavefront c works on row c / kPmPerRow of the round, a contiguous run of its mask words -----
+        // The decision is made on the bit patterns (|y| and the threshold are non-negative floats: their patterns are
+        // ordered): with a = |y|'s pattern and b the threshold's, thr_compare's "kept" (a != 0, a - b >= -1) is
+        // a >= lo = max(b - 1, 1), and "float32 cannot decide" (|a - b| <= 1) is a - lo <= span = b + 1 - lo.  Three
+        // vector instructions a word; ties only raise a flag here.  A NaN or negative threshold keeps every stored
+        // value: b = 0 does that.
+        const int c = wave - kPmLoaders, r_in = c / kPmPerRow, part = c - r_in * kPmPerRow;
+        const int wpw = (n_words + kPmPerRow - 1) / kPmPerRow;  // words per wavefront (<= 64)
+        const int u_begin = part * wpw;
+        const int n_u = u_begin >= n_words ? 0 : (n_words - u_begin < wpw ? n_words - u_begin : wpw);
+        const bool owns_last = n_u > 0 && u_begin + n_u == n_words;
+        const unsigned long long tail_mask = (P.W & 63) ? (1ull << (P.W & 63)) - 1ull : ~0ull;  // of the row's last word
+        const unsigned lane_off = (unsigned)(u_begin * 64 + lane) * 4u;
+        int64_t row = (int64_t)blockIdx.x * kPmRows + r_in;
+        // chunk of the row (its threshold), kept incrementally
+        int64_t ch = 0, rem = 0, ch_step = 0, rem_step = 0;
+        if (has_thr) {
+            ch = uniform_i64((row + row_phase) / chunksize);  // (the 64-bit division is vector code)
+            rem = (row + row_phase) - ch * chunksize;
+            ch_step = uniform_i64(stride_rows / chunksize);
+            rem_step = stride_rows - ch_step * chunksize;
+        }
+        // The results leave through LDS: every wavefront puts its words and its kept count into the round's staging
+        // block (two blocks, alternating), and after the next barrier ONE wavefront writes the round -- kPmRows adjacent
+        // mask rows, contiguous in memory -- with a couple of full-width stores.  Twelve short stores and twelve atomics a
+        // round queue behind the loaders' LDS-DMA instructions in the CU's one vector-memory pipeline and stall the
+        // wavefronts that issue them: measured 0.05 ms of 0.2.
+        unsigned char* const stage0 = smem + (size_t)g.n_slots * slot_bytes;
+        const unsigned my_word_off = (unsigned)(r_in * n_words + u_begin + lane) * 8u;
+        const unsigned my_cnt_off = (unsigned)g.stage_cnt_off + (unsigned)(r_in * kPmPerRow + part) * 4u;
+        const bool storer = c == kPmConsumers - 1;
+        const auto flush = [&](int64_t k) {  // round k of this workgroup: staging block k & 1 -> mask, row_nnz
+            const unsigned char* st = stage0 + (size_t)(k & 1) * g.stage_block;
+            const int64_t row0 = ((int64_t)blockIdx.x + k * gridDim.x) * kPmRows;
+            const int valid = P.n_rows - row0 < kPmRows ? (int)(P.n_rows - row0) : kPmRows;
+            unsigned long long* dst = mask + row0 * (int64_t)n_words;
+            for (int w = lane; w < valid * n_words; w += 64) dst[w] = *reinterpret_cast<const unsigned long long*>(st + w * 8);
+            if (lane < valid) {
+                int tot = 0;
+#pragma unroll
+                for (int q = 0; q < kPmPerRow; ++q) tot += *reinterpret_cast<const int*>(st + g.stage_cnt_off + (lane * kPmPerRow + q) * 4);
+                row_nnz[row0 + lane] = tot;
+            }
+        };
+        // the loop over the rounds, compiled once per word count 1..16 (straight-line code: a jump per word costs as much
+        // as the word) and once for longer runs (NW = 17: sweeps of eight words)
+        const auto consume = [&](auto nw_tag) {
+            constexpr int NW = decltype(nw_tag)::value;
+            int slot_i = 0;
+            double th = has_thr && row < P.n_rows ? scalar_load_f64(thr + ch) : 0.0;
+            for (int64_t k = 0; k < n_mine; ++k) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");  // the slot was written by the loaders' DMA: read it after the barrier
+                const unsigned char* lrow = smem + (size_t)slot_i * slot_bytes + (size_t)r_in * g.row_stride + lane_off;
+                slot_i = slot_i + 1 == g.n_slots ? 0 : slot_i + 1;
+                unsigned char* stage = stage0 + (size_t)(k & 1) * g.stage_block;
+                if (storer && k > 0) flush(k - 1);
+                if (lane == 0) *reinterpret_cast<int*>(stage + my_cnt_off) = 0;
+                bool skip = row >= P.n_rows || NW == 0;  // (uniform; the barrier count is kept by the loop header)
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_PM_EXP_NOCONSUME)
+                skip = true;
+#endif
+                if (!skip) {
+                    const float thf = (float)th;
+                    const int thb = thf > 0.0f ? __float_as_int(thf) : 0;
+                    const unsigned lo = thb > 2 ? (unsigned)thb - 1u : 1u, span = (unsigned)thb + 1u - lo;
+                    unsigned long long mine = 0, tie_any = 0;
+                    int kept = 0;
+                    // (a read past the row's end -- the last word, in the sweeps the words of the next wavefront --
+                    // returns other rows' bytes or, past the allocation, zero: those windows are masked / never used)
+#define ICV_PM_Y(I) (*reinterpret_cast<const unsigned*>(lw + (I) * 256))
+                    if constexpr (NW <= 16) {
+                        const unsigned char* lw = lrow;
+                        unsigned y[16];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) y[t] = t < NW ? ICV_PM_Y(t) : 0u;
+                        int mine_lo = 0, mine_hi = 0;
+                        if constexpr (NW > 15) ICV_PM_WORD(15, y[15])
+                        if constexpr (NW > 14) ICV_PM_WORD(14, y[14])
+                        if constexpr (NW > 13) ICV_PM_WORD(13, y[13])
+                        if constexpr (NW > 12) ICV_PM_WORD(12, y[12])
+                        if constexpr (NW > 11) ICV_PM_WORD(11, y[11])
+                        if constexpr (NW > 10) ICV_PM_WORD(10, y[10])
+                        if constexpr (NW > 9) ICV_PM_WORD(9, y[9])
+                        if constexpr (NW > 8) ICV_PM_WORD(8, y[8])
+                        if constexpr (NW > 7) ICV_PM_WORD(7, y[7])
+                        if constexpr (NW > 6) ICV_PM_WORD(6, y[6])
+                        if constexpr (NW > 5) ICV_PM_WORD(5, y[5])
+                        if constexpr (NW > 4) ICV_PM_WORD(4, y[4])
+                        if constexpr (NW > 3) ICV_PM_WORD(3, y[3])
+                        if constexpr (NW > 2) ICV_PM_WORD(2, y[2])
+                        if constexpr (NW > 1) ICV_PM_WORD(1, y[1])
+                        if constexpr (NW > 0) ICV_PM_WORD(0, y[0])
+                        mine = ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;
+                    } else {
+                        for (int i0 = 0; i0 < n_u; i0 += 8) {
+                            const unsigned char* lw = lrow + i0 * 256;
+                            const unsigned y0 = ICV_PM_Y(0), y1 = ICV_PM_Y(1), y2 = ICV_PM_Y(2), y3 = ICV_PM_Y(3), y4 = ICV_PM_Y(4),
+                                           y5 = ICV_PM_Y(5), y6 = ICV_PM_Y(6), y7 = ICV_PM_Y(7);
+                            int mine_lo = 0, mine_hi = 0;
+                            switch (n_u - i0) {  // (uniform) the words there are, last first
+                                default: ICV_PM_WORD(7, y7)
+                                case 7: ICV_PM_WORD(6, y6)
+                                case 6: ICV_PM_WORD(5, y5)
+                                case 5: ICV_PM_WORD(4, y4)
+                                case 4: ICV_PM_WORD(3, y3)
+                                case 3: ICV_PM_WORD(2, y2)
+                                case 2: ICV_PM_WORD(1, y1)
+                                case 1: ICV_PM_WORD(0, y0)
+                            }
+                            // lanes 0..7 of this sweep are words i0..i0 + 7
+                            const unsigned long long w8 = ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;
+                            const unsigned long long sh = __shfl(w8, (lane - i0) & 63, 64);
+                            if (lane >= i0 && lane < i0 + 8) mine = sh;
+                        }
+                    }
+#undef ICV_PM_Y
+                    if (owns_last) {  // windows past W in the row's last word
+                        const unsigned long long last = __shfl(mine, n_u - 1, 64);
+                        kept -= __builtin_popcountll(last & ~tail_mask);
+                        if (lane == n_u - 1) mine &= tail_mask;
+                    }
+                    // ties (about one window in 1e7; none without a threshold): every flagged window is recomputed in
+                    // float64 from the input, each by its own lane
+                    // ties (about one window in 1e7; none without a threshold): the wavefront's words of this row go on
+                    // a list, k_thr_mask_ties recomputes the flagged windows in float64 after this kernel.  (The code that
+                    // does it is large; a call from here, even one never taken, costs the loop a quarter of its speed.)
+                    if (has_thr && tie_any != 0ull && lane == 0) tie_list[atomicAdd(tie_n, 1u)] = ((unsigned long long)row << 8) | (unsigned)part;
+                    if (lane < n_u) *reinterpret_cast<unsigned long long*>(stage + my_word_off) = mine;
+                    if (lane == 0) *reinterpret_cast<int*>(stage + my_cnt_off) = kept;
+                }
+                // the next round's row and threshold
+                row += stride_rows;
+                if (has_thr) {
+                    const int64_t ch_was = ch;
+                    ch += ch_step;
+                    rem += rem_step;
+                    if (rem >= chunksize) {
+                        rem -= chunksize;
+                        ++ch;
+                    }
+                    if (ch != ch_was && row < P.n_rows) th = scalar_load_f64(thr + ch);
+                }
+            }
+            __builtin_amdgcn_s_barrier();  // the last round is staged
+            if (storer && n_mine > 0) flush(n_mine - 1);
+        };
+        switch (n_u) {  // (uniform)
+            case 0: consume(std::integral_constant<int, 0>{}); break;
+            case 1: consume(std::integral_constant<int, 1>{}); break;
+            case 2: consume(std::integral_constant<int, 2>{}); break;
+            case 3: consume(std::integral_constant<int, 3>{}); break;
+            case 4: consume(std::integral_constant<int, 4>{}); break;
+            case 5: consume(std::integral_constant<int, 5>{}); break;
+            case 6: consume(std::integral_constant<int, 6>{}); break;
+            case 7: consume(std::integral_constant<int, 7>{}); break;
+            case 8: consume(std::integral_constant<int, 8>{}); break;
+            case 9: consume(std::integral_constant<int, 9>{}); break;
+            case 10: consume(std::integral_constant<int, 10>{}); break;
+            case 11: consume(std::integral_constant<int, 11>{}); break;
+            case 12: consume(std::integral_constant<int, 12>{}); break;
+            case 13: consume(std::integral_constant<int, 13>{}); break;
+            case 14: consume(std::integral_constant<int, 14>{}); break;
+            case 15: consume(std::integral_constant<int, 15>{}); break;
+            case 16: consume(std::integral_constant<int, 16>{}); break;
+            default: consume(std::integral_constant<int, 17>{}); break;
+        }
+    }
+}
+#undef ICV_PM_WORD
+
+// The flagged windows of k_thr_mask_ring's list, recomputed in float64 from the input (canonical order); bits cleared in
+// the mask, row counts lowered.  One workgroup per list entry (a row and one wavefront's run of its words): the threads
+// find the flagged windows, then -- as k_thr_mask does -- stage each window's genes in LDS together and thread 0 adds them
+// in the canonical order.  The last workgroup to finish zeroes the two counters for the next call (tie_n[0] = entries,
+// tie_n[1] = workgroups done).
+template <typename T, bool CSR>
+__global__ void __launch_bounds__(256) k_thr_mask_ties(const KParams P, const double* thr, int64_t chunksize, int64_t row_phase,
+                                                       unsigned long long* mask, int n_words, int64_t* row_nnz, unsigned* tie_n,
+                                                       const unsigned long long* tie_list) {
+    __shared__ int n_t, n_dropped;
+    __shared__ int tj[64];
+    __shared__ double vals[kTieBuf];
+    const unsigned n = __hip_atomic_load(tie_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int wpw = (n_words + kPmPerRow - 1) / kPmPerRow;
+    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+        const unsigned long long item = tie_list[e];
+        const int64_t row = (int64_t)(item >> 8);
+        const int part = (int)(item & 255), u_begin = part * wpw;
+        const int n_u = n_words - u_begin < wpw ? n_words - u_begin : wpw;
+        const double th = thr[(row + row_phase) / chunksize];
+        const float thf = (float)th;
+        const int thb = thf > 0.0f ? __float_as_int(thf) : 0;
+        const unsigned lo = thb > 2 ? (unsigned)thb - 1u : 1u, span = (unsigned)thb + 1u - lo;
+        unsigned long long* mrow = mask + row * (int64_t)n_words;
+        const auto drop_window = [&](int j) {
+            atomicAnd(mrow + (j >> 6), ~(1ull << (j & 63)));
+            atomicAdd(&n_dropped, 1);
+        };
+        if (threadIdx.x == 0) {
+            n_t = 0;
+            n_dropped = 0;
+        }
+        __syncthreads();
+        for (int w = threadIdx.x; w < n_u * 64; w += 256) {
+            const int j = u_begin * 64 + w;
+            if (j >= P.W) continue;
+            const unsigned d = (__float_as_uint(P.out[row * P.ldo + j]) & 0x7fffffffu) - lo;
+            if ((int)d < 0 || d > span) continue;
+            const int idx = atomicAdd(&n_t, 1);
+            if (idx < 64) {
+                tj[idx] = j;
+            } else {  // more than 64 undecided windows in one run of words (a row equal to the reference): serially
+                const int st = P.w_start[j];
+                const double yd = window_canonical(P, j, [&](int kk) { return value_at<T, CSR>(P, row, st + kk); }) - P.cell_median[row];
+                if (fabs(yd) < th) drop_window(j);
+            }
+        }
+        __syncthreads();
+        const int nt = n_t < 64 ? n_t : 64;
+        for (int i = 0; i < nt; ++i) {
+            const int j = tj[i];
+            const int st = P.w_start[j], ln = P.w_len[j];
+            const int len = ln > 0 ? ln : -ln;
+            if (len <= kTieBuf) {
+                for (int k = threadIdx.x; k < len; k += 256) vals[k] = value_at<T, CSR>(P, row, st + k);
+                __syncthreads();
+                if (threadIdx.x == 0 && fabs(window_canonical(P, j, [&](int k) { return vals[k]; }) - P.cell_median[row]) < th) drop_window(j);
+                __syncthreads();
+            } else if (threadIdx.x == 0) {
+                if (fabs(window_canonical(P, j, [&](int k) { return value_at<T, CSR>(P, row, st + k); }) - P.cell_median[row]) < th) drop_window(j);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && n_dropped)
+            atomicAdd(reinterpret_cast<unsigned long long*>(row_nnz + row), (unsigned long long)(-(long long)n_dropped));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(tie_n + 1, 1u) == gridDim.x - 1) {
+            tie_n[0] = 0;
+            tie_n[1] = 0;
+        }
+    }
+}
+
+}  // namespace icv

@@ -740,9 +740,10 @@ __global__ void __launch_bounds__(256) k_chunk_thr_part(const double* chunk_part
 // x_res: k_smooth_se sums its windows in another float64 order (equal to ~1e-12), so its float32
 // value can differ from the canonical one in the last bit.
 // ---------------------------------------------------------------------------------------
-// |y| against the float32 threshold: -1 below, +1 above, 0 float32 cannot decide (a NaN threshold or value: +1)
+// |y| against the float32 threshold: -1 below, +1 above, 0 float32 cannot decide (a NaN value, or a threshold that is
+// NaN, zero or negative -- nothing is below those: +1)
 __device__ __forceinline__ int thr_compare(float a, float thf) {
-    if (!(thf == thf) || !(a == a)) return 1;
+    if (!(thf > 0.0f) || !(a == a)) return 1;
     const int d = __float_as_int(a) - __float_as_int(thf);  // both non-negative: the bit patterns are ordered
     return d < -1 ? -1 : (d > 1 ? 1 : 0);
 }
@@ -1588,50 +1589,64 @@ __global__ void __launch_bounds__(256) k_csr_row_abs_sum(const T* data, const in
     if ((threadIdx.x & 63) == 0) row_sum[row] = acc;
 }
 
-// indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r]: ONE 1024-thread workgroup, 16 consecutive counts per
-// thread and sweep (16 384 rows per sweep: the counts of a piece are a few hundred KB, the scan is a ~15 us epilogue of
-// the mask pass, not worth a multi-workgroup scheme)
-constexpr int kScanPer = 16;
+// indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r], in two launches over blocks of kScanBlock rows:
+// k_row_block_sums (one workgroup per block: the block's total) and k_row_offsets (one workgroup per block: the totals
+// of the blocks before it, then the scan of its own rows).  Round 4 started with ONE workgroup walking all rows (0.1 ms
+// per 100 000 rows, latency of 7 dependent sweeps); this form is two ~5 us launches at any row count.
+constexpr int kScanPer = 4;
+constexpr int kScanBlock = 1024 * kScanPer;
+__device__ __forceinline__ long long block_sum_1024(long long s, long long* wsum) {  // every thread gets the total
+    s = (long long)wave_sum_u64((unsigned long long)s);
+    __syncthreads();  // wsum free again
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    long long tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += wsum[w];
+    return tot;
+}
+__global__ void __launch_bounds__(1024) k_row_block_sums(const int64_t* __restrict__ row_nnz, int64_t n_rows,
+                                                         int64_t* __restrict__ block_sums) {
+    __shared__ long long wsum[16];
+    const int64_t r0 = (int64_t)blockIdx.x * kScanBlock + (int64_t)kScanPer * threadIdx.x;
+    long long s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) s += r0 + k < n_rows ? row_nnz[r0 + k] : 0;
+    const long long tot = block_sum_1024(s, wsum);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
 __global__ void __launch_bounds__(1024) k_row_offsets(const int64_t* __restrict__ row_nnz, int64_t n_rows,
+                                                      const int64_t* __restrict__ block_sums,
                                                       int64_t* __restrict__ indptr) {
     __shared__ long long wsum[16];
-    __shared__ long long carry_s;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) {
-        carry_s = 0;
-        indptr[0] = 0;
+    const int64_t r0 = (int64_t)blockIdx.x * kScanBlock + (int64_t)kScanPer * t;
+    long long v[kScanPer], s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        v[k] = r0 + k < n_rows ? row_nnz[r0 + k] : 0;
+        s += v[k];
     }
+    long long before = 0;  // the blocks before this one
+    for (int b = t; b < (int)blockIdx.x; b += 1024) before += block_sums[b];
+    before = block_sum_1024(before, wsum);
+    long long incl = s;  // inclusive scan of the threads' sums over the wavefront
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned lo = (unsigned)__shfl_up((int)(unsigned)incl, o);
+        const unsigned hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)incl >> 32), o);
+        if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    __syncthreads();  // wsum free again
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    for (int64_t r0 = 0; r0 < n_rows; r0 += 1024 * kScanPer) {
-        long long v[kScanPer], s = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    long long run = before + incl - s;
+    if (blockIdx.x == 0 && t == 0) indptr[0] = 0;
 #pragma unroll
-        for (int k = 0; k < kScanPer; ++k) {
-            const int64_t r = r0 + (int64_t)kScanPer * t + k;
-            v[k] = r < n_rows ? row_nnz[r] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k) s += v[k];
-        long long incl = s;  // inclusive scan of the threads' sums over the wavefront
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned lo = (unsigned)__shfl_up((int)(unsigned)incl, o);
-            const unsigned hi = (unsigned)__shfl_up((int)(unsigned)((unsigned long long)incl >> 32), o);
-            if (lane >= o) incl += (long long)(((unsigned long long)hi << 32) | lo);
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        long long before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        long long run = before + incl - s;
-#pragma unroll
-        for (int k = 0; k < kScanPer; ++k) {
-            const int64_t r = r0 + (int64_t)kScanPer * t + k;
-            run += v[k];
-            if (r < n_rows) indptr[r + 1] = run;
-        }
-        __syncthreads();
-        if (t == 1023) carry_s = run;
-        __syncthreads();
+    for (int k = 0; k < kScanPer; ++k) {
+        run += v[k];
+        if (r0 + k < n_rows) indptr[r0 + k + 1] = run;
     }
 }
 
