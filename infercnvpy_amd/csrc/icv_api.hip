@@ -49,7 +49,7 @@ int fail(int code, const std::string& msg) {
 // getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
-    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring;
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring;
     int wgs_per_cu;        // 0 = not set
     double ward_compact_x; // 0 = not set
     void load() {
@@ -59,6 +59,7 @@ struct Knobs {
         phase_profile = std::getenv("ICV_PHASE_PROFILE") != nullptr;
         ward_in_place = std::getenv("ICV_WARD_IN_PLACE") != nullptr;
         no_mask_ring = std::getenv("ICV_NO_MASK_RING") != nullptr;
+        no_fill_ring = std::getenv("ICV_NO_FILL_RING") != nullptr;
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_WARD_COMPACT_X");
@@ -825,11 +826,16 @@ int launch_apply(const icv_matrix* m, const icv::KParams& K, const double* thr, 
 
 // ---- reference profile in the reference's evaluation order (csrc/icv_kernel_chain.hpp) ------------------------------
 namespace {
-int current_cu_count() {
+int current_cu_count() {  // (hipGetDeviceProperties costs a fraction of a millisecond: asked once per device)
+    static std::atomic<int> cached[64];
     int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) return prop.multiProcessorCount;
-    return 256;
+    n = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 // line -> tile of ChainLaunch's split (tile t owns the lines [t * n_lines / grid, (t + 1) * n_lines / grid))
@@ -1531,8 +1537,23 @@ int icv_csr_fill_masked(const float* x, int64_t n_rows, int32_t n_cols, int64_t 
     if (!x || !mask || !indptr || !indices || !data || n_cols < 0 || ld < n_cols)
         return fail(ICV_ERR_INVALID, "bad csr_fill_masked arguments");
     if (n_rows < 1) return ICV_OK;
-    hipLaunchKernelGGL(icv::k_csr_fill_masked, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, n_rows, n_cols, ld,
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // streamed form (k_csr_fill_ring: rows, mask rows and row offsets through an LDS ring, one persistent workgroup per
+    // CU) where the rows are 16-byte aligned and at least 1 KB; else one wavefront per row
+    const icv::FillRing fr(n_cols);
+    if (!knobs().no_fill_ring && fr.ok && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(mask) & 7) == 0) {
+        const int n_cu = current_cu_count();
+        const int64_t rounds = (n_rows + icv::kPmRows - 1) / icv::kPmRows;
+        const unsigned gx = (unsigned)(rounds < n_cu ? rounds : n_cu);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_csr_fill_ring),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, icv::kPmLds));  // (per device: every call)
+        hipLaunchKernelGGL(icv::k_csr_fill_ring, dim3(gx), dim3(icv::kPmThreads), fr.lds_bytes(), st, x, n_rows, n_cols, ld,
+                           reinterpret_cast<const unsigned long long*>(mask), indptr, indices, data);
+        HIP_TRY(hipGetLastError());
+        return ICV_OK;
+    }
+    hipLaunchKernelGGL(icv::k_csr_fill_masked, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, x, n_rows, n_cols, ld,
                        reinterpret_cast<const unsigned long long*>(mask), (n_cols + 63) / 64, indptr, indices, data);
     HIP_TRY(hipGetLastError());
     return ICV_OK;

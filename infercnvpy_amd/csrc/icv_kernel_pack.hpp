@@ -448,4 +448,295 @@ __global__ void __launch_bounds__(256) k_thr_mask_ties(const KParams P, const do
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// csr_matrix(x_res) from the keep-mask, streamed: k_csr_fill_ring.
+//
+// k_csr_fill_masked (one wavefront per row) issues a load and two scattered stores per 64 windows: 87 vector-memory
+// instructions per row of config 2, and the CU's one vector-memory pipeline takes ~16 cycles for each -- 0.24 ms per
+// 100 000 cells whatever the memory system could do.  Here the rows come through the LDS ring of k_thr_mask_ring (the
+// round's mask rows and row offsets ride along as extra LDS-DMA pieces of loader 0), the consumers compact the kept
+// windows of the round -- kPmRows rows, adjacent in the output -- into an LDS staging area as {column, value bits}
+// pairs, and in the NEXT round (after its barrier; two staging blocks alternate) all of them copy the block out with
+// full-width stores (column as int32, value widened to float64 on the way): a few dozen vector-memory instructions per
+// round instead of 350, one barrier per round, the loaders never wait for the consumers' phases.  A round with more kept
+// windows than a staging block holds (no threshold, dense rows) is done in passes with two more barriers each.
+struct FillRing {
+    int row_bytes, row_stride, n_ld, per_loader, n_slots;
+    int n_words, mask_off, n_mask_ld, ip_off, slot_total, n_extra;
+    int stage_off, cap;  // staging: byte offset in LDS, entries (8 bytes each) per block
+    bool ok;
+    __host__ __device__ explicit FillRing(int W) {
+        n_words = (W + 63) / 64;
+        row_bytes = W * 4;
+        row_stride = (row_bytes + 15) / 16 * 16;
+        n_ld = (row_bytes + 1023) / 1024;
+        per_loader = (kPmRows * n_ld + kPmLoaders - 1) / kPmLoaders;
+        mask_off = kPmRows * row_stride;
+        n_mask_ld = (kPmRows * n_words * 8 + 255) / 256;  // 256-byte pieces (4 bytes per lane: exact to the word)
+        ip_off = mask_off + n_mask_ld * 256;
+        slot_total = ip_off + 256;                         // kPmRows + 1 row offsets in one piece
+        n_extra = n_mask_ld + 1;
+        int s = (kPmLds - 16 * 1024) / slot_total;         // at least 2 048 staging entries
+        if (s > kPmMaxSlots) s = kPmMaxSlots;
+        while (s > 2 && (s - 1) * (per_loader + n_extra) > 60) --s;
+        n_slots = s;
+        stage_off = s * slot_total;
+        cap = s >= 2 ? (kPmLds - stage_off) / 2 / 8 / 64 * 64 : 0;  // two blocks, alternating
+        ok = s >= 2 && (s - 1) * (per_loader + n_extra) <= 60 && per_loader <= kPmMaxPer && row_bytes >= 1024 &&
+             n_words <= 64 && cap >= 1024;
+    }
+    __host__ __device__ int lds_bytes() const { return stage_off + 2 * cap * 8; }
+};
+
+// LDS-DMA, 4 bytes per lane: from base + off (off per lane, bytes) to lds_base + 4 * lane
+__device__ __forceinline__ void lds_dma4_s(const void* base, unsigned off, unsigned lds_base) {
+    base = reinterpret_cast<const void*>(uniform_i64(reinterpret_cast<int64_t>(base)));
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(off), "s"(base), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ int64_t lds_uniform_i64(const unsigned char* p) {  // a wave-uniform LDS word into scalar registers
+    return uniform_i64(*reinterpret_cast<const int64_t*>(p));
+}
+
+// x: n_rows x n_cols float32 (rows 16-byte aligned), mask / indptr as written by the mask pass and icv_row_offsets;
+// indices / data: the packed output.  grid = CUs; dynamic LDS = FillRing::lds_bytes().
+__global__ void __launch_bounds__(kPmThreads) k_csr_fill_ring(const float* x, int64_t n_rows, int n_cols, int64_t ld,
+                                                              const unsigned long long* mask, const int64_t* indptr,
+                                                              int32_t* indices, double* data) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const FillRing g(n_cols);
+    const int n_words = g.n_words;
+    const int64_t total_rounds = (n_rows + kPmRows - 1) / kPmRows;
+    const int64_t n_mine = total_rounds > blockIdx.x ? (total_rounds - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    const int64_t stride_rows = (int64_t)gridDim.x * kPmRows;
+    // passes over the staging area for a round with n kept windows (every wavefront computes it from the round's row
+    // offsets in LDS: the barriers of a round are 2 * passes, for loaders and consumers alike)
+    const auto passes_of = [&](int n) { return n > g.cap ? (n + g.cap - 1) / g.cap : 1; };
+
+    if (wave < kPmLoaders) {
+        unsigned p_dst[kPmMaxPer], p_off[kPmMaxPer];
+        int p_row[kPmMaxPer];
+        bool p_on[kPmMaxPer];
+#pragma unroll
+        for (int t = 0; t < kPmMaxPer; ++t) {
+            int q = t * kPmLoaders + wave;
+            if (q >= kPmRows * g.n_ld) q = 0;
+            const int r = q / g.n_ld, piece = q - r * g.n_ld;
+            p_row[t] = r;
+            p_dst[t] = (unsigned)r * (unsigned)g.row_stride + (unsigned)piece * 1024u;
+            p_off[t] = (unsigned)(piece * 64 + lane) * 16u;
+            p_on[t] = t < g.per_loader && (int)p_off[t] < g.row_bytes;
+        }
+        const int64_t row_step_bytes = ld * 4;
+        const unsigned char* issue_base = reinterpret_cast<const unsigned char*>(x) + (int64_t)blockIdx.x * kPmRows * row_step_bytes;
+        int64_t issue_row0 = (int64_t)blockIdx.x * kPmRows;
+        int issue_slot = 0;
+        const int n_extra = wave == 0 ? g.n_extra : 0;
+        const auto issue = [&]() {
+            const unsigned slot_lds = lds0 + (unsigned)issue_slot * (unsigned)g.slot_total;
+            const unsigned char* rb[kPmRows];
+#pragma unroll
+            for (int r = 0; r < kPmRows; ++r) rb[r] = issue_row0 + r < n_rows ? issue_base + r * row_step_bytes : issue_base;
+#pragma unroll
+            for (int t = 0; t < kPmMaxPer; ++t) {
+                if (t < g.per_loader) {  // (uniform)
+                    const unsigned char* base = rb[0];
+#pragma unroll
+                    for (int r = 1; r < kPmRows; ++r) base = p_row[t] == r ? rb[r] : base;
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_FR_EXP_NOLOAD)
+                    (void)base;
+#else
+                    if (p_on[t]) lds_dma16_s(base, p_off[t], slot_lds + p_dst[t]);
+#endif
+                }
+            }
+            if (wave == 0) {
+                // the round's mask rows and kPmRows + 1 row offsets.  Every piece is issued with at least one lane (the
+                // count of outstanding loads must not depend on the data): lanes past the valid bytes re-read byte 0
+                // into their own, unused place
+                const int valid = n_rows - issue_row0 < kPmRows ? (int)(n_rows - issue_row0) : kPmRows;
+                const unsigned char* mb = reinterpret_cast<const unsigned char*>(mask + issue_row0 * (int64_t)n_words);
+                const unsigned m_valid = (unsigned)(valid * n_words * 8);
+                for (int pc = 0; pc < g.n_mask_ld; ++pc) {
+                    const unsigned off = (unsigned)(pc * 64 + lane) * 4u;
+                    lds_dma4_s(mb, off < m_valid ? off : 0u, slot_lds + (unsigned)g.mask_off + (unsigned)pc * 256u);
+                }
+                const unsigned ioff = (unsigned)lane * 4u;
+                lds_dma4_s(indptr + issue_row0, ioff < (unsigned)(valid + 1) * 8u ? ioff : 0u, slot_lds + (unsigned)g.ip_off);
+            }
+            issue_slot = issue_slot + 1 == g.n_slots ? 0 : issue_slot + 1;
+            issue_base += stride_rows * row_step_bytes;
+            issue_row0 += stride_rows;
+        };
+        const int D = g.n_slots - 1;
+        int slot_i = 0;
+        int64_t row0 = (int64_t)blockIdx.x * kPmRows;
+        for (int64_t k = 0; k < D - 1 && k < n_mine; ++k) issue();
+        for (int64_t k = 0; k < n_mine; ++k) {
+            if (k + D - 1 < n_mine) {
+                issue();
+                pm_wait_vmcnt((D - 1) * (g.per_loader + n_extra));  // round k has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // A
+            asm volatile("" ::: "memory");
+            const unsigned char* sl = smem + (size_t)slot_i * g.slot_total;
+            slot_i = slot_i + 1 == g.n_slots ? 0 : slot_i + 1;
+            const int valid = n_rows - row0 < kPmRows ? (int)(n_rows - row0) : kPmRows;
+            const int n_round = (int)(lds_uniform_i64(sl + g.ip_off + 8 * valid) - lds_uniform_i64(sl + g.ip_off));
+            const int np = passes_of(n_round);
+            if (np > 1)
+                for (int b = 0; b < 2 * np; ++b) __builtin_amdgcn_s_barrier();  // (staged, copied) per pass
+            row0 += stride_rows;
+        }
+        __builtin_amdgcn_s_barrier();  // the consumers' last block
+    } else {
+        const int c = wave - kPmLoaders, r_in = c / kPmPerRow, part = c - r_in * kPmPerRow;
+        const int wpw = (n_words + kPmPerRow - 1) / kPmPerRow;
+        const int u_begin = part * wpw;
+        const int n_u = u_begin >= n_words ? 0 : (n_words - u_begin < wpw ? n_words - u_begin : wpw);
+        const unsigned lane_off = (unsigned)(u_begin * 64 + lane) * 4u;
+        unsigned char* const stage0 = smem + g.stage_off;
+        const int j_lane = u_begin * 64 + lane;
+        // n entries of a staging block -> indices / data at entry `at` (all consumer wavefronts, 64 entries a step)
+        const auto copy_out = [&](const unsigned char* st, int n, int64_t at) {
+            int32_t* oi = indices + at;
+            double* od = data + at;
+#if defined(ICV_DEV_EXPERIMENTS) && (defined(ICV_FR_EXP_NOCONSUME) || defined(ICV_FR_EXP_NOCOPY))
+            n = 0;
+#endif
+            for (int e = c * 64 + lane; e < n; e += kPmConsumers * 64) {
+                const uint2 v = *reinterpret_cast<const uint2*>(st + (size_t)e * 8);
+                oi[e] = (int32_t)v.x;
+                od[e] = (double)__uint_as_float(v.y);
+            }
+        };
+        const auto consume = [&](auto nw_tag) {
+            constexpr int NW = decltype(nw_tag)::value;
+            int slot_i = 0, pend_n = 0;
+            int64_t pend_at = 0;
+            int64_t row0 = (int64_t)blockIdx.x * kPmRows;
+            for (int64_t k = 0; k < n_mine; ++k) {
+                __builtin_amdgcn_s_barrier();  // the round has landed; the previous round's staging block is complete
+                asm volatile("" ::: "memory");
+                const unsigned char* sl = smem + (size_t)slot_i * g.slot_total;
+                slot_i = slot_i + 1 == g.n_slots ? 0 : slot_i + 1;
+                const int valid = n_rows - row0 < kPmRows ? (int)(n_rows - row0) : kPmRows;
+                const int64_t ip0 = lds_uniform_i64(sl + g.ip_off);
+                const int n_round = (int)(lds_uniform_i64(sl + g.ip_off + 8 * valid) - ip0);
+#if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_FR_EXP_NOCONSUME)
+                const bool have = false;
+#else
+                const bool have = r_in < valid && NW > 0;
+#endif
+                // this wavefront's first output position inside the round: the row's offset + the kept windows of the
+                // row's earlier words
+                unsigned long long wl = 0;
+                int base0 = 0;
+                if (have) {
+                    if (lane < n_words) wl = *reinterpret_cast<const unsigned long long*>(sl + g.mask_off + (r_in * n_words + lane) * 8);
+                    const int pc = __builtin_popcountll(wl);
+                    const int excl = wave_scan_dpp(pc) - pc;
+                    base0 = (int)(lds_uniform_i64(sl + g.ip_off + 8 * r_in) - ip0) + __builtin_amdgcn_readlane(excl, u_begin);
+                }
+                const unsigned char* lrow = sl + (size_t)r_in * g.row_stride + lane_off;
+                const int np = passes_of(n_round);
+                unsigned char* const stage = stage0 + (size_t)(k & 1) * g.cap * 8;
+                const unsigned stage_lds = lds0 + (unsigned)g.stage_off + (unsigned)(k & 1) * (unsigned)g.cap * 8u;
+                // the previous round's block (complete: every wavefront has passed this round's barrier)
+                if (pend_n > 0) copy_out(stage0 + (size_t)((k - 1) & 1) * g.cap * 8, pend_n, pend_at);
+                pend_n = 0;
+                if (np == 1) {
+                    // the usual round (everything fits the block): the mask word IS the lane mask of the write -- no test
+                    // per lane, no branch, the row's values all requested before the first use
+                    if (have) {
+                        if constexpr (NW <= 16) {
+                            unsigned yb[NW > 0 ? NW : 1];
+#pragma unroll
+                            for (int t = 0; t < NW; ++t) yb[t] = *reinterpret_cast<const unsigned*>(lrow + t * 256);
+                            int b = base0;
+#pragma unroll
+                            for (int t = 0; t < NW; ++t) {
+                                const unsigned m_lo = __builtin_amdgcn_readlane((unsigned)wl, u_begin + t);
+                                const unsigned m_hi = __builtin_amdgcn_readlane((unsigned)(wl >> 32), u_begin + t);
+                                const int rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0));
+                                const unsigned addr = stage_lds + (unsigned)(b + rank) * 8u;
+                                const unsigned long long val = ((unsigned long long)yb[t] << 32) | (unsigned)(j_lane + t * 64);
+                                const unsigned long long m = ((unsigned long long)m_hi << 32) | m_lo;
+                                unsigned long long sv;
+                                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                                             : "=&s"(sv)
+                                             : "s"(m), "v"(addr), "v"(val)
+                                             : "memory");
+                                b += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
+                            }
+                        } else {
+                            int b = base0;
+                            for (int t = 0; t < n_u; ++t) {
+                                const unsigned long long m = __shfl(wl, u_begin + t, 64);
+                                const unsigned yv = *reinterpret_cast<const unsigned*>(lrow + t * 256);
+                                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                                if ((m >> lane) & 1ull)
+                                    *reinterpret_cast<uint2*>(stage + (size_t)(b + rank) * 8) = make_uint2((unsigned)(j_lane + t * 64), yv);
+                                b += __builtin_popcountll(m);
+                            }
+                        }
+                    }
+                    pend_n = n_round;  // copied out in the next round
+                    pend_at = ip0;
+                } else {
+                    for (int p = 0; p < np; ++p) {
+                        const int p0 = p * g.cap;
+                        if (have) {
+                            int b = base0 - p0;
+                            for (int t = 0; t < n_u; ++t) {
+                                const unsigned long long m = __shfl(wl, u_begin + t, 64);
+                                const unsigned yv = *reinterpret_cast<const unsigned*>(lrow + t * 256);
+                                const unsigned pos = (unsigned)(b + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0)));
+                                if (((m >> lane) & 1ull) && pos < (unsigned)g.cap)
+                                    *reinterpret_cast<uint2*>(stage + (size_t)pos * 8) = make_uint2((unsigned)(j_lane + t * 64), yv);
+                                b += __builtin_popcountll(m);
+                            }
+                        }
+                        __builtin_amdgcn_s_barrier();  // the pass is staged
+                        copy_out(stage, n_round - p0 < g.cap ? n_round - p0 : g.cap, ip0 + p0);
+                        __builtin_amdgcn_s_barrier();  // ... and copied: the block is free
+                    }
+                }
+                row0 += stride_rows;
+            }
+            __builtin_amdgcn_s_barrier();
+            if (pend_n > 0) copy_out(stage0 + (size_t)((n_mine - 1) & 1) * g.cap * 8, pend_n, pend_at);
+        };
+        switch (n_u) {  // (uniform)
+            case 0: consume(std::integral_constant<int, 0>{}); break;
+            case 1: consume(std::integral_constant<int, 1>{}); break;
+            case 2: consume(std::integral_constant<int, 2>{}); break;
+            case 3: consume(std::integral_constant<int, 3>{}); break;
+            case 4: consume(std::integral_constant<int, 4>{}); break;
+            case 5: consume(std::integral_constant<int, 5>{}); break;
+            case 6: consume(std::integral_constant<int, 6>{}); break;
+            case 7: consume(std::integral_constant<int, 7>{}); break;
+            case 8: consume(std::integral_constant<int, 8>{}); break;
+            case 9: consume(std::integral_constant<int, 9>{}); break;
+            case 10: consume(std::integral_constant<int, 10>{}); break;
+            case 11: consume(std::integral_constant<int, 11>{}); break;
+            case 12: consume(std::integral_constant<int, 12>{}); break;
+            case 13: consume(std::integral_constant<int, 13>{}); break;
+            case 14: consume(std::integral_constant<int, 14>{}); break;
+            case 15: consume(std::integral_constant<int, 15>{}); break;
+            case 16: consume(std::integral_constant<int, 16>{}); break;
+            default: consume(std::integral_constant<int, 17>{}); break;
+        }
+    }
+}
+
 }  // namespace icv

@@ -37,6 +37,10 @@ def _two_step(torch, _engine, _lib, plan, dm, ref, res, chunksize, lfc_clip=3.0)
     ("csr", np.float64, [700, 320, 150, 100, 60], 101, 7, None, 999),
     ("dense", np.float32, cases.GENES_PER_CHROM_20K, 100, 1, 1.5, 300),     # 17 822 windows: 279 mask words
     ("dense", np.float32, [130, 40], 100, 10, 3.0, 5000),                   # a handful of windows, most rows empty
+    ("dense", np.float32, cases.GENES_PER_CHROM_20K, 100, 10, None, 1501),  # every stored window kept: the streamed fill
+                                                                            # kernel takes passes; a partial last round
+    ("dense", np.float32, cases.GENES_PER_CHROM_20K, 100, 5, 1.5, 803),     # 3 603 windows: 57 mask words, 19 per wavefront
+    ("csr", np.float32, cases.GENES_PER_CHROM_20K, 100, 10, 0.2, 2),        # fewer rows than a round
 ])
 def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
     from infercnvpy_amd import _engine, _lib

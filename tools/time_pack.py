@@ -66,9 +66,22 @@ def main():
     out["row_offsets"] = timed(lambda: _lib.check(lib.icv_row_offsets(_engine._ptr(part.counts), n, _engine._ptr(indptr), st)))
     indices = torch.empty(n * W, dtype=torch.int32, device="cuda")
     data = torch.empty(n * W, dtype=torch.float64, device="cuda")
-    out["fill"] = timed(lambda: _lib.check(lib.icv_csr_fill_masked(
+    fill = lambda: _lib.check(lib.icv_csr_fill_masked(  # noqa: E731
         _engine._ptr(part.out), n, W, part.out.stride(0), _engine._ptr(part.mask), _engine._ptr(indptr),
-        _engine._ptr(indices), _engine._ptr(data), st)))
+        _engine._ptr(indices), _engine._ptr(data), st))
+    os.environ["ICV_NO_FILL_RING"] = "1"
+    lib.icv_developer_knobs_reload()
+    out["fill[per_row]"] = timed(fill)
+    nnz = int(indptr[-1].item())
+    ref_i, ref_d = indices[:nnz].clone(), data[:nnz].clone()
+    indices.zero_()
+    data.zero_()
+    os.environ.pop("ICV_NO_FILL_RING")
+    lib.icv_developer_knobs_reload()
+    out["fill[ring]"] = timed(fill)
+    out["fill[ring] == fill[per_row]"] = bool(torch.equal(indices[:nnz], ref_i) and torch.equal(data[:nnz].view(torch.int64), ref_d.view(torch.int64)))
+    os.environ.pop("ICV_NO_MASK_RING", None)
+    lib.icv_developer_knobs_reload()
     out["threshold_csr"] = timed(lambda: _engine.threshold_csr(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=5000))
     for k, val in out.items():
         print(k, val)
