@@ -13,9 +13,9 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           (reference=None: the all-cell mean is part of the step), on BASELINE config 2: dense fp32 100 000 cells x
           20 000 genes (chr1..22, random var order) as a CUDA tensor in adata.X, window 100, step 10, chunksize 5000.
           Inside: reference-order column means (k_colchain, bit-equal to np.mean) -> fused centre / clip /
-          pyramid-smooth / median kernel -> per-chunk std -> noise threshold + CSR packing of X_cnv (k_thr_mask,
-          k_row_offsets, k_csr_fill_masked; reference _infercnv.py:449-455 is inside the chunk kernel) -> X_cnv as
-          device CSR float64.
+          pyramid-smooth / median kernel -> per-chunk std -> noise threshold + CSR packing of X_cnv
+          (k_thr_mask_ring, k_row_offsets, k_csr_fill_ring; reference _infercnv.py:449-455 is inside the chunk kernel)
+          -> X_cnv as device CSR float64.
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
   N > 1   one process per GPU over the rows of config 3: float64 column sums + ONE RCCL all-reduce of [G + 1] float64
           -> the same smoothing kernel -> per-chunk std -> noise threshold + CSR pack (dist.run_shard(pack=True)): the
@@ -468,9 +468,10 @@ def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, it
         "roofline_k_colchain": _roof(in_bytes, avg["k_colchain"], {
             "note": "one pass over the matrix; CSR: + k_csr_tile_bounds (column indices once more, 4 B per tile and row)"}),
         "roofline_threshold_and_csr_pack": _roof((4 * W + 8) * n_local + 12 * nnz, avg["threshold_and_csr_pack"], {
-            "kernels": "k_thr_mask + k_row_offsets + k_csr_fill_masked",
-            "note": "algorithmic bytes: x_res once (4 W per cell) + 12 B per kept entry + 8 B row offset; the two "
-                    "kernels read x_res twice (the second time partly from the Infinity Cache)"}),
+            "kernels": "k_thr_mask_ring (+ k_thr_mask_ties) + k_row_block_sums + k_row_offsets + k_csr_fill_ring",
+            "note": "algorithmic bytes: x_res once (4 W per cell) + 12 B per kept entry + 8 B row offset; the mask "
+                    "pass and the fill pass each stream x_res through an LDS ring (x_res is read twice, the keep-mask "
+                    "-- W / 8 bytes per cell -- written and read once)"}),
     }
 
 

@@ -417,10 +417,10 @@ def threshold_csr(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_
     ``res.out`` of :func:`run_hot_path` (``apply=False``) -> :class:`PackedCsr`.  ``capacity`` (entries) defaults to the
     worst case rows x windows; nothing is read back, the call is asynchronous.
 
-    Default: keep-mask + row counts (``icv_threshold_mask``, rows in reverse: the tail of x_res is still in the Infinity
-    Cache), ``icv_row_offsets``, ``icv_csr_fill_masked`` -- 0.5 ms per 100 000 cells.  ``single_pass=True``:
-    ``icv_threshold_pack`` (one kernel with a decoupled look-back; 0.7 ms: its scattered 4- / 8-byte stores and the
-    16-row tickets cost more than the second read of x_res they save -- profiles/r04_pack_experiments.txt)."""
+    Default: keep-mask + row counts (``icv_threshold_mask``: ``k_thr_mask_ring``, x_res streamed through an LDS ring),
+    ``icv_row_offsets``, ``icv_csr_fill_masked`` (``k_csr_fill_ring``) -- 0.33 ms per 100 000 cells.
+    ``single_pass=True``: ``icv_threshold_pack`` (one kernel with a decoupled look-back; 0.7 ms, kept for comparison --
+    profiles/r04_pack_experiments.txt)."""
     torch = _torch()
     lib = _lib.load()
     rows = res.out.shape[0]
