@@ -84,3 +84,61 @@ def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
             np.testing.assert_array_equal(small.indices[: nnz // 2].cpu().numpy(), ix2[: nnz // 2])
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("fmt,dyn,n,ties", [("dense", 1.5, 4099, False), ("csr", None, 1203, False), ("dense", 1.5, 613, True)])
+def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, monkeypatch):
+    """k_thr_mask_ring (+ k_thr_mask_ties) / k_csr_fill_ring against k_thr_mask / k_csr_fill_masked (developer knobs
+    ICV_NO_MASK_RING / ICV_NO_FILL_RING) at the benchmark geometry: identical mask words, row counts and CSR arrays.
+    ``ties``: rows equal to the reference and thresholds placed ON window values -- every such window is within one ulp
+    of its threshold and goes through the float64 recomputation (list + k_thr_mask_ties here, in the kernel there)."""
+    from infercnvpy_amd import _engine, _lib
+    from infercnvpy_amd._plan import GenePlan
+
+    torch = _engine._torch()
+    lib = _lib.load()
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K, seed_perm=3)
+    X = cases.synthetic_expr(n, len(v["names"]), seed=n, dtype=np.float32)
+    ref_h = X.mean(axis=0).astype(np.float32)
+    if ties:
+        X[5] = ref_h
+        X[77] = ref_h
+    dm = _engine.to_device_matrix(sp.csr_matrix(X) if fmt == "csr" else X)
+    ref = torch.from_numpy(ref_h).cuda()
+    plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+    chunksize = 500
+    try:
+        res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=dyn, chunksize=chunksize, apply=False)
+        if ties:  # thresholds equal to |x_res| of a window of the chunk's first row, one and two ulps around it
+            xr = res.out.cpu().numpy()
+            thr = res.thr.cpu().numpy().copy()
+            for c in range(thr.shape[0]):
+                row = xr[c * chunksize]
+                nz = np.flatnonzero(row)
+                if nz.size:
+                    a = np.abs(row[nz[c % nz.size]])
+                    thr[c] = float(np.nextafter(a, np.float32([0, np.inf, 0][c % 3]), dtype=np.float32)) if c % 3 else float(a)
+            res.thr.copy_(torch.from_numpy(thr))
+        out = {}
+        for tag, env in (("ring", {}), ("per_row", {"ICV_NO_MASK_RING": "1", "ICV_NO_FILL_RING": "1"})):
+            for k in ("ICV_NO_MASK_RING", "ICV_NO_FILL_RING"):
+                monkeypatch.delenv(k, raising=False)
+            for k, val in env.items():
+                monkeypatch.setenv(k, val)
+            lib.icv_developer_knobs_reload()
+            part = _engine.threshold_mask(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+            pk = _engine.threshold_csr(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+            nnz = pk.nnz()
+            out[tag] = (part.mask.cpu().numpy(), part.counts.cpu().numpy(), pk.indptr.cpu().numpy(),
+                        pk.indices[:nnz].cpu().numpy(), pk.data[:nnz].cpu().numpy())
+        for a, b in zip(out["ring"], out["per_row"]):
+            np.testing.assert_array_equal(a, b)
+        assert out["ring"][1].sum() == out["ring"][2][-1]
+        # twice in a row: the tie counters of the plan are back at zero after every call
+        part2 = _engine.threshold_mask(plan, dm, ref, None, res, lfc_clip=3.0, chunksize=chunksize)
+        np.testing.assert_array_equal(part2.mask.cpu().numpy(), out["per_row"][0])
+    finally:
+        for k in ("ICV_NO_MASK_RING", "ICV_NO_FILL_RING"):
+            monkeypatch.delenv(k, raising=False)
+        lib.icv_developer_knobs_reload()
+        plan.close()
