@@ -244,18 +244,25 @@ int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, con
  * icv_infercnv_smooth / icv_infercnv_run with ICV_FLAG_NO_APPLY) is left untouched; the kept entries
  * (|x| >= thr in float64, x != 0; NaN kept) are recorded as bits, `mask` = n_rows x n_words uint64 with
  * n_words = ceil(n_windows / 64), and counted into `row_nnz`.  `thr` NULL = no threshold (dynamic_threshold=None).
- * icv_csr_fill_masked then packs indices / values at indptr[row] (caller-side prefix sum of row_nnz).
- * x_res is read twice in total and never rewritten. */
+ * icv_row_offsets turns row_nnz into indptr, icv_csr_fill_masked then packs indices / values at indptr[row]: the
+ * public path's three calls, nothing is read back.  x_res is read twice in total and never rewritten.
+ * Both passes stream x_res through an LDS ring (one persistent workgroup per CU, LDS-DMA loader wavefronts:
+ * k_thr_mask_ring / k_csr_fill_ring, csrc/icv_kernel_pack.hpp) when its rows are 16-byte aligned (ldo a multiple of 4)
+ * and hold 256 .. 2 048 windows (four rows a round through 160 KB of LDS); other shapes run one workgroup / wavefront
+ * per row.  The streamed mask pass needs 24 * n_rows bytes of temporary device memory (stream-ordered) when `thr` is
+ * given. */
 int icv_threshold_mask(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
                        double lfc_clip, int32_t flags, const float *out, int64_t ldo, const double *cell_median,
                        const double *thr, int64_t chunksize, int64_t row_phase, uint64_t *mask,
                        int64_t *row_nnz, void *stream);
 int icv_csr_fill_masked(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const uint64_t *mask,
                         const int64_t *indptr, int32_t *indices, double *data, void *stream);
-/* the prefix sum between the two: indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r] (device arrays) */
+/* the prefix sum between the two: indptr[0] = 0, indptr[r + 1] = row_nnz[0] + ... + row_nnz[r] (device arrays; two
+ * launches over blocks of 4 096 rows, 8 bytes of temporary device memory per block) */
 int icv_row_offsets(const int64_t *row_nnz, int64_t n_rows, int64_t *indptr, void *stream);
 
-/* Step 5b and the packing in ONE pass (what the public path and bench.py's headline run): the decision of
+/* Step 5b and the packing in ONE pass (kept for comparison: 0.7 ms per 100 000 cells of config 2 against 0.33 ms for
+ * the three calls above, profiles/r04_pack_experiments.txt): the decision of
  * icv_threshold_mask, the rows' offsets from a two-level decoupled look-back over the rows (no mask array, no prefix-sum call,
  * no second kernel) and the kept entries written from the row: x_res is read from HBM once.  `indptr` n_rows + 1
  * offsets starting at 0; `indices` / `data` hold `capacity` entries (n_rows * n_windows can never overflow; entries
