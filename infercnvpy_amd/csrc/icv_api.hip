@@ -1521,7 +1521,7 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
 }
 
 int icv_row_offsets(const int64_t* row_nnz, int64_t n_rows, int64_t* indptr, void* stream) {
-    if (!row_nnz || !indptr || n_rows < 0) return fail(ICV_ERR_INVALID, "bad row_offsets arguments");
+    if ((!row_nnz && n_rows > 0) || !indptr || n_rows < 0) return fail(ICV_ERR_INVALID, "bad row_offsets arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned nb = (unsigned)((n_rows + icv::kScanBlock - 1) / icv::kScanBlock);
     AsyncBuf sums;

@@ -68,12 +68,6 @@ __device__ __forceinline__ double scalar_load_f64(const double* p) {
     return v;
 }
 
-// row count += v by one lane (plain instruction: the compiler's atomic optimiser would wrap a loop over the lanes around it)
-__device__ __forceinline__ void atomic_add_i64_noret(int64_t* p, int64_t v) {
-    p = reinterpret_cast<int64_t*>(uniform_i64(reinterpret_cast<int64_t>(p)));
-    asm volatile("global_atomic_add_x2 %0, %1, %2" ::"v"(0u), "v"(v), "s"(p) : "memory");
-}
-
 // Geometry of the ring for rows of W float32 (host and device agree through this struct)
 struct PackRing {
     int row_bytes, row_stride, n_ld, per_loader, n_slots;

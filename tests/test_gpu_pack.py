@@ -142,3 +142,23 @@ def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, monkeypat
             monkeypatch.delenv(k, raising=False)
         lib.icv_developer_knobs_reload()
         plan.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 4095, 4096, 4097, 12288, 1_000_003])
+def test_row_offsets_equal_a_prefix_sum(n):
+    """icv_row_offsets (k_row_block_sums + k_row_offsets over blocks of 4 096 rows) against torch.cumsum, at sizes on
+    both sides of the block boundaries and with counts whose total passes 2^32."""
+    from infercnvpy_amd import _engine, _lib
+
+    torch = _engine._torch()
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n + 1)
+    counts = torch.randint(0, 20_481, (max(n, 1),), device="cuda", generator=g, dtype=torch.int64)[:n]
+    indptr = torch.full((n + 1,), -7, dtype=torch.int64, device="cuda")
+    _lib.check(lib.icv_row_offsets(_engine._ptr(counts), n, _engine._ptr(indptr), _engine._stream_ptr(torch)))
+    exp = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    if n:
+        torch.cumsum(counts, 0, out=exp[1:])
+    assert torch.equal(indptr, exp)
+    if n >= 1_000_000:
+        assert int(indptr[-1]) > 2**32
