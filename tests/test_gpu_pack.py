@@ -86,8 +86,10 @@ def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
         plan.close()
 
 
-@pytest.mark.parametrize("fmt,dyn,n,ties", [("dense", 1.5, 4099, False), ("csr", None, 1203, False), ("dense", 1.5, 613, True)])
-def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, monkeypatch):
+@pytest.mark.parametrize("fmt,dyn,n,ties,dtype", [
+    ("dense", 1.5, 4099, False, np.float32), ("csr", None, 1203, False, np.float32), ("dense", 1.5, 613, True, np.float32),
+    ("csr", 1.5, 310, True, np.float32), ("dense", 1.5, 205, True, np.float64), ("csr", 1.5, 203, True, np.float64)])
+def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, dtype, monkeypatch):
     """k_thr_mask_ring (+ k_thr_mask_ties) / k_csr_fill_ring against k_thr_mask / k_csr_fill_masked (developer knobs
     ICV_NO_MASK_RING / ICV_NO_FILL_RING) at the benchmark geometry: identical mask words, row counts and CSR arrays.
     ``ties``: rows equal to the reference and thresholds placed ON window values -- every such window is within one ulp
@@ -98,8 +100,8 @@ def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, monkeypat
     torch = _engine._torch()
     lib = _lib.load()
     v = cases.synthetic_var(cases.GENES_PER_CHROM_20K, seed_perm=3)
-    X = cases.synthetic_expr(n, len(v["names"]), seed=n, dtype=np.float32)
-    ref_h = X.mean(axis=0).astype(np.float32)
+    X = cases.synthetic_expr(n, len(v["names"]), seed=n, dtype=dtype)
+    ref_h = X.mean(axis=0).astype(dtype)
     if ties:
         X[5] = ref_h
         X[77] = ref_h
