@@ -1,16 +1,25 @@
-// Step 5b (noise threshold) as a keep-mask, streamed: k_thr_mask_ring.
+// The public path's noise threshold + CSR pack (reference tl/_infercnv.py:449-455), streamed:
+//   k_thr_mask_ring (+ k_thr_mask_ties)   step 5b as a keep-mask + row counts        (icv_threshold_mask)
+//   k_csr_fill_ring                        csr_matrix(x_res) from x_res + mask + indptr (icv_csr_fill_masked)
+// DESIGN.md 4.6 has the measurements, profiles/r04_pack_experiments.txt every step on the way.
 //
-// The round-3 kernel k_thr_mask (one short-lived 256-thread workgroup per row, eight 4-byte loads per thread in flight)
-// reads x_res at 3 TB/s; every variant that gave a wavefront more loads in flight came out slower
-// (profiles/r04_pack_experiments.txt).  What does stream at 6.3 TB/s on this chip is the structure of k_colchain: ONE
-// persistent 1024-thread workgroup per CU whose loader wavefronts copy rows HBM -> LDS with LDS-DMA (no registers, no
-// ds_write, the ring IS the bytes in flight -- and with ~5 us of latency under load a CU needs ~130 KB of them) while the
-// other wavefronts work on the rows that have landed.  Here: rows are packed into the ring at their own length (rounded
-// to 16 bytes), two rows per round, every slot but the one being read in flight; four loader wavefronts share the 1 KB
-// pieces of a round; twelve consumer wavefronts -- six per row, each a contiguous run of mask words -- read the windows
-// from LDS 64 at a time (a ballot IS a mask word), decide them as k_thr_mask does (float32 decides; a window within one
-// ulp of the threshold is flagged and recomputed in float64 from the input, canonical order) and write the row's mask
-// words and kept count.
+// The per-row kernels k_thr_mask / k_csr_fill_masked (one short-lived workgroup / wavefront per row) read x_res at
+// 3 TB/s; every variant that gave a wavefront more loads in flight came out slower.  What does stream at 6.3 TB/s on this
+// chip is the structure of k_colchain: ONE persistent 1024-thread workgroup per CU whose loader wavefronts copy rows
+// HBM -> LDS with LDS-DMA (no registers, no ds_write, the ring IS the bytes in flight -- and with ~5 us of latency under
+// load a CU needs ~100 KB of them) while the other wavefronts work on the rows that have landed, one s_barrier per round.
+// Here: rows are packed into the ring at their own length (rounded to 16 bytes), kPmRows = 4 adjacent rows per round,
+// every slot but the one being read in flight; four loader wavefronts share the 1 KB pieces of a round; twelve consumer
+// wavefronts -- three per row, each a contiguous run of the row's 64-window words -- work from LDS.
+//
+// Three rules made this faster than the per-row kernels (each was measured the hard way):
+//   * a CU's 16 wavefronts sit on 4 SIMDs that issue one vector and one scalar instruction per ~4 cycles: ~10
+//     instructions per 64 windows is the budget at which HBM, not the consumers, sets the pace;
+//   * nothing in a consumer's loop may wait on vmcnt (gfx9 counts a wavefront's loads AND stores in one in-order
+//     counter: waiting for a load after a store waits for the store's acknowledgement) -- everything a consumer reads
+//     comes through LDS or the scalar cache;
+//   * few, wide stores: results are staged in LDS and written by full wavefronts (a dozen short stores per round queue
+//     behind the loaders' LDS-DMA instructions in the CU's one vector-memory pipeline).
 #pragma once
 #include <type_traits>
 
@@ -37,7 +46,6 @@ constexpr int kPmLds = 160 * 1024;
 __device__ __forceinline__ void pm_wait_vmcnt(int n) {
     switch (n) {
 #define ICV_PM_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-#define ICV_PM_W8(B) ICV_PM_W(B) ICV_PM_W(B + 1) ICV_PM_W(B + 2) ICV_PM_W(B + 3) ICV_PM_W(B + 4) ICV_PM_W(B + 5) ICV_PM_W(B + 6) ICV_PM_W(B + 7)
         ICV_PM_W(1) ICV_PM_W(2) ICV_PM_W(3) ICV_PM_W(4) ICV_PM_W(5) ICV_PM_W(6) ICV_PM_W(7)
         ICV_PM_W(8) ICV_PM_W(9) ICV_PM_W(10) ICV_PM_W(11) ICV_PM_W(12) ICV_PM_W(13) ICV_PM_W(14) ICV_PM_W(15)
         ICV_PM_W(16) ICV_PM_W(17) ICV_PM_W(18) ICV_PM_W(19) ICV_PM_W(20) ICV_PM_W(21) ICV_PM_W(22) ICV_PM_W(23)
@@ -46,21 +54,17 @@ __device__ __forceinline__ void pm_wait_vmcnt(int n) {
         ICV_PM_W(40) ICV_PM_W(41) ICV_PM_W(42) ICV_PM_W(43) ICV_PM_W(44) ICV_PM_W(45) ICV_PM_W(46) ICV_PM_W(47)
         ICV_PM_W(48) ICV_PM_W(49) ICV_PM_W(50) ICV_PM_W(51) ICV_PM_W(52) ICV_PM_W(53) ICV_PM_W(54) ICV_PM_W(55)
         ICV_PM_W(56) ICV_PM_W(57) ICV_PM_W(58) ICV_PM_W(59) ICV_PM_W(60)
-#undef ICV_PM_W8
 #undef ICV_PM_W
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
-// A wave-uniform double through the scalar cache.  gfx9 counts vector loads AND stores in one in-order counter (vmcnt):
-// a wavefront that stores and then waits for a later vector load waits for the store's acknowledgement from memory
-// (several microseconds under load).  The consumers below store a row's mask words every round, so nothing they read
-// may come through the vector memory path: rows come from LDS, the threshold from here.
 __device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // a wave-uniform value into scalar registers
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
     return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
+// a wave-uniform double through the scalar cache (the consumers' threshold: see the second rule above)
 __device__ __forceinline__ double scalar_load_f64(const double* p) {
     p = reinterpret_cast<const double*>(uniform_i64(reinterpret_cast<int64_t>(p)));
     double v;
@@ -121,7 +125,7 @@ __device__ __forceinline__ void lds_dma16_s(const void* base, unsigned off, unsi
 // mask: n_rows x n_words uint64 (bit j & 63 of word j >> 6 = window j kept), row_nnz: kept windows of the row.
 // tie_n (zero on entry) / tie_list (n_rows * kPmPerRow entries): the (row, wavefront part) pairs with undecided windows.
 // grid = CUs (fewer rounds: fewer workgroups); dynamic LDS = PackRing::lds_bytes().
-// Rows of `out` start on 16-byte boundaries (the caller checks; else the round-3 kernel runs).
+// Rows of `out` start on 16-byte boundaries (the caller checks; else the per-row kernel k_thr_mask runs).
 __global__ void __launch_bounds__(kPmThreads) k_thr_mask_ring(const KParams P, const double* thr, int64_t chunksize,
                                                               int64_t row_phase, unsigned long long* mask, int n_words,
                                                               int64_t* row_nnz, unsigned* tie_n, unsigned long long* tie_list) {
