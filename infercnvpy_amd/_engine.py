@@ -430,7 +430,9 @@ def threshold_csr(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_
                               row_phase=row_phase, flags=flags, row0=row0, row1=row1, capacity=capacity)
     part = threshold_mask(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize, row_phase=row_phase,
                           flags=flags, row0=row0, row1=row1)
-    cap = rows * W if capacity is None else int(capacity)
+    # (the fill kernels write at the row offsets without a bound: never less than the worst case here; a smaller
+    # ``capacity`` is honoured by the single-pass form only, which drops the overflow)
+    cap = rows * W if capacity is None else max(int(capacity), rows * W)
     indptr = torch.empty(rows + 1, dtype=torch.int64, device="cuda")
     indices = torch.empty(max(cap, 1), dtype=torch.int32, device="cuda")
     data = torch.empty(max(cap, 1), dtype=torch.float64, device="cuda")
