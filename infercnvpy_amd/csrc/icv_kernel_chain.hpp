@@ -363,9 +363,24 @@ struct ChainLaunch {
 // CSR input: the same chain over slices of the tile rebuilt in LDS
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kCcRows = 60;       // rows per round (one loader wavefront, lane = row; a multiple of the chain's ten)
-constexpr int kCcBlock = 32;      // rows per block of the bounds table
+constexpr int kCcBlock = 32;      // rows per workgroup of k_csr_tile_bounds
+// Layout of the bounds table.  Row-major (a row's n_tiles + 1 words contiguous): a wavefront writes its row's words into
+// ~1 KB (nine cache lines it completes itself), and the 32 tiles of an XCD read neighbouring words of ONE line per row
+// (the tiles are dealt to the XCDs in contiguous runs).  The first layout, blocks of 32 rows x (tile, row): every store
+// of a row went to a different line that 31 other rows had to complete -- 67 MB of open lines over the chip, 1.47 GB
+// written for a 0.51 GB table.
+#ifndef ICV_CC_TABLE_ROW_MAJOR
+#define ICV_CC_TABLE_ROW_MAJOR 1
+#endif
+__host__ __device__ inline int64_t cc_bounds_index(int64_t i, int t, int n_tiles) {
+#if ICV_CC_TABLE_ROW_MAJOR
+    return i * (int64_t)(n_tiles + 1) + t;
+#else
+    return ((i / kCcBlock) * (int64_t)(n_tiles + 1) + t) * kCcBlock + (i % kCcBlock);
+#endif
+}
 
-// bounds[(blk * (n_tiles + 1) + t) * 32 + r] = number of entries of selected row blk * 32 + r in the tiles before t
+// bounds[cc_bounds_index(i, t)] = number of entries of selected row i in the tiles before t
 // (t = 0 .. n_tiles; the row's entries of tile t are [bounds[t], bounds[t + 1]) from the row's start): one pass over the
 // column indices, rows' columns ascending (canonical CSR).  line_tile[l] = tile of cache line l of a row.
 // grid = ceil(n_sel / 32) workgroups of four wavefronts; a wavefront takes one row at a time.
@@ -379,7 +394,6 @@ __global__ void __launch_bounds__(256) k_csr_tile_bounds(const int64_t* __restri
     // workgroups per CU and the pass is bound by the latency of its dependent loads: 3.9 instead of 2.4 ms per 500 000
     // rows; four chunks of 64 entries in flight per wavefront instead)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* blk = bounds + (int64_t)blockIdx.x * (n_tiles + 1) * kCcBlock;
     for (int r = wave; r < kCcBlock; r += 4) {
         const int64_t i = (int64_t)blockIdx.x * kCcBlock + r;
         if (i >= n_sel) break;  // (uniform)
@@ -407,7 +421,7 @@ __global__ void __launch_bounds__(256) k_csr_tile_bounds(const int64_t* __restri
                 if (lane == 0) P = carry;
                 carry = __shfl(T[u], 63);
                 if (pos <= len)
-                    for (int t = P + 1; t <= T[u]; ++t) blk[t * kCcBlock + r] = (uint32_t)pos;
+                    for (int t = P + 1; t <= T[u]; ++t) bounds[cc_bounds_index(i, t, n_tiles)] = (uint32_t)pos;
             }
         }
     }
@@ -469,9 +483,8 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csr(const T* __restrict
             a_lo = a_hi = 0;
             if (k < n_rounds && lane < kCcRows && i < n_sel) {
                 const int64_t row = LIST ? sel[i] : i;
-                const uint32_t* bb = bounds + ((i / kCcBlock) * (n_tiles + 1) + tile) * kCcBlock + (i % kCcBlock);
-                a_lo = bb[0];
-                a_hi = bb[kCcBlock];
+                a_lo = bounds[cc_bounds_index(i, tile, n_tiles)];
+                a_hi = bounds[cc_bounds_index(i, tile + 1, n_tiles)];
                 a_rp = indptr[row];
             }
         };
