@@ -239,6 +239,23 @@ int icv_csr_count(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, in
 int icv_csr_fill(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, const int64_t *indptr,
                  int32_t *indices, double *data, void *stream);
 
+/* Geometry of the streamed pack kernels for rows of n_windows float32 (host logic, no GPU needed): whether
+ * icv_threshold_mask / icv_csr_fill_masked take the LDS-ring kernels at this width (given aligned rows), how the 160 KB
+ * of LDS of a CU are split, and how many LDS-DMA loads a loader wavefront keeps in flight (the hardware counter holds 63). */
+typedef struct {
+    int32_t rows_per_round;        /* adjacent rows a workgroup takes per barrier */
+    int32_t mask_streamed;         /* 1: k_thr_mask_ring applies */
+    int32_t mask_ring_slots;       /* ring slots of rows_per_round rows (one being read, the others in flight) */
+    int32_t mask_lds_bytes;        /* ring + the two staging blocks of mask words and counts */
+    int32_t mask_loads_in_flight;  /* per loader wavefront */
+    int32_t fill_streamed;         /* 1: k_csr_fill_ring applies */
+    int32_t fill_ring_slots;
+    int32_t fill_lds_bytes;        /* ring (rows + the round's mask rows and row offsets) + two staging blocks */
+    int32_t fill_loads_in_flight;  /* loader 0 (it also brings the mask rows and row offsets) */
+    int32_t fill_stage_entries;    /* kept windows per staging block: a round with more takes passes */
+} icv_pack_info;
+int icv_pack_geometry(int32_t n_windows, icv_pack_info *h_info);
+
 /* Step 5b fused with the packing (the public tl.infercnv path: X_cnv leaves the GPU as CSR and the dense thresholded
  * matrix is never needed): same decision as icv_apply_threshold, but `out` (the UN-thresholded x_res of
  * icv_infercnv_smooth / icv_infercnv_run with ICV_FLAG_NO_APPLY) is left untouched; the kept entries

@@ -29,7 +29,7 @@ EXPORTS = (
     "icv_plan_last_kernel", "icv_plan_se_tables",
     "icv_colsum", "icv_colchain", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
-    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_threshold_pack", "icv_corr_iqr",
+    "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_pack_geometry", "icv_threshold_pack", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
     "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_gather", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
     "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_last_error", "icv_version",
@@ -49,6 +49,12 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_cols_all", "n_genes_used", "n_chr", "window", "step", "n_windows", "block", "n_blocks", "padded_len",
         "lds_bytes_f32", "lds_bytes_f64", "workgroups_per_cu_f32")]
+
+
+class PackInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "rows_per_round", "mask_streamed", "mask_ring_slots", "mask_lds_bytes", "mask_loads_in_flight", "fill_streamed",
+        "fill_ring_slots", "fill_lds_bytes", "fill_loads_in_flight", "fill_stage_entries")]
 
 
 class Profile(C.Structure):
@@ -107,6 +113,7 @@ def load():
     lib.icv_threshold_mask.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp, vp, vp]
     lib.icv_threshold_pack.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, i64, i64, vp, vp, vp, i64, vp]
     lib.icv_row_offsets.argtypes = [vp, i64, vp, vp]
+    lib.icv_pack_geometry.argtypes = [i32, P(PackInfo)]
     lib.icv_csr_fill_masked.argtypes = [vp, i64, i32, i64, vp, vp, vp, vp, vp]
     lib.icv_corr_iqr.argtypes = [vp, i64, i32, i64, P(C.c_double), vp]
     lib.icv_pairwise_sqeuclidean.argtypes = [vp, i64, i32, i64, i64, i64, vp, i64, vp]

@@ -1520,6 +1520,23 @@ int icv_threshold_pack(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, c
     return ICV_OK;
 }
 
+int icv_pack_geometry(int32_t n_windows, icv_pack_info* info) {
+    if (!info || n_windows < 1) return fail(ICV_ERR_INVALID, "bad pack_geometry arguments");
+    const icv::PackRing pr(n_windows);
+    const icv::FillRing fr(n_windows);
+    info->rows_per_round = icv::kPmRows;
+    info->mask_streamed = pr.ok ? 1 : 0;
+    info->mask_ring_slots = pr.ok ? pr.n_slots : 0;
+    info->mask_lds_bytes = pr.ok ? pr.lds_bytes() : 0;
+    info->mask_loads_in_flight = pr.ok ? (pr.n_slots - 1) * pr.per_loader : 0;
+    info->fill_streamed = fr.ok ? 1 : 0;
+    info->fill_ring_slots = fr.ok ? fr.n_slots : 0;
+    info->fill_lds_bytes = fr.ok ? fr.lds_bytes() : 0;
+    info->fill_loads_in_flight = fr.ok ? (fr.n_slots - 1) * (fr.per_loader + fr.n_extra) : 0;
+    info->fill_stage_entries = fr.ok ? fr.cap : 0;
+    return ICV_OK;
+}
+
 int icv_row_offsets(const int64_t* row_nnz, int64_t n_rows, int64_t* indptr, void* stream) {
     if ((!row_nnz && n_rows > 0) || !indptr || n_rows < 0) return fail(ICV_ERR_INVALID, "bad row_offsets arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);

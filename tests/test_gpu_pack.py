@@ -88,7 +88,8 @@ def test_pack_equals_mask_and_fill(fmt, dtype, genes, window, step, dyn, n):
 
 @pytest.mark.parametrize("fmt,dyn,n,ties,dtype", [
     ("dense", 1.5, 4099, False, np.float32), ("csr", None, 1203, False, np.float32), ("dense", 1.5, 613, True, np.float32),
-    ("csr", 1.5, 310, True, np.float32), ("dense", 1.5, 205, True, np.float64), ("csr", 1.5, 203, True, np.float64)])
+    ("csr", 1.5, 310, True, np.float32), ("dense", 1.5, 205, True, np.float64), ("csr", 1.5, 203, True, np.float64),
+    ("dense", 1.5, 2051, True, "narrow"), ("dense", None, 1030, False, "narrow")])
 def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, dtype, monkeypatch):
     """k_thr_mask_ring (+ k_thr_mask_ties) / k_csr_fill_ring against k_thr_mask / k_csr_fill_masked (developer knobs
     ICV_NO_MASK_RING / ICV_NO_FILL_RING) at the benchmark geometry: identical mask words, row counts and CSR arrays.
@@ -99,7 +100,10 @@ def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, dtype, mo
 
     torch = _engine._torch()
     lib = _lib.load()
-    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K, seed_perm=3)
+    # "narrow": 338 windows -- rows of 1.3 KB, sixteen ring slots, two mask words per consumer wavefront
+    genes = cases.GENES_PER_CHROM_20K if dtype != "narrow" else [1700, 1400, 520]
+    dtype = np.float32 if dtype == "narrow" else dtype
+    v = cases.synthetic_var(genes, seed_perm=3)
     X = cases.synthetic_expr(n, len(v["names"]), seed=n, dtype=dtype)
     ref_h = X.mean(axis=0).astype(dtype)
     if ties:
@@ -111,6 +115,11 @@ def test_streamed_kernels_equal_the_per_row_kernels(fmt, dyn, n, ties, dtype, mo
     chunksize = 500
     try:
         res = _engine.run_hot_path(plan, dm, ref, dynamic_threshold=dyn, chunksize=chunksize, apply=False)
+        import ctypes as C
+
+        geo = _lib.PackInfo()
+        _lib.check(lib.icv_pack_geometry(plan.n_windows, C.byref(geo)))
+        assert geo.mask_streamed and geo.fill_streamed and res.out.stride(0) % 4 == 0  # the streamed kernels do run here
         if ties:  # thresholds equal to |x_res| of a window of the chunk's first row, one and two ulps around it
             xr = res.out.cpu().numpy()
             thr = res.thr.cpu().numpy().copy()
