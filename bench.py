@@ -17,9 +17,15 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           (k_thr_mask_ring, k_row_offsets, k_csr_fill_ring; reference _infercnv.py:449-455 is inside the chunk kernel)
           -> X_cnv as device CSR float64.
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
-  N > 1   one process per GPU over the rows of config 3: float64 column sums + ONE RCCL all-reduce of [G + 1] float64
-          -> the same smoothing kernel -> per-chunk std -> noise threshold + CSR pack (dist.run_shard(pack=True)): the
-          public call's work per rank, with the all-reduce in place of the sequential reference-order chains.
+  N > 1   one process per GPU over the rows of config 3 (dist.run_shard per rank).  TWO forms of the reference means
+          are timed back to back, K steps each: `value` = the reference's own evaluation order (icv_colchain
+          accumulators handed from rank to rank, pipelined over 4 column groups, means broadcast:
+          dist.reference_means_chained -- the same computation as the N = 1 public call, X_cnv bit-identical for any
+          N); `value_allreduce_means` = float64 column sums + ONE RCCL all-reduce of [G + 1] float64 (concurrent,
+          correctly rounded means: tl.infercnv(mean_order="float64")).  Both -> the same smoothing kernel -> per-chunk
+          std -> noise threshold + CSR pack (dist.run_shard(pack=True)).
+          The N = 1 line carries `scale_n1`: config 3's 1 M cells on ONE rank through this same per-rank code path,
+          both forms -- the N = 1 point a scaling curve over the N > 1 lines starts from.
   N > 1   BASELINE config 3: 1 000 000 cells x 20 000 genes in total, row shards aligned to the 5000-cell chunks
           (dist.shard_bounds; 125 000 cells per GPU at N = 8): strong scaling.  Every 5000-cell chunk is generated
           from its own seed, so the data do not depend on N.
@@ -196,8 +202,33 @@ def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2, slice_cells=
                   f"chunk {max(busy):.1f} s, mean {sum(busy) / len(busy):.1f} s, pool wall {wall:.1f} s incl. start-up and "
                   f"building the chunks",
     }
-    rate_l, n_l, busy_l, wall_l = _cpu_pool_rate(logical, window, step, cells_per_worker, reps)
     out = dict(spec)
+    # the whole box on config 3's chunk list: 200 chunks of 5000 cells (1 M cells) through one pool of min(physical
+    # cores, 200) workers, the reference's own structure at its default n_jobs (process_map(max_workers=cpu_count()),
+    # tl/_infercnv.py:120-135); the rate is cells / pool wall time after the workers have built their chunks (the clock
+    # of every chunk runs over its compute only; wall = the pool's makespan of those compute times, reconstructed from
+    # the per-chunk times in task order over `workers` slots)
+    n_cfg3 = CONFIG3_CELLS // chunk
+    workers = max(1, min(physical, n_cfg3))
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(max_workers=workers) as pool:
+        busy3 = list(pool.map(_cpu_chunk_worker, [(700 + i, chunk, window, step) for i in range(n_cfg3)]))
+    wall3 = time.perf_counter() - t0
+    slots = [0.0] * workers
+    for b in busy3:  # greedy list scheduling in task order = what the pool does
+        k = slots.index(min(slots))
+        slots[k] += b
+    makespan = max(slots)
+    out["whole_box"] = {
+        "value": n_cfg3 * chunk / makespan, "unit": "cells/s", "cores": workers, "kind": "port",
+        "wall_cells_per_s": n_cfg3 * chunk / wall3, "per_process_cells_per_s": chunk / (sum(busy3) / len(busy3)),
+        "sample": f"config 3's chunk list: {n_cfg3} chunks of {chunk} cells (1 M cells x 20000 genes dense fp32, window "
+                  f"{window} step {step}) through ProcessPoolExecutor(max_workers={workers} = min(physical cores "
+                  f"{physical}, {n_cfg3})), oracle chunk kernel; makespan of the chunks' compute times {makespan:.1f} s "
+                  f"(mean chunk {sum(busy3) / len(busy3):.1f} s, slowest {max(busy3):.1f} s), pool wall {wall3:.1f} s "
+                  f"incl. start-up and building the chunks",
+    }
+    rate_l, n_l, busy_l, wall_l = _cpu_pool_rate(logical, window, step, cells_per_worker, reps)
     out["oversubscribed"] = {
         "value": rate_l, "unit": "cells/s", "cores": logical, "kind": "port",
         "per_process_cells_per_s": rate_l / logical,
@@ -341,8 +372,12 @@ def pmc_traffic(key, cells):
 
 
 def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksize, steps, warmup, dist=None,
-             bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None, pack=False):
-    """Time `steps` passes of the hot path over the resident rows of `dm`; returns (seconds, roofline dict)."""
+             bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None, pack=False,
+             means="allreduce"):
+    """Time `steps` passes of the per-rank hot path (dist.run_shard) over the resident rows of `dm`; returns (seconds,
+    roofline dict).  means = "chained": the reference's own bits -- icv_colchain accumulators handed from rank to rank,
+    pipelined over column groups (dist.reference_means_chained), the same computation as the N = 1 public call;
+    "allreduce": float64 column sums + ONE all-reduce (correctly rounded means, concurrent)."""
     n_total = n_local if n_total is None else n_total
     W = plan.n_windows
     out = _engine.alloc_out(n_local, W)
@@ -350,14 +385,16 @@ def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksiz
     fixed_ref = (_engine.column_sums(dm)[0] / n_local).float() if no_refmean else None
 
     def one_step():
-        if fixed_ref is None:
+        if fixed_ref is not None:
+            ref = fixed_ref
+        elif means == "chained":
+            ref = icd.reference_means_chained(dm, [n_total])[0]
+        else:
             sums.zero_()
             _engine.column_sums(dm, None, 1, sums)
             # the only collective of the path: [G] float64 sums + the row count, over RCCL / xGMI
             ref = icd.reference_means(sums, [n_local], "float32", device_out=True)[0] if dist is not None \
                 else (sums[0] / n_local).float()
-        else:
-            ref = fixed_ref
         # no host synchronisation inside a step: the library records HIP events around the smoothing kernel on
         # the launch stream (icv_profile_begin) and the times are read after the timed region
         return icd.run_shard(plan, dm, ref, global_row0=row0, n_obs_global=n_total, lfc_clip=3.0,
@@ -439,12 +476,16 @@ def _roof(bytes_, ms, extra=None):
 
 def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, iters=10):
     """The kernels of the public call one by one (engine-level calls as tl.infercnv makes them, events on the launch
-    stream): reference-order means, smoothing + chunk thresholds, threshold + CSR pack; each with its roofline."""
+    stream): reference-order means, smoothing + chunk thresholds, threshold + CSR pack; each with its roofline.
+    Two untimed iterations first (the second one finds the caching allocator warm: every iteration frees its result
+    buffers -- 21.6 GB at 1 M cells -- before the next one asks for them, so no timed stage waits for an allocation);
+    at least ten timed ones; median (the figure used) and min per stage."""
     W = plan.n_windows
+    iters = max(int(iters), 10)
     ms = {"k_colchain": [], "smooth_and_thresholds": [], "threshold_and_csr_pack": []}
     nnz = 0
     is_csr = fmt == "csr"
-    for it in range(iters + 1):
+    for it in range(iters + 2):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
         acc = _engine.column_chain(dm, None, None, n_local)
@@ -457,17 +498,21 @@ def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, it
         torch.cuda.synchronize()
         if it == 0:
             nnz = pk.nnz()
-            continue
-        for k, (a, b) in zip(ms, ((0, 1), (1, 2), (2, 3))):
-            ms[k].append(ev[a].elapsed_time(ev[b]))
-        del res, pk
-    avg = {k: sum(v) / len(v) for k, v in ms.items()}
+        if it >= 2:
+            for k, (a, b) in zip(ms, ((0, 1), (1, 2), (2, 3))):
+                ms[k].append(ev[a].elapsed_time(ev[b]))
+        del res, pk, acc, ref
+    med = {k: sorted(v)[len(v) // 2] for k, v in ms.items()}
     in_bytes = (4 * G if not is_csr else 8 * nnz_row + 8) * n_local
     return {
-        "kernel_ms": avg, "sum_ms": sum(avg.values()), "x_cnv_nnz": nnz,
-        "roofline_k_colchain": _roof(in_bytes, avg["k_colchain"], {
-            "note": "one pass over the matrix; CSR: + k_csr_tile_bounds (column indices once more, 4 B per tile and row)"}),
-        "roofline_threshold_and_csr_pack": _roof((4 * W + 8) * n_local + 12 * nnz, avg["threshold_and_csr_pack"], {
+        "kernel_ms": med, "kernel_ms_min": {k: min(v) for k, v in ms.items()}, "iterations": iters,
+        "sum_ms": sum(med.values()), "x_cnv_nnz": nnz,
+        "roofline_k_colchain": _roof(in_bytes, med["k_colchain"], {
+            "note": "one pass over the matrix; CSR: + k_csr_tile_bounds (column indices once more, 2 B per tile and row)"}),
+        "roofline_smooth_and_thresholds": _roof(
+            ((4 * G if not is_csr else 8 * nnz_row + 8) + 4 * W) * n_local, med["smooth_and_thresholds"],
+            {"note": "the smoothing kernel + the per-chunk threshold kernel; algorithmic bytes as the main roofline"}),
+        "roofline_threshold_and_csr_pack": _roof((4 * W + 8) * n_local + 12 * nnz, med["threshold_and_csr_pack"], {
             "kernels": "k_thr_mask_ring (+ k_thr_mask_ties) + k_row_block_sums + k_row_offsets + k_csr_fill_ring",
             "note": "algorithmic bytes: x_res once (4 W per cell) + 12 B per kept entry + 8 B row offset; the mask "
                     "pass and the fill pass each stream x_res through an LDS ring (x_res is read twice, the keep-mask "
@@ -542,7 +587,7 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), window, 10, ("chrX", "chrY"),
                               torch.cuda.current_device())
         dm = T._resident_matrix(ad.X, torch)
-        st = stage_times(torch, _engine, plan, dm, cells, CHUNK, fmt, nnz_row=nnz_row, iters=3)
+        st = stage_times(torch, _engine, plan, dm, cells, CHUNK, fmt, nnz_row=nnz_row, iters=10)
         return {"workload": label + "; one cnv.tl.infercnv(adata) call per step on the resident matrix, "
                                     "reference = all-cell mean (in the step), X_cnv as device CSR",
                 "ms_per_step": dt / steps * 1e3, "cells_per_s": cells / (dt / steps), "steps": steps,
@@ -562,9 +607,24 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
 
     def one_million():
         X = synth_rows(torch, 0, CONFIG3_CELLS, G)
-        return api_leg(SimpleAnnData(X, var=var), CONFIG3_CELLS, "dense", 100,
+        leg_ = api_leg(SimpleAnnData(X, var=var), CONFIG3_CELLS, "dense", 100,
                        "BASELINE config 3's matrix on ONE GPU: dense fp32 1000000 x 20000 (80 GB resident), window 100 "
                        "(the size north_star quotes its targets on)", 3, "dense_w100")
+        # the N = 1 point of the scaling curve on the code path the N > 1 lines time (dist.run_shard per rank, one
+        # rank here): the same 1 M cells, both forms of the reference means
+        dm = _engine.DeviceMatrix(dense=X)
+        plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+        scale = {"workload": "BASELINE config 3's 1 000 000 cells on ONE rank through the per-rank code path of "
+                             "bench.py --gpus N (means -> dist.run_shard(pack=True)); cells/s comparable with the N > 1 "
+                             "lines' value / value_allreduce_means", "n_gpus": 1, "cells": CONFIG3_CELLS, "steps": 3}
+        for form in ("chained", "allreduce"):
+            dt, roof = hbm_step(torch, icd, _engine, plan, dm, CONFIG3_CELLS, "dense", 100, 10, CHUNK, steps=3,
+                                warmup=1, traffic_key="dense_w100", pack=True, means=form)
+            scale[form] = {"ms_per_step": dt / 3 * 1e3, "value": CONFIG3_CELLS / (dt / 3), "unit": "cells/s",
+                           "smooth_kernel_ms": roof["kernel_ms"], "roofline_frac": roof["frac"]}
+        plan.close()
+        leg_["scale_n1"] = scale
+        return leg_
 
     leg("config3_cells_on_one_gpu", one_million)
 
@@ -713,16 +773,20 @@ def main():
         stages["x_cnv_nnz_public_call"] = nnz_out
         ad = None
     else:
-        # N > 1: the same per-rank work as the public call (thresholds applied while X_cnv is packed to device CSR), with
-        # the reference means from float64 sums + ONE all-reduce instead of the sequential reference-order chains
+        # N > 1 (or --engine-step): the per-rank code path, dist.run_shard, with the thresholds applied while X_cnv is
+        # packed to device CSR.  `value` times the CHAINED reference means (the N = 1 public call's own computation:
+        # numpy's bits, the ranks pipelined over column groups); the float64 all-reduce form is timed right after it
+        # and reported beside it.
+        common = dict(dist=dist, bounds=bounds, row0=row0, n_total=n_total, no_refmean=args.no_refmean, nnz_row=nnz_row,
+                      traffic_key=traffic_key, pack=not args.engine_step)
         dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
-                            args.steps, args.warmup, dist=dist, bounds=bounds, row0=row0, n_total=n_total,
-                            no_refmean=args.no_refmean, nnz_row=nnz_row, traffic_key=traffic_key,
-                            pack=not args.engine_step)
+                            args.steps, args.warmup, means="chained", **common)
+        dt_ar, roof_ar = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
+                                  args.chunksize, args.steps, args.warmup, means="allreduce", **common)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else "cuda")
+        t = torch.tensor([dt, dt_ar], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_ar = float(t[0].item()), float(t[1].item())
 
     def host_barrier(tag):
         """Ranks meet through the rendezvous store (CPU only): no collective kernel spins on the idle GPUs while rank
@@ -745,8 +809,11 @@ def main():
     else:
         name = ("custom (not a BASELINE configuration): " +
                 ("dense fp32" if args.format == "dense" else f"CSR fp32 density {args.density}"))
+    rank_path = stages is None
     result = {
-        "metric": f"cells/sec through tl.infercnv (window={args.window}), input resident in HBM",
+        "metric": (f"cells/sec through tl.infercnv (window={args.window}), input resident in HBM" if not rank_path else
+                   f"cells/sec through the tl.infercnv hot path (window={args.window}) as dist.run_shard on every rank "
+                   f"(reference-order means chained over the ranks), input resident in HBM"),
         "value": value,
         "unit": "cells/s",
         "n_gpus": n_gpus,
@@ -769,7 +836,9 @@ def main():
                         + ("; step = one cnv.tl.infercnv(adata) call, adata.X a CUDA tensor, X_cnv returned as device "
                            "CSR float64 (reference-order means, smoothing, noise threshold + CSR pack)"
                            if stages is not None else
-                           "; step = float64 column sums (+ all-reduce) + smoothing + thresholds "
+                           "; step = reference-order column means (icv_colchain accumulators handed from rank to "
+                           "rank, pipelined over 4 column groups: numpy's own bits, the computation of the N = 1 "
+                           "public call) + smoothing + thresholds "
                            + ("applied while X_cnv is packed to device CSR (dist.run_shard(pack=True))" if not args.engine_step
                               else "applied in place (dist.run_shard)")),
             "io_dtype": "f32 matrix in, f32 x_res out",
@@ -781,11 +850,24 @@ def main():
             "parallelism": f"{n_gpus} rank(s) (torch.distributed world size "
                            f"{dist.get_world_size() if dist is not None else 1}, backend "
                            f"{('gloo, ALL RANKS ON cuda:0 (dry run)' if dry else 'nccl/RCCL') if dist is not None else 'none'}), "
-                           + ("row shards aligned to the chunks, one all-reduce of the [G+1] float64 reference sums per "
-                              "step, no other collective" if n_gpus > 1 else "one GPU, no collective"),
+                           + ("row shards aligned to the chunks; value: the [G] float32 chain accumulators travel rank to "
+                              "rank point to point in 4 column groups + one broadcast of the means; value_allreduce_means: "
+                              "one all-reduce of the [G+1] float64 reference sums per step; no other collective"
+                              if n_gpus > 1 else "one GPU, no collective"),
         },
         "roofline": roof,
     }
+    if rank_path:
+        result["value_allreduce_means"] = n_total / (dt_ar / args.steps)
+        result["ms_per_step_allreduce_means"] = dt_ar / args.steps * 1e3
+        result["forms"] = {
+            "value": "reference means in the reference's own evaluation order (dist.reference_means_chained): X_cnv "
+                     "bit-identical to the one-GPU public call for any number of ranks",
+            "value_allreduce_means": "float64 column sums + one all-reduce (dist.reference_means): correctly rounded "
+                                     "means, concurrent over the ranks, ~1e-3 of the X_cnv entries next to the noise "
+                                     "threshold may differ from the reference (tl.infercnv(mean_order='float64'))",
+            "smooth_kernel_ms_allreduce_run": roof_ar["kernel_ms"],
+        }
     if stages is not None:
         result["stages"] = stages
     if dry:
@@ -808,6 +890,9 @@ def main():
         if not args.no_extra and default_geometry and args.cells is None:
             which = [w for w in args.extra.split(",") if w]
             result["extra"] = extra_legs(torch, icd, _engine, GenePlan, cases, which)
+            leg3 = result["extra"].get("config3_cells_on_one_gpu")
+            if isinstance(leg3, dict) and "scale_n1" in leg3:
+                result["scale_n1"] = leg3.pop("scale_n1")
     if n_gpus > 1 and not args.no_e2e and args.format == "dense":
         # the public API over all GPUs of the job, from host memory: rank 0 drives every GPU from one process while
         # the other ranks have released their HBM and wait

@@ -58,8 +58,9 @@ typedef struct {
     int32_t dtype;          /* ICV_F32 | ICV_F64 (dtype of `values`)                   */
     int64_t n_rows;         /* cells                                                   */
     int32_t n_cols;         /* genes = n_cols_all of the plan                          */
-    int32_t _pad;
-    int64_t ld;             /* dense: row stride in elements (>= n_cols)               */
+    int32_t _pad;           /* dense: column offset of `values` inside its row when the matrix is a column view of a
+                               wider one (0 otherwise); only icv_colchain looks at it (which loads stay in bounds)  */
+    int64_t ld;             /* dense: row stride in elements (>= _pad + n_cols)        */
     const void *values;     /* dense: n_rows x ld row-major; csr: nnz values           */
     const int64_t *indptr;  /* csr: n_rows + 1                                         */
     const int32_t *indices; /* csr: nnz column indices, unique and ascending within a row */
@@ -152,8 +153,7 @@ int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, 
  * `acc`.  `scale` is used for CSR input only (1 / n of the whole group, rounded to the matrix dtype inside).
  * Columns are the only parallelism an exact chain has: one workgroup per 128..512-byte tile of a row streams its rows
  * through an LDS ring (LDS-DMA) while one wavefront adds them in order.  CSR needs 4 * (tiles + 1) bytes of temporary
- * device memory per row (stream-ordered).  A row list on a dense matrix whose row stride is not a multiple of 16 bytes
- * synchronises the stream once (the last list entry is read back).
+ * device memory per row (stream-ordered).  Nothing is read back: the call never synchronises.
  * icv_colchain_mean: mean[c] = acc[c] / count in the dtype (dense); for CSR the accumulators already are the means.
  * icv_colmean_csc: means of a CSC matrix (colptr n_cols + 1 int64, row_idx int32, values), entries of rows with
  * row_group[row] == group only (row_group NULL: all), scale = 1 / n as above; `mean` n_cols values of the dtype. */
@@ -391,6 +391,26 @@ int icv_row_abs_sum(const float *x, int64_t n_rows, int32_t n_cols, int64_t ld, 
  * stored entries are read, nothing is densified */
 int icv_csr_row_abs_sum(const void *data, int32_t dtype, const int64_t *indptr, int64_t n_rows, double *row_sum,
                         void *stream);
+
+/* per-group sums of per-cell values (cnv_score: score[g] = sum_g(row_sum) / (n_g * n_windows), tl/_scores.py:65-68):
+ * sums[g] = sum of values[i] with group[i] == g (device int32 labels 0 .. n_groups-1; others are ignored), counts[g] =
+ * how many.  Fixed summation order (one workgroup per group, strided partial sums + tree): the same bits for host and
+ * device-resident X_cnv. */
+int icv_group_sums(const double *values, const int32_t *group, int64_t n, int32_t n_groups, double *sums,
+                   int64_t *counts, void *stream);
+
+/* ---- device-resident CSR (a user-built device matrix as adata.X; X_cnv as tl.infercnv leaves it in HBM) ---------
+ * icv_csr_check: the matrix is what the kernels expect -- offsets non-decreasing and inside [0, capacity] (capacity =
+ * entries the index / value buffers hold), column indices inside [0, n_cols), ascending and unique within every row
+ * (the host path gets this from scipy's canonical format; reference tl/_infercnv.py:115-116).  ICV_ERR_INVALID with
+ * the defect in icv_last_error() otherwise.  Synchronises the stream (one flag is read back).
+ * icv_csr_densify: out[q * ldo + c] = value of row rows[q] (device int64 list; NULL: rows 0 .. n_sel-1), column c, as
+ * float32 -- the dense tile the fp32 MFMA contractions read (icv_corr_iqr for tl.ithcna, tl/_scores.py:197-213;
+ * icv_pairwise_sqeuclidean for config 5); `data` float32 or float64. */
+int icv_csr_check(const int64_t *indptr, const int32_t *indices, int64_t n_rows, int32_t n_cols, int64_t capacity,
+                  void *stream);
+int icv_csr_densify(const void *data, int32_t dtype, const int64_t *indptr, const int32_t *indices, const int64_t *rows,
+                    int64_t n_sel, int32_t n_cols, float *out, int64_t ldo, void *stream);
 
 /* ---- misc --------------------------------------------------------------------------------- */
 const char *icv_last_error(void);

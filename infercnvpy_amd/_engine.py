@@ -35,28 +35,58 @@ def _ptr(t):
 
 
 class DeviceMatrix:
-    """A cells x genes matrix resident in HBM (dense row-major or CSR), float32 or float64."""
+    """A cells x genes matrix resident in HBM (dense row-major or CSR), float32 or float64.
 
-    def __init__(self, *, dense=None, indptr=None, indices=None, data=None, shape=None, indptr_host=None):
+    ``DeviceMatrix(dense=tensor)`` or ``DeviceMatrix(indptr=int64, indices=int32, data=float32 / float64,
+    shape=(cells, genes))`` (CUDA tensors).  A CSR matrix built by the caller is checked on the device (``validate``,
+    one pass over the column indices and one flag read back): row offsets non-decreasing and inside the buffers, column
+    indices inside ``[0, genes)``, ascending and unique within every row -- what the host path gets from scipy's
+    canonical format.  ``ValueError`` otherwise (unsorted rows would give silently wrong windows)."""
+
+    def __init__(self, *, dense=None, indptr=None, indices=None, data=None, shape=None, indptr_host=None,
+                 validate=True):
         torch = _torch()
         if dense is not None:
-            assert dense.is_cuda and dense.dim() == 2 and dense.stride(1) == 1
-            assert dense.dtype in (torch.float32, torch.float64)
+            if not (isinstance(dense, torch.Tensor) and dense.is_cuda and dense.dim() == 2):
+                raise ValueError("DeviceMatrix: `dense` must be a 2-D CUDA tensor")
+            if dense.dtype not in (torch.float32, torch.float64):
+                raise ValueError("DeviceMatrix: a device matrix must be float32 or float64")
+            if dense.stride(1) != 1 and dense.shape[1] > 1:
+                raise ValueError("DeviceMatrix: rows must be contiguous (stride 1 along the genes)")
             self.format = _lib.ICV_DENSE
             self.dense = dense
             self.shape = tuple(dense.shape)
             self.dtype = dense.dtype
             self._keep = (dense,)
         else:
-            assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
-            assert data.dtype in (torch.float32, torch.float64)
+            for name, t in (("indptr", indptr), ("indices", indices), ("data", data)):
+                if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 1 and t.is_contiguous()):
+                    raise ValueError(f"DeviceMatrix: `{name}` must be a contiguous 1-D CUDA tensor")
+            if shape is None or len(tuple(shape)) != 2:
+                raise ValueError("DeviceMatrix: a CSR matrix needs shape=(cells, genes)")
+            if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
+                raise ValueError("DeviceMatrix: indptr must be int64 and indices int32")
+            if data.dtype not in (torch.float32, torch.float64):
+                raise ValueError("DeviceMatrix: a device matrix must be float32 or float64")
+            if indptr.numel() != int(shape[0]) + 1:
+                raise ValueError("DeviceMatrix: indptr must hold cells + 1 offsets")
+            if not (indptr.device == indices.device == data.device):
+                raise ValueError("DeviceMatrix: indptr, indices and data must live on one GPU")
             self.format = _lib.ICV_CSR
             self.indptr, self.indices, self.data = indptr, indices, data
-            self.shape = tuple(shape)
+            self.shape = (int(shape[0]), int(shape[1]))
             self.dtype = data.dtype
             self._keep = (indptr, indices, data)
+            if validate:
+                with torch.cuda.device(indptr.device):
+                    _lib.check(_lib.load().icv_csr_check(_ptr(indptr), _ptr(indices), self.shape[0], self.shape[1],
+                                                         min(indices.numel(), data.numel()), _stream_ptr(torch)))
             # host copy of the row pointers (8 B per row): slices need indptr[row0], indptr[row1]
             self.indptr_host = indptr_host if indptr_host is not None else indptr.cpu().numpy()
+
+    @property
+    def device(self):
+        return self._keep[0].device
 
     def c_struct(self, row0=0, row1=None):
         """icv_matrix for rows [row0, row1)."""
@@ -100,6 +130,7 @@ def to_device_matrix(X, dtype=None, device="cuda"):
         data = X.data if np_dtype is None else X.data.astype(np_dtype, copy=False)
         indptr64 = X.indptr.astype(np.int64, copy=False)
         return DeviceMatrix(
+            validate=False,  # canonical scipy CSR
             indptr_host=indptr64,
             indptr=torch.from_numpy(np.ascontiguousarray(indptr64)).to(device),
             indices=torch.from_numpy(np.ascontiguousarray(X.indices.astype(np.int32, copy=False))).to(device),
@@ -127,17 +158,33 @@ def column_sums(dm: DeviceMatrix, row_group=None, n_groups=1, sums=None, row0=0,
     return sums
 
 
-def column_chain(dm: DeviceMatrix, acc=None, rows=None, count=None, row0=0, row1=None):
+def column_chain(dm: DeviceMatrix, acc=None, rows=None, count=None, row0=0, row1=None, cols=None):
     """Continue the reference-order column sums (``icv_colchain``): ``acc`` (device, ``n_cols`` values of the matrix
     dtype; None = start from zero) += the rows ``rows`` (ascending indices RELATIVE to ``row0``; None = all) of
     ``dm[row0:row1]``, added one after the other as numpy's ``np.mean(X, axis=0)`` / scipy's CSR ``mean`` add them.
-    ``count``: rows of the WHOLE group (CSR input multiplies every entry by ``1 / count`` first, as scipy does)."""
+    ``count``: rows of the WHOLE group (CSR input multiplies every entry by ``1 / count`` first, as scipy does).
+    ``cols = (c0, c1)`` (dense only): only the columns [c0, c1) -- ``acc`` stays the full-width vector, its slice is
+    continued (the chains of different columns are independent: ranks pipeline over column groups, ``dist.py``)."""
     torch = _torch()
     lib = _lib.load()
     if acc is None:
         acc = torch.zeros(dm.shape[1], dtype=dm.dtype, device="cuda")
     assert acc.dtype == dm.dtype and acc.is_cuda and acc.numel() == dm.shape[1] and acc.is_contiguous()
     m = dm.c_struct(row0, row1)
+    acc_ptr = acc.data_ptr()
+    if cols is not None:
+        c0, c1 = int(cols[0]), int(cols[1])
+        if dm.format != _lib.ICV_DENSE:
+            raise ValueError("column_chain: column ranges are for dense matrices")
+        if not 0 <= c0 <= c1 <= dm.shape[1]:
+            raise ValueError("column_chain: column range out of bounds")
+        if c1 == c0:
+            return acc
+        esz = 4 if dm.dtype == torch.float32 else 8
+        m.values += c0 * esz
+        m.n_cols = c1 - c0
+        m._pad = c0  # column offset of the view inside its row (the library's bounds reasoning needs it)
+        acc_ptr += c0 * esz
     rows_d, n_sel = None, m.n_rows
     if rows is not None:
         rows = np.ascontiguousarray(rows, dtype=np.int32)
@@ -150,7 +197,7 @@ def column_chain(dm: DeviceMatrix, acc=None, rows=None, count=None, row0=0, row1
         if not count:
             raise ValueError("column_chain: CSR input needs the row count of the group")
         scale = 1.0 / float(count)
-    _lib.check(lib.icv_colchain(C.byref(m), _ptr(rows_d), n_sel, scale, _ptr(acc), _stream_ptr(torch)))
+    _lib.check(lib.icv_colchain(C.byref(m), _ptr(rows_d), n_sel, scale, C.c_void_p(acc_ptr), _stream_ptr(torch)))
     return acc
 
 
@@ -261,7 +308,7 @@ class SlabStream:
             d_data = torch.empty(max(nnz, 1), dtype=tdtype, device="cuda")
             d_indptr = torch.from_numpy(indptr64).cuda()
             self.dm = DeviceMatrix(indptr=d_indptr, indices=d_indices, data=d_data, shape=(self.n_rows, X.shape[1]),
-                                   indptr_host=indptr64)
+                                   indptr_host=indptr64, validate=False)  # (filled later, from a canonical matrix)
             idx_h, dat_h = X.indices, X.data
 
             def copy_indices(r0, r1):
@@ -386,7 +433,11 @@ def threshold_mask(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc
 
 class PackedCsr:
     """X_cnv of a row range as device CSR: ``indptr`` (rows + 1 int64, from 0), ``indices`` (int32) / ``data`` (float64)
-    buffers of which the first ``indptr[-1]`` entries are valid."""
+    buffers of which the first ``indptr[-1]`` entries are valid.
+
+    This is what ``tl.infercnv`` leaves in ``obsm["X_cnv"]`` for an HBM-resident matrix; ``tl.cnv_score``,
+    ``tl.ithcna``, ``tl.cell_linkage`` / ``tl.ward_linkage`` and ``pl.chromosome_heatmap(_summary)`` take it as they
+    take the host matrix (the tool functions work on the device arrays; only the plots copy it to the host)."""
 
     def __init__(self, indptr, indices, data, n_cols, thr=None):
         self.indptr, self.indices, self.data, self.n_cols, self.thr = indptr, indices, data, n_cols, thr
@@ -399,6 +450,10 @@ class PackedCsr:
     def shape(self):
         return (self.n_rows, self.n_cols)
 
+    @property
+    def device(self):
+        return self.indptr.device
+
     def nnz(self):
         """Number of stored entries (reads one value back: synchronises the current stream)."""
         return int(self.indptr[-1].item())
@@ -409,6 +464,36 @@ class PackedCsr:
         n = int(ip[-1])
         return sp.csr_matrix((self.data[:n].cpu().numpy(), self.indices[:n].cpu().numpy(), ip),
                              shape=(self.n_rows, self.n_cols))
+
+    def toarray(self):
+        """Host dense float64 matrix (``scipy``'s ``toarray``)."""
+        return self.to_scipy().toarray()
+
+    def dense_rows(self, rows=None):
+        """Device float32 ``len(rows) x n_cols`` tile of the selected rows (boolean mask or index array; None = all):
+        the input of the fp32 MFMA contractions (``icv_csr_densify``); the values are float32 numbers widened to
+        float64, so nothing is rounded.  Row stride padded to 16 bytes."""
+        torch = _torch()
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            rows_d, n_sel = None, self.n_rows
+            if rows is not None:
+                rows = np.asarray(rows)
+                if rows.dtype == bool:
+                    if rows.shape[0] != self.n_rows:
+                        raise IndexError("boolean row mask of the wrong length")
+                    rows = np.flatnonzero(rows)
+                rows = np.ascontiguousarray(rows, dtype=np.int64)
+                if rows.size and (rows.min() < 0 or rows.max() >= self.n_rows):
+                    raise IndexError("row index out of range")
+                n_sel = int(rows.shape[0])
+                rows_d = torch.from_numpy(rows).cuda()
+            ld = (self.n_cols + 3) // 4 * 4
+            out = torch.empty((n_sel, max(ld, 1)), dtype=torch.float32, device="cuda")[:, :self.n_cols]
+            code = _lib.ICV_F32 if self.data.dtype == torch.float32 else _lib.ICV_F64
+            _lib.check(lib.icv_csr_densify(_ptr(self.data), code, _ptr(self.indptr), _ptr(self.indices), _ptr(rows_d),
+                                           n_sel, self.n_cols, _ptr(out), out.stride(0), _stream_ptr(torch)))
+        return out
 
 
 def threshold_csr(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_clip, chunksize, row_phase=0,
@@ -828,9 +913,17 @@ def row_abs_sum(x_cnv):
 
 
 def csr_row_abs_sum(x_csr):
-    """per-row sum |x| of a host scipy CSR matrix: only indptr and the stored values go to the GPU."""
+    """per-row sum |x| of a CSR X_cnv (device float64 vector): a host scipy matrix sends only indptr and the stored
+    values to the GPU, a :class:`PackedCsr` is read where it lies."""
     torch = _torch()
     lib = _lib.load()
+    if isinstance(x_csr, PackedCsr):
+        with torch.cuda.device(x_csr.device):
+            res = torch.empty(x_csr.n_rows, dtype=torch.float64, device="cuda")
+            code = _lib.ICV_F32 if x_csr.data.dtype == torch.float32 else _lib.ICV_F64
+            _lib.check(lib.icv_csr_row_abs_sum(_ptr(x_csr.data), code, _ptr(x_csr.indptr), x_csr.n_rows, _ptr(res),
+                                               _stream_ptr(torch)))
+        return res
     x_csr = x_csr.tocsr()
     data = x_csr.data if x_csr.data.dtype in (np.float32, np.float64) else x_csr.data.astype(np.float64)
     d = torch.from_numpy(np.ascontiguousarray(data)).cuda()
@@ -841,13 +934,32 @@ def csr_row_abs_sum(x_csr):
     return res
 
 
-def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, thr=None, chunksize=5000,
-                row_phase=0, flags=0):
-    """calculate_gene_values: float64 ``rows x n_vars`` device tensor, NaN where a gene has no value."""
+def group_sums(values, codes, n_groups):
+    """(sums, counts) per group of a device float64 vector: ``codes`` (host int32, -1 = no group) names the group of
+    every element.  Fixed summation order on the device (``icv_group_sums``); host numpy arrays of length n_groups."""
     torch = _torch()
     lib = _lib.load()
-    out = torch.empty((dm.shape[0], dm.shape[1]), dtype=torch.float64, device="cuda")
-    m = dm.c_struct()
+    with torch.cuda.device(values.device):
+        codes_d = torch.from_numpy(np.ascontiguousarray(codes, dtype=np.int32)).cuda()
+        sums = torch.empty(max(n_groups, 1), dtype=torch.float64, device="cuda")
+        counts = torch.empty(max(n_groups, 1), dtype=torch.int64, device="cuda")
+        _lib.check(lib.icv_group_sums(_ptr(values), _ptr(codes_d), values.numel(), int(n_groups), _ptr(sums),
+                                      _ptr(counts), _stream_ptr(torch)))
+        return sums[:n_groups].cpu().numpy(), counts[:n_groups].cpu().numpy()
+
+
+def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, thr=None, chunksize=5000,
+                row_phase=0, flags=0, row0=0, row1=None, out=None):
+    """calculate_gene_values for rows [row0, row1): float64 ``rows x n_vars`` device tensor (``out``: written in place),
+    NaN where a gene has no value.  ``thr``: the thresholds of the chunks of THOSE rows."""
+    torch = _torch()
+    lib = _lib.load()
+    row1 = dm.shape[0] if row1 is None else row1
+    if out is None:
+        out = torch.empty((row1 - row0, dm.shape[1]), dtype=torch.float64, device="cuda")
+    assert out.dtype == torch.float64 and out.shape[0] == row1 - row0 and out.shape[1] == dm.shape[1]
+    assert out.stride(1) == 1 or out.shape[1] <= 1
+    m = dm.c_struct(row0, row1)
     _lib.check(lib.icv_gene_values(
         plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(thr), int(chunksize),
         int(row_phase), _ptr(out), out.stride(0), _stream_ptr(torch)))

@@ -22,6 +22,7 @@
 #include "icv_kernel_se.hpp"
 #include "icv_kernel_chain.hpp"
 #include "icv_kernel_pack.hpp"
+#include "icv_kernel_util.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -856,20 +857,12 @@ template <typename T>
 int colchain_dense(const icv_matrix* m, const int32_t* rows, int64_t n_sel, T* acc, hipStream_t st) {
     const icv::ChainLaunch L(m->n_cols, (int)sizeof(T), current_cu_count());
     constexpr int EPL = 16 / (int)sizeof(T);
-    // the buffer's last row goes through the guarded tail when a 16-byte segment load could run past the end
+    // the buffer's last row goes through the guarded tail when a 16-byte segment load could run past the end; with a
+    // row list the kernel itself looks whether the list ends with that row (one scalar load: nothing is read back)
     int64_t tail = -1, n_dma = n_sel;
-    if ((int64_t)(m->n_cols + EPL - 1) / EPL * EPL > m->ld) {
-        int64_t last = m->n_rows - 1;
-        if (rows) {
-            int32_t h_last = 0;
-            HIP_TRY(hipMemcpyAsync(&h_last, rows + (n_sel - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            last = h_last;
-        }
-        if (last == m->n_rows - 1) {
-            tail = last;
-            n_dma = n_sel - 1;
-        }
+    if ((int64_t)(m->_pad > 0 ? m->_pad : 0) + (int64_t)(m->n_cols + EPL - 1) / EPL * EPL > m->ld) {
+        tail = m->n_rows - 1;
+        if (!rows) n_dma = n_sel - 1;
     }
     typedef void (*kern_t)(const T*, int64_t, int, int, int, const int32_t*, int64_t, int64_t, T*);
     const kern_t kern = rows ? (kern_t)icv::k_colchain<T, true> : (kern_t)icv::k_colchain<T, false>;
@@ -2251,6 +2244,59 @@ int icv_csr_row_abs_sum(const void* data, int32_t dtype, const int64_t* indptr, 
     else
         hipLaunchKernelGGL(icv::k_csr_row_abs_sum<double>, grid, block, 0, st, static_cast<const double*>(data), indptr,
                            n_rows, row_sum);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_csr_check(const int64_t* indptr, const int32_t* indices, int64_t n_rows, int32_t n_cols, int64_t capacity,
+                  void* stream) {
+    if (!indptr || n_rows < 0 || n_cols < 0 || capacity < 0 || (capacity > 0 && !indices))
+        return fail(ICV_ERR_INVALID, "bad csr_check arguments");
+    if (n_rows == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AsyncBuf flag_b;
+    HIP_TRY(flag_b.alloc(sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(flag_b.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(icv::k_csr_check, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, indptr, indices, n_rows,
+                       n_cols, capacity, flag_b.as<int>());
+    HIP_TRY(hipGetLastError());
+    int h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flag, flag_b.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_flag & icv::kCsrBadOffsets)
+        return fail(ICV_ERR_INVALID, "device CSR: row offsets must be non-decreasing and inside the index / value buffers");
+    if (h_flag & icv::kCsrBadColumn) return fail(ICV_ERR_INVALID, "device CSR: a column index is outside [0, n_cols)");
+    if (h_flag & icv::kCsrUnsorted)
+        return fail(ICV_ERR_INVALID, "device CSR: column indices must be ascending and unique within every row "
+                                     "(scipy: sum_duplicates() / sort_indices() before the upload)");
+    return ICV_OK;
+}
+
+int icv_csr_densify(const void* data, int32_t dtype, const int64_t* indptr, const int32_t* indices, const int64_t* rows,
+                    int64_t n_sel, int32_t n_cols, float* out, int64_t ldo, void* stream) {
+    if (!indptr || !out || n_sel < 0 || n_cols < 0 || ldo < n_cols || (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad csr_densify arguments");
+    if (n_sel == 0 || n_cols == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)((n_sel - 1) * ldo + n_cols) * sizeof(float), st));
+    dim3 grid((unsigned)((n_sel + 3) / 4)), block(256);
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(icv::k_csr_densify<float>, grid, block, 0, st, static_cast<const float*>(data), indptr, indices,
+                           rows, n_sel, out, ldo);
+    else
+        hipLaunchKernelGGL(icv::k_csr_densify<double>, grid, block, 0, st, static_cast<const double*>(data), indptr,
+                           indices, rows, n_sel, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_group_sums(const double* values, const int32_t* group, int64_t n, int32_t n_groups, double* sums,
+                   int64_t* counts, void* stream) {
+    if (!sums || !counts || n < 0 || n_groups < 0 || (n > 0 && (!values || !group)))
+        return fail(ICV_ERR_INVALID, "bad group_sums arguments");
+    if (n_groups == 0) return ICV_OK;
+    hipLaunchKernelGGL(icv::k_group_sums, dim3((unsigned)n_groups), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       values, group, n, sums, counts);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

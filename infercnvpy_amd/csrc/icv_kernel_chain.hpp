@@ -224,13 +224,18 @@ __device__ __forceinline__ void chain_rounds_var(const unsigned char* smem, int 
 // row-major matrix x (sel == nullptr: rows 0..n_sel), in that order.  Workgroup b of gridDim.x owns the cache lines
 // [b * n_lines / grid, (b + 1) * n_lines / grid) of every row (1..4 lines: the caller sizes the grid); `lds_bytes` of
 // dynamic LDS (kChLdsFull / kChLdsHalf) are the ring.
-// tail_row >= 0: that row is added last by the chain wavefront with guarded loads (the caller excludes it from n_sel):
-// the one row whose 16-byte segment loads could run past the end of the buffer.
+// tail_row >= 0: the one row whose 16-byte segment loads could run past the end of the buffer (its last row, when the
+// row stride is not a multiple of 16 bytes): it is added last by the chain wavefront with guarded loads.  Without a row
+// list the caller excludes it from n_sel; with one the kernel looks whether the (ascending) list ends with it.
 template <typename T, bool LIST>
 __global__ void __launch_bounds__(kChThreads) k_colchain(const T* __restrict__ x, int64_t ld, int n_cols, int n_lines,
                                                          int lds_bytes, const int32_t* __restrict__ sel, int64_t n_sel,
                                                          int64_t tail_row, T* __restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (LIST && tail_row >= 0) {  // (uniform: kernel arguments and one scalar load)
+        if ((int64_t)sel[n_sel - 1] == tail_row) n_sel -= 1;
+        else tail_row = -1;
+    }
     typedef typename ChainLane<T>::type lane_t;
     constexpr int EPL = 16 / (int)sizeof(T);  // elements per loader lane (one 16-byte load)
     constexpr int CPL = 8 / (int)sizeof(T);   // columns per chain lane

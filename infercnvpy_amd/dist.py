@@ -115,13 +115,44 @@ def _p2p(tensor, peer, send, group=None):
         (dist.send if send else dist.recv)(tensor, peer, group=group)
 
 
-def reference_means_chained(dm_local, counts_global, local_rows=None, group=None):
+def _group_ranks(group=None):
+    """(rank in the group, group size, global rank of every group member) -- peers of send / recv / broadcast are GLOBAL
+    ranks in torch.distributed, whatever the group (the default group's ranks were used for a subgroup)."""
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1, [0]
+    size = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if group is None:
+        return rank, size, list(range(size))
+    return rank, size, [dist.get_global_rank(group, r) for r in range(size)]
+
+
+def chain_column_groups(n_cols: int, esz: int, n_groups: int):
+    """Column ranges [(c0, c1)] of the pipelined chain: ``n_groups`` runs of whole 128-byte lines (the tile unit of
+    ``k_colchain``), as even as the lines allow; fewer groups when there are fewer lines."""
+    per_line = 128 // esz
+    n_lines = -(-n_cols // per_line)
+    n_groups = max(1, min(int(n_groups), n_lines))
+    out = []
+    for t in range(n_groups):
+        l0, l1 = t * n_lines // n_groups, (t + 1) * n_lines // n_groups
+        out.append((min(n_cols, l0 * per_line), min(n_cols, l1 * per_line)))
+    return out
+
+
+def reference_means_chained(dm_local, counts_global, local_rows=None, group=None, n_col_groups=4):
     """The reference profile in the REFERENCE'S OWN evaluation order over row-sharded ranks (bit-equal to
     ``np.mean(X, axis=0)`` / scipy's CSR mean of the whole matrix, reference :385, :400): a float32 column sum is a
     sequential chain, so rank k continues the accumulators of rank k - 1 (``icv_colchain``) and hands them to rank
-    k + 1 -- R x G values point to point -- and the last rank's means are broadcast.  The ranks take turns: the pass
-    costs the sum of the ranks' kernel times (the float64 :func:`reference_means` is the concurrent alternative:
-    correctly rounded, one all-reduce, but not the reference's bits).
+    k + 1 -- R x G values point to point -- and the last rank's means are broadcast.
+
+    The chains of different columns are independent, so the hand-over is PIPELINED over ``n_col_groups`` column groups
+    (dense matrices): rank k starts group g as soon as rank k - 1 has handed that group over, while rank k - 1 works on
+    group g + 1.  With T groups and R ranks the pass costs (T + R - 1) group passes instead of R x T: (T + R - 1) / T
+    times one rank's pass (T = 1: the ranks simply take turns).  CSR shards are handed over whole (the column tiles of
+    ``k_colchain_csr`` share one bounds pass).  The float64 :func:`reference_means` is the concurrent alternative:
+    correctly rounded, one all-reduce, but not the reference's bits.
 
     ``dm_local``: this rank's rows (``_engine.DeviceMatrix``); ``counts_global``: rows per category over ALL ranks;
     ``local_rows``: per category the ascending local row indices (None: one category, all rows).  Returns the
@@ -131,26 +162,35 @@ def reference_means_chained(dm_local, counts_global, local_rows=None, group=None
     from . import _engine, _lib
 
     dist = _dist()
-    rank, size = world()
+    rank, size, peers = _group_ranks(group)
     n_groups = len(counts_global)
-    accs = torch.zeros((n_groups, dm_local.shape[1]), dtype=dm_local.dtype, device="cuda")
-    if size > 1 and rank > 0:
-        _p2p(accs, rank - 1, send=False, group=group)
-    for g in range(n_groups):
-        rows = None if local_rows is None else local_rows[g]
-        if dm_local.shape[0] and (rows is None or len(rows)):
-            _engine.column_chain(dm_local, accs[g], rows, int(counts_global[g]))
-    if size > 1 and rank < size - 1:
-        _p2p(accs, rank + 1, send=True, group=group)
+    n_cols = dm_local.shape[1]
     is_csr = dm_local.format == _lib.ICV_CSR
+    esz = 4 if dm_local.dtype == torch.float32 else 8
+    col_groups = [(0, n_cols)] if (is_csr or size == 1) else chain_column_groups(n_cols, esz, n_col_groups)
+    device = getattr(dm_local, "device", "cuda")
+    accs = torch.zeros((n_groups, n_cols), dtype=dm_local.dtype, device=device)
+    for c0, c1 in col_groups:
+        whole = c0 == 0 and c1 == n_cols
+        if size > 1 and rank > 0:
+            buf = accs if whole else torch.empty((n_groups, c1 - c0), dtype=accs.dtype, device=device)
+            _p2p(buf, peers[rank - 1], send=False, group=group)
+            if not whole:
+                accs[:, c0:c1] = buf
+        for g in range(n_groups):
+            rows = None if local_rows is None else local_rows[g]
+            if dm_local.shape[0] and (rows is None or len(rows)):
+                _engine.column_chain(dm_local, accs[g], rows, int(counts_global[g]), cols=None if whole else (c0, c1))
+        if size > 1 and rank < size - 1:
+            _p2p(accs if whole else accs[:, c0:c1].contiguous(), peers[rank + 1], send=True, group=group)
     means = torch.stack([_engine.chain_mean(accs[g], int(counts_global[g]), is_csr) for g in range(n_groups)])
     if size > 1:
         if means.is_cuda and dist.get_backend(group) != "nccl":
             h = means.cpu()
-            dist.broadcast(h, size - 1, group=group)
+            dist.broadcast(h, peers[size - 1], group=group)
             means.copy_(h)
         else:
-            dist.broadcast(means, size - 1, group=group)
+            dist.broadcast(means, peers[size - 1], group=group)
     return means
 
 

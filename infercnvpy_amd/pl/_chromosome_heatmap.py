@@ -22,6 +22,12 @@ import numpy as np
 import scipy.sparse as sp
 
 
+def _host_matrix(x):
+    """``obsm["X_cnv"]`` as the plots read it: a device-resident ``PackedCsr`` (tl.infercnv on a matrix in HBM) is copied
+    to a host scipy CSR matrix here, at the plot boundary (reference :55 reads the matrix as infercnv wrote it)."""
+    return x.to_scipy() if hasattr(x, "to_scipy") and hasattr(x, "dense_rows") else x
+
+
 def _sorted_chr_pos(adata, use_rep):
     # re-sort: saving and loading AnnData does not keep dict order (reference :57-59)
     items = sorted(adata.uns[use_rep]["chr_pos"].items(), key=lambda kv: kv[1])
@@ -139,7 +145,8 @@ def chromosome_heatmap(adata, *, groupby: str = "cnv_leiden", use_rep: str = "cn
     """Heatmap of smoothed gene expression by chromosome (reference :11-92)."""
     if groupby == "cnv_leiden" and "cnv_leiden" not in adata.obs.columns:
         raise ValueError("'cnv_leiden' is not in `adata.obs`. Did you run `tl.leiden()`?")
-    x = adata.obsm[f"X_{use_rep}"]
+    x_dev = adata.obsm[f"X_{use_rep}"]
+    x = _host_matrix(x_dev)
     chr_names, chr_pos = _sorted_chr_pos(adata, use_rep)
 
     data = x.data if sp.issparse(x) else np.asarray(x)
@@ -173,7 +180,7 @@ def chromosome_heatmap_summary(adata, *, groupby: str = "cnv_leiden", use_rep: s
     """Heatmap of per-group mean smoothed expression, each group drawn 10 rows high (reference :95-193)."""
     if groupby == "cnv_leiden" and "cnv_leiden" not in adata.obs.columns:
         raise ValueError("'cnv_leiden' is not in `adata.obs`. Did you run `tl.leiden()`?")
-    x = adata.obsm[f"X_{use_rep}"]
+    x = _host_matrix(adata.obsm[f"X_{use_rep}"])
     groups = _categories(adata.obs[groupby])  # reference: adata.obs[groupby].unique() of a categorical column
     labels = np.asarray(adata.obs[groupby].values)
 

@@ -72,6 +72,17 @@ def _means_from_chains(accs, counts, cats, is_sparse):
     return np.vstack(rows)
 
 
+def _means_from_sums(shard_sums, counts, cats, dtype):
+    """R x G means from the shards' float64 column sums (``mean_order="float64"``): the shards are added in row order,
+    the quotient is rounded once to the matrix dtype."""
+    total = shard_sums[0].copy()
+    for part in shard_sums[1:]:
+        total += part
+    cnt = np.atleast_1d(np.asarray(counts, dtype=np.float64))
+    rows = list((total / cnt[:, None]).astype(dtype))
+    return np.vstack(_repeat_rows(rows, cats))
+
+
 def _current_first(torch, n_dev):
     """The visible GPUs, the caller's current device first (a caller that did ``torch.cuda.set_device(3)`` gets GPU 3
     for ``n_jobs=1`` and GPU 3 among the first for more: ADVICE r3)."""
@@ -125,35 +136,114 @@ class _Shard:
         self.accs = None        # host, per group: reference-order accumulators after this shard's rows
 
 
-_PLAN_CACHE = {}
+_PLAN_CACHE = {}  # key -> _PlanEntry, most recently used last
 _PLAN_CACHE_LOCK = threading.Lock()
 _PLAN_CACHE_MAX = 8
 
 
-def _cached_plan(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
-    """GenePlan for calls on HBM-resident matrices, kept between calls: planning the gene order costs ~9 ms of host time
-    at 20 000 genes, three times the GPU time of 100 000 cells.  Keyed by the CONTENT of the annotation (an object
-    column by the identity of its immutable string objects, which the cache entry keeps alive), the window geometry
-    and the device; the eight most recent plans are kept."""
+class _PlanEntry:
+    """The plans of one (annotation, geometry, device): idle ones wait for the next call, ``busy`` counts the calls
+    that hold one.  A plan admits one compute call at a time (it owns the per-call device workspace), so concurrent
+    callers each check out their own."""
+
+    def __init__(self, make):
+        self.make, self.idle, self.busy, self.evicted = make, [], 0, False
+
+
+def _plan_key(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
+    """Key by the CONTENT of the annotation: object / string columns through their factorised codes and category
+    strings (not through object addresses: ADVICE r4), numeric columns through their bytes."""
+    import pandas as pd
+
     chrom, start = np.asarray(var_chrom), np.asarray(var_start)
+    if chrom.dtype.kind in "OUS":
+        codes, uniques = pd.factorize(chrom, use_na_sentinel=True)
+        ckey = (codes.astype(np.int32).tobytes(), tuple(str(u) for u in uniques))
+    else:
+        ckey = (chrom.dtype.str, chrom.tobytes())
+    if start.dtype.kind == "O":
+        skey = ("O", pd.to_numeric(pd.Series(start), errors="coerce").to_numpy(dtype=np.float64, na_value=np.nan).tobytes())
+    else:
+        skey = (start.dtype.str, start.tobytes())
     excl = None if exclude_chromosomes is None else tuple(exclude_chromosomes)
-    key = (chrom.dtype.str, chrom.tobytes(), start.dtype.str, start.tobytes(), int(window_size), int(step), excl,
-           int(device))
+    return (ckey, skey, int(window_size), int(step), excl, int(device))
+
+
+def _plan_entry(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
+    """(key, entry) of the cache, created and moved to the most-recent end; evicts the least recently used entries
+    that no call holds (their idle plans are closed; an entry in use is closed when its last plan comes back)."""
+    key = _plan_key(var_chrom, var_start, window_size, step, exclude_chromosomes, device)
+    ent = _PLAN_CACHE.pop(key, None)
+    if ent is None:
+        chrom, start = np.array(var_chrom, copy=True), np.array(var_start, copy=True)  # (not a view of the DataFrame)
+
+        def make():
+            return GenePlan(chrom, start, window_size=window_size, step=step, exclude_chromosomes=exclude_chromosomes)
+
+        ent = _PlanEntry(make)
+    _PLAN_CACHE[key] = ent
+    for k in list(_PLAN_CACHE):
+        if len(_PLAN_CACHE) <= _PLAN_CACHE_MAX:
+            break
+        if k == key:
+            continue
+        old = _PLAN_CACHE.pop(k)
+        old.evicted = True
+        while old.idle:
+            old.idle.pop().close()
+    return key, ent
+
+
+def _checkout_plan(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
+    """A GenePlan for ONE call on an HBM-resident matrix, kept between calls: planning the gene order costs ~9 ms of
+    host time at 20 000 genes, three times the GPU time of 100 000 cells.  Returns ``(entry, plan)``; hand the plan
+    back with :func:`_checkin_plan`.  Two threads calling at once get two plans (a shared plan answered the
+    second with "plan busy", and an eviction could destroy a plan in use)."""
     with _PLAN_CACHE_LOCK:
-        ent = _PLAN_CACHE.pop(key, None)
-        if ent is None:
-            ent = (GenePlan(chrom, start, window_size=window_size, step=step, exclude_chromosomes=exclude_chromosomes),
-                   chrom)
-        _PLAN_CACHE[key] = ent  # most recently used last
-        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
-            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))[0].close()
-        return ent[0]
+        _, ent = _plan_entry(var_chrom, var_start, window_size, step, exclude_chromosomes, device)
+        plan = ent.idle.pop() if ent.idle else None
+        ent.busy += 1
+    if plan is None:
+        try:
+            plan = ent.make()
+        except BaseException:
+            with _PLAN_CACHE_LOCK:
+                ent.busy -= 1
+            raise
+    return ent, plan
+
+
+def _checkin_plan(ent, plan):
+    with _PLAN_CACHE_LOCK:
+        ent.busy -= 1
+        if ent.evicted:
+            plan.close()
+        else:
+            ent.idle.append(plan)
+
+
+def _cached_plan(var_chrom, var_start, window_size, step, exclude_chromosomes, device):
+    """The idle plan the next single-threaded resident call with these arguments will use (created if there is none):
+    for callers that attach to it between calls (``bench.py``: ``icv_profile_begin`` / ``_collect``)."""
+    with _PLAN_CACHE_LOCK:
+        _, ent = _plan_entry(var_chrom, var_start, window_size, step, exclude_chromosomes, device)
+        if not ent.idle:
+            ent.idle.append(ent.make())
+        return ent.idle[-1]
 
 
 def _clear_plan_cache():
     with _PLAN_CACHE_LOCK:
         while _PLAN_CACHE:
-            _PLAN_CACHE.popitem()[1][0].close()
+            ent = _PLAN_CACHE.popitem()[1]
+            ent.evicted = True
+            while ent.idle:
+                ent.idle.pop().close()
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_clear_plan_cache)  # cached plans own device buffers: release them before the HIP runtime goes
 
 
 def _resident_matrix(X, torch):
@@ -168,85 +258,170 @@ def _resident_matrix(X, torch):
     return None
 
 
-def _infercnv_resident(adata, dm, *, reference_key, reference_cat, reference, lfc_clip, window_size, step,
-                       dynamic_threshold, exclude_chromosomes, chunksize, inplace, key_added, calculate_gene_values, tm):
+def _is_real_anndata(adata):
+    mod = type(adata).__module__ or ""
+    return mod == "anndata" or mod.startswith("anndata.")
+
+
+def _repeat_rows(rows, cats):
+    """Per-category rows in the order the categories were listed (the same label listed twice: its row repeats)."""
+    if cats is None:
+        return rows
+    labels = cats.tolist()
+    if len(set(labels)) == len(labels):
+        return rows
+    first = {c: i for i, c in reversed(list(enumerate(labels)))}
+    return [rows[first[c]] for c in labels]
+
+
+def _infercnv_resident(var, obs, dm, *, reference_key, reference_cat, reference, lfc_clip, window_size, step,
+                       dynamic_threshold, exclude_chromosomes, chunksize, calculate_gene_values, mean_order, tm):
     """The call on a matrix that is resident in HBM (no host copies, no synchronisation): reference means as chains on
-    the device, one smoothing launch, threshold + CSR pack in one pass; ``X_cnv`` stays on the device as a
-    :class:`infercnvpy_amd.PackedCsr` (``.to_scipy()`` for the host matrix)."""
+    the device, one smoothing launch per piece, threshold + CSR pack; returns ``(chr_pos, PackedCsr, gene values |
+    None)`` with everything still on the device."""
     torch = _engine._torch()
     t_start = _time.perf_counter()
     dev = dm._keep[0].device.index
     n_obs, n_vars = dm.shape
     with torch.cuda.device(dev):
-        plan = _cached_plan(adata.var["chromosome"].to_numpy(), adata.var["start"].to_numpy(), window_size, step,
-                            exclude_chromosomes, dev)
-        if plan.n_without_position:
-            log.warning(f"Skipped {plan.n_without_position} genes because they don't have a genomic position annotated. ")
-        is_csr = dm.format == _lib.ICV_CSR
-        np_dtype = np.float32 if dm.dtype == torch.float32 else np.float64
-        flags = 0
-        if reference is not None:
-            given = np.asarray(reference)
-            if given.ndim == 1:
-                given = given[np.newaxis, :]
-            if given.shape[1] != n_vars:
-                raise ValueError("Reference must match the number of genes in AnnData. ")
-            if np.result_type(np_dtype, given.dtype) != np_dtype:
-                raise ValueError("a device-resident matrix needs a reference of its own (or a narrower) dtype: "
-                                 "numpy would promote the subtraction (pass the matrix as float64)")
-            ref = torch.from_numpy(np.ascontiguousarray(given.astype(np_dtype))).cuda()
-        else:
-            groups = cats = None
-            if reference_key is None or reference_cat is None:
-                log.warning("Using mean of all cells as reference. For better results, provide either "
-                            "`reference`, or both `reference_key` and `reference_cat`. ")
-                counts = [n_obs]
+        ent, plan = _checkout_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), window_size, step,
+                                   exclude_chromosomes, dev)
+        try:
+            if plan.n_without_position:
+                log.warning(f"Skipped {plan.n_without_position} genes because they don't have a genomic position annotated. ")
+            is_csr = dm.format == _lib.ICV_CSR
+            np_dtype = np.float32 if dm.dtype == torch.float32 else np.float64
+            flags = 0
+            if reference is not None:
+                given = np.asarray(reference)
+                if given.ndim == 1:
+                    given = given[np.newaxis, :]
+                if given.shape[1] != n_vars:
+                    raise ValueError("Reference must match the number of genes in AnnData. ")
+                if np.result_type(np_dtype, given.dtype) != np_dtype:
+                    raise ValueError("a device-resident matrix needs a reference of its own (or a narrower) dtype: "
+                                     "numpy would promote the subtraction (pass the matrix as float64)")
+                ref = torch.from_numpy(np.ascontiguousarray(given.astype(np_dtype))).cuda()
             else:
-                groups, counts, cats = _reference_groups(adata.obs, reference_key, reference_cat)
-            rows = []
-            for gi, n_g in enumerate(counts):
-                sel = None if groups is None else np.nonzero(groups == gi)[0]
-                acc = _engine.column_chain(dm, None, sel, int(n_g))
-                rows.append(_engine.chain_mean(acc, int(n_g), is_csr))
-            if cats is not None:
-                labels = cats.tolist()
-                first = {c: i for i, c in reversed(list(enumerate(labels)))}
-                rows = [rows[first[c]] for c in labels]
-            ref = torch.stack(rows)
-        if ref.shape[0] == 1:
-            ref_lo, ref_hi = ref[0].contiguous(), None
-        else:
-            ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
-        # pieces of whole chunks whose result buffers (4 + 12 bytes per window, worst case) fit next to the matrix
-        free_b, _ = torch.cuda.mem_get_info()
-        per_row = 16 * plan.n_windows + 64 + (8 * (2 * n_vars + plan.n_windows) if calculate_gene_values else 0)
-        piece = max(chunksize, int(0.4 * free_b // per_row) // chunksize * chunksize)
-        parts, genes = [], []
-        for r0 in range(0, max(n_obs, 1), piece):
-            r1 = min(n_obs, r0 + piece)
-            res = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, dynamic_threshold=dynamic_threshold,
-                                       chunksize=chunksize, flags=flags, row0=r0, row1=r1, apply=False)
-            parts.append(_engine.threshold_csr(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
-                                               flags=flags, row0=r0, row1=r1))
+                groups = cats = None
+                if reference_key is None or reference_cat is None:
+                    log.warning("Using mean of all cells as reference. For better results, provide either "
+                                "`reference`, or both `reference_key` and `reference_cat`. ")
+                    counts = [n_obs]
+                else:
+                    groups, counts, cats = _reference_groups(obs, reference_key, reference_cat)
+                if mean_order == "float64":
+                    # opt-in: float64 column sums (one concurrent pass, correctly rounded means -- not numpy's order)
+                    sums = _engine.column_sums(dm, groups, len(counts))
+                    cnt = torch.as_tensor(np.asarray(counts, dtype=np.float64)).cuda()
+                    rows = list((sums / cnt[:, None]).to(dm.dtype))
+                else:
+                    rows = []
+                    for gi, n_g in enumerate(counts):
+                        sel = None if groups is None else np.nonzero(groups == gi)[0]
+                        acc = _engine.column_chain(dm, None, sel, int(n_g))
+                        rows.append(_engine.chain_mean(acc, int(n_g), is_csr))
+                ref = torch.stack(_repeat_rows(rows, cats))
+            if ref.shape[0] == 1:
+                ref_lo, ref_hi = ref[0].contiguous(), None
+            else:
+                ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
+            # pieces of whole chunks whose result buffers (4 + 12 bytes per window, worst case) fit next to the matrix
+            free_b, _ = torch.cuda.mem_get_info()
+            per_row = 16 * plan.n_windows + 64 + (8 * (n_vars + plan.n_windows) if calculate_gene_values else 0)
             if calculate_gene_values:
-                if r0 != 0 or r1 != n_obs:
-                    raise NotImplementedError("calculate_gene_values on a device matrix that needs several pieces")
-                genes.append(_engine.gene_values(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr,
-                                                 chunksize=chunksize, flags=flags))
-            del res
-        x_cnv = parts[0] if len(parts) == 1 else _engine.concat_packed(parts)
-        tm["kernel"] = plan.last_kernel()
-        tm["devices"] = [dev]
-        tm["total"] = _time.perf_counter() - t_start  # host time only: nothing has been waited for
-        chr_pos = dict(plan.chr_pos)
-    per_gene = genes[0] if genes else None
-    if inplace:
-        adata.obsm[f"X_{key_added}"] = x_cnv
-        adata.uns[key_added] = {"chr_pos": chr_pos}
-        if calculate_gene_values:
-            adata.layers[f"gene_values_{key_added}"] = per_gene
-        return None
-    return chr_pos, x_cnv, per_gene
+                free_b = max(free_b - 8 * n_vars * n_obs, free_b // 8)  # the float64 gene matrix of ALL rows stays
+            piece = max(chunksize, int(0.4 * free_b // per_row) // chunksize * chunksize)
+            parts = []
+            genes = torch.empty((n_obs, n_vars), dtype=torch.float64, device="cuda") if calculate_gene_values else None
+            for r0 in range(0, max(n_obs, 1), piece):
+                r1 = min(n_obs, r0 + piece)
+                res = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
+                                           dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
+                                           row0=r0, row1=r1, apply=False)
+                parts.append(_engine.threshold_csr(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
+                                                   chunksize=chunksize, flags=flags, row0=r0, row1=r1))
+                if calculate_gene_values and r1 > r0:
+                    # (pieces are whole chunks: the piece's thresholds are the thresholds of its rows' chunks)
+                    _engine.gene_values(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr, chunksize=chunksize,
+                                        flags=flags, row0=r0, row1=r1, out=genes[r0:r1])
+                del res
+            x_cnv = parts[0] if len(parts) == 1 else _engine.concat_packed(parts)
+            tm["kernel"] = plan.last_kernel()
+            tm["devices"] = [dev]
+            tm["pieces"] = len(parts)
+            tm["total"] = _time.perf_counter() - t_start  # host time only: nothing has been waited for
+            chr_pos = dict(plan.chr_pos)
+        finally:
+            _checkin_plan(ent, plan)
+    return chr_pos, x_cnv, genes
+
+
+def _check_var(var, var_names):
+    if not var_names.is_unique:
+        raise ValueError("Ensure your var_names are unique!")
+    if {"chromosome", "start", "end"} - set(var.columns) != set():
+        raise ValueError(
+            "Genomic positions not found. There need to be `chromosome`, `start`, and `end` columns in `adata.var`. ")
+
+
+def _check_mean_order(mean_order):
+    if mean_order not in ("reference", "float64"):
+        raise ValueError("mean_order must be 'reference' (numpy's / scipy's evaluation order) or 'float64'")
+
+
+def infercnv_device(
+    X,
+    var,
+    obs=None,
+    *,
+    reference_key: str | None = None,
+    reference_cat: None | str | Sequence[str] = None,
+    reference: np.ndarray | None = None,
+    lfc_clip: float = 3,
+    window_size: int = 100,
+    step: int = 10,
+    dynamic_threshold: float | None = 1.5,
+    exclude_chromosomes: Sequence[str] | None = ("chrX", "chrY"),
+    chunksize: int = 5000,
+    calculate_gene_values: bool = False,
+    mean_order: str = "reference",
+    _timings: dict | None = None,
+):
+    """``tl.infercnv`` for a matrix that already lives in HBM, without an AnnData container (not part of the reference
+    API): ``X`` is a CUDA ``torch.Tensor`` (cells x genes, float32 / float64) or an ``infercnvpy_amd.DeviceMatrix``,
+    ``var`` the genes' annotation (``adata.var``: ``chromosome``, ``start``, ``end``, unique index), ``obs`` the
+    cells' (``adata.obs``; needed for ``reference_key``).  The other arguments mean what they mean in
+    :func:`infercnv`.
+
+    Returns ``(chr_pos, x_cnv, gene_values)``: ``x_cnv`` an ``infercnvpy_amd.PackedCsr`` (device CSR float64),
+    ``gene_values`` a device float64 tensor or None.  Nothing is copied from or to the host and the call does not wait
+    for the GPU.  This is the entry point for users of a real ``anndata.AnnData``, which does not accept device
+    tensors in ``X`` / ``layers`` / ``obsm``::
+
+        chr_pos, x_cnv, _ = cnv.tl.infercnv_device(X_gpu, adata.var, adata.obs, reference_key="cell_type", ...)
+        adata.obsm["X_cnv"] = x_cnv.to_scipy()          # the reference's host matrix
+        adata.uns["cnv"] = {"chr_pos": chr_pos}
+    """
+    _check_var(var, var.index)
+    _check_mean_order(mean_order)
+    _lib.load()
+    dm = _resident_matrix(X, sys.modules.get("torch"))
+    if dm is None:
+        raise ValueError("infercnv_device: X must be a CUDA torch.Tensor or an infercnvpy_amd.DeviceMatrix "
+                         "(host matrices go through tl.infercnv)")
+    if dm.shape[1] != len(var):
+        raise ValueError("X must have one column per row of `var`")
+    if reference is None and reference_key is not None and reference_cat is not None and obs is None:
+        raise ValueError("reference_key needs `obs`")
+    chunksize = int(chunksize)
+    if chunksize < 1:
+        raise ValueError("chunksize must be >= 1")
+    return _infercnv_resident(
+        var, obs, dm, reference_key=reference_key, reference_cat=reference_cat, reference=reference,
+        lfc_clip=lfc_clip, window_size=window_size, step=step, dynamic_threshold=dynamic_threshold,
+        exclude_chromosomes=exclude_chromosomes, chunksize=chunksize, calculate_gene_values=calculate_gene_values,
+        mean_order=mean_order, tm=_timings if _timings is not None else {})
 
 
 def infercnv(
@@ -267,6 +442,7 @@ def infercnv(
     key_added: str = "cnv",
     calculate_gene_values: bool = False,
     devices: Sequence[int] | None = None,
+    mean_order: str = "reference",
     _timings: dict | None = None,
 ):
     """Infer copy number variation by averaging gene expression over genomic regions (GPU).
@@ -304,7 +480,19 @@ def infercnv(
     ``infercnvpy_amd.DeviceMatrix`` (dense or CSR device arrays) -- is processed in place on its GPU: nothing is copied
     from or to the host, the call returns without waiting for the GPU, and ``obsm["X_cnv"]`` is an
     ``infercnvpy_amd.PackedCsr`` (device CSR; ``.to_scipy()`` gives the reference's host matrix, bit-identical to the
-    host-input call).  ``n_jobs`` / ``devices`` do not apply to it.
+    host-input call).  ``n_jobs`` / ``devices`` do not apply to it.  ``tl.cnv_score``, ``tl.ithcna``,
+    ``tl.cell_linkage`` and ``pl.chromosome_heatmap(_summary)`` take that object as they take the host matrix.  This
+    works with the duck-typed ``infercnvpy_amd.SimpleAnnData`` (any container with ``X, obs, var, obsm, uns, layers``);
+    a real ``anndata.AnnData`` refuses device tensors in ``X``, so its users call :func:`infercnv_device` (same
+    arguments, explicit ``X, var, obs``) and store ``x_cnv.to_scipy()`` -- and should this function ever be handed a
+    real AnnData with a resident matrix, it writes the reference's host objects into it.
+
+    ``mean_order`` (not part of the reference API; applies when the reference profile is a mean over cells):
+    ``"reference"`` (default) forms the means in numpy's / scipy's own evaluation order -- the reference's bits, but a
+    sequential chain per column, so several GPUs take turns on it; ``"float64"`` is the opt-in for multi-GPU jobs that
+    prefer speed: every GPU adds float64 column sums of its rows concurrently and the host adds the shards' sums
+    (correctly rounded means; ~1e-3 of the ``X_cnv`` entries next to the noise threshold may fall on the other side
+    than in the reference).
 
     Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
     while the pieces that have landed are smoothed (reference means: chained); the noise threshold and the CSR
@@ -313,21 +501,33 @@ def infercnv(
     """
     tm = _timings if _timings is not None else {}
     t_start = _time.perf_counter()
-    if not adata.var_names.is_unique:
-        raise ValueError("Ensure your var_names are unique!")
-    if {"chromosome", "start", "end"} - set(adata.var.columns) != set():
-        raise ValueError(
-            "Genomic positions not found. There need to be `chromosome`, `start`, and `end` columns in `adata.var`. ")
+    _check_var(adata.var, adata.var_names)
+    _check_mean_order(mean_order)
     _lib.load()  # fail loudly before doing any work if the HIP extension is missing
 
     X0 = adata.X if layer is None else adata.layers[layer]
     dm0 = _resident_matrix(X0, sys.modules.get("torch"))
     if dm0 is not None:
-        return _infercnv_resident(
-            adata, dm0, reference_key=reference_key, reference_cat=reference_cat, reference=reference,
+        chunksize = int(chunksize)
+        if chunksize < 1:
+            raise ValueError("chunksize must be >= 1")
+        chr_pos, x_cnv, per_gene = _infercnv_resident(
+            adata.var, adata.obs, dm0, reference_key=reference_key, reference_cat=reference_cat, reference=reference,
             lfc_clip=lfc_clip, window_size=window_size, step=step, dynamic_threshold=dynamic_threshold,
-            exclude_chromosomes=exclude_chromosomes, chunksize=int(chunksize), inplace=inplace, key_added=key_added,
-            calculate_gene_values=calculate_gene_values, tm=tm)
+            exclude_chromosomes=exclude_chromosomes, chunksize=chunksize,
+            calculate_gene_values=calculate_gene_values, mean_order=mean_order, tm=tm)
+        if not inplace:
+            return chr_pos, x_cnv, per_gene
+        if _is_real_anndata(adata):
+            # anndata validates what goes into obsm / layers and takes neither a PackedCsr nor a device tensor: a real
+            # AnnData gets the reference's host objects (tl.infercnv_device keeps the result on the GPU)
+            x_cnv = x_cnv.to_scipy()
+            per_gene = per_gene.cpu().numpy() if per_gene is not None else None
+        adata.obsm[f"X_{key_added}"] = x_cnv
+        adata.uns[key_added] = {"chr_pos": chr_pos}
+        if calculate_gene_values:
+            adata.layers[f"gene_values_{key_added}"] = per_gene
+        return None
 
     var_chrom, var_start = adata.var["chromosome"].to_numpy(), adata.var["start"].to_numpy()
     plan_kw = dict(window_size=window_size, step=step, exclude_chromosomes=exclude_chromosomes)
@@ -398,7 +598,8 @@ def infercnv(
     tm["plan"] = _time.perf_counter() - t_start
     tm["devices"] = list(devs)
 
-    if need_means and X_csc is not None:
+    f64_means = need_means and mean_order == "float64"
+    if need_means and X_csc is not None and not f64_means:
         # CSC input: np.add.reduceat per column over ALL rows of the group -- not separable by row shards; the CSC
         # arrays go to the first GPU in column blocks (values + row indices, 8 bytes per stored entry)
         t0 = _time.perf_counter()
@@ -464,7 +665,27 @@ def infercnv(
             return streams[i]
 
         try:
-            if need_means:
+            if f64_means:
+                # opt-in: float64 column sums of this shard's rows, all shards at once; the host adds the shards' sums
+                t0 = _time.perf_counter()
+                sums = torch.zeros((n_groups, n_vars), dtype=torch.float64, device="cuda")
+                for i, (s0, _) in enumerate(slabs):
+                    ss = slab_stream(i)
+                    for r0, r1 in ss.pieces():
+                        rg = None if groups is None else groups[s.g0 + s0 + r0: s.g0 + s0 + r1]
+                        _engine.column_sums(ss.dm, rg, n_groups, sums, r0, r1)
+                    ss = None
+                s.accs = sums.cpu().numpy()
+                if multi:
+                    barrier.wait()
+                    if s.index == 0:
+                        ref_box["ref"] = _means_from_sums([sh.accs for sh in shards], counts, cats, mean_dtype)
+                    barrier.wait()
+                    ref = ref_box["ref"]
+                else:
+                    ref = _means_from_sums([s.accs], counts, cats, mean_dtype)
+                s.tm["reference_pass"] = _time.perf_counter() - t0
+            elif need_means:
                 t0 = _time.perf_counter()
                 if slabs:
                     slab_stream(0)  # the upload starts now, whatever this shard has to wait for

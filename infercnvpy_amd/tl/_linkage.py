@@ -16,23 +16,34 @@ from .. import _engine
 
 
 def ward_linkage(X, *, return_rounds: bool = False):
-    """Ward linkage (scipy format, ``(n - 1) x 4`` float64) of the rows of ``X`` (dense or sparse host matrix).
+    """Ward linkage (scipy format, ``(n - 1) x 4`` float64) of the rows of ``X`` (dense or sparse host matrix, or the
+    device-resident :class:`infercnvpy_amd.PackedCsr` that ``tl.infercnv`` leaves in ``obsm["X_cnv"]`` for a matrix in
+    HBM: config 5's input then never leaves the GPU).
 
     The distance matrix lives in HBM: ``6 n^2`` bytes with the spare columns the Ward rounds like (200 000 cells:
     240 GB of the 288 GB; Ward 0.53 s), ``4 n^2`` without them when memory is short (160 GB; Ward 0.97 s).  For
     more cells than one GPU holds: ``infercnvpy_amd.dist.ward_linkage_sharded``.
     """
     torch = _engine._torch()
-    if sp.issparse(X):
-        X = X.toarray()
-    X = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
-    if X.ndim != 2:
-        raise ValueError("X must be a 2-D matrix (cells x features)")
-    if not np.isfinite(X).all():
-        raise ValueError("The condensed distance matrix must contain only finite values.")  # scipy's error
-    if X.shape[0] < 2:
-        raise ValueError("at least two cells are needed for a linkage")
-    xd = torch.from_numpy(X).cuda()
+    if isinstance(X, _engine.PackedCsr):  # X_cnv of a device-resident tl.infercnv call: densified in HBM
+        if X.n_rows < 2:
+            raise ValueError("at least two cells are needed for a linkage")
+        xd = X.dense_rows()
+        if not bool(torch.isfinite(xd).all()):
+            raise ValueError("The condensed distance matrix must contain only finite values.")  # scipy's error
+    else:
+        if torch.is_tensor(X):
+            X = X.detach().cpu().numpy()
+        if sp.issparse(X):
+            X = X.toarray()
+        X = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
+        if X.ndim != 2:
+            raise ValueError("X must be a 2-D matrix (cells x features)")
+        if not np.isfinite(X).all():
+            raise ValueError("The condensed distance matrix must contain only finite values.")  # scipy's error
+        if X.shape[0] < 2:
+            raise ValueError("at least two cells are needed for a linkage")
+        xd = torch.from_numpy(X).cuda()
     d2 = _engine.pairwise_sqeuclidean(xd, spare=True)
     del xd
     Z, rounds = _engine.ward_linkage(d2, spare=_engine.has_spare_columns(d2))

@@ -13,7 +13,9 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
               inplace: bool = True, obs_key=None):
     """score[group] = mean(|X_cnv[cells of group, :]|), zeros included (reference :65-68).
 
-    The per-cell ``sum |x|`` runs on the GPU in float64; groups are combined on the host.
+    The per-cell ``sum |x|`` and the per-group sums run on the GPU in float64.  ``obsm["X_cnv"]`` may be the host CSR
+    matrix of a host-input ``tl.infercnv`` call, a dense array, or the device-resident
+    :class:`infercnvpy_amd.PackedCsr` of a call on an HBM-resident matrix (nothing is copied then).
     """
     if obs_key is not None:
         warnings.warn(
@@ -29,18 +31,24 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
     torch = _engine._torch()
     x = adata.obsm[f"X_{use_rep}"]
     n_win = x.shape[1]
-    if sp.issparse(x):  # what tl.infercnv writes: CSR float64 -- only the stored values travel, in float64
-        row_abs = _engine.csr_row_abs_sum(x).cpu().numpy()
+    if isinstance(x, _engine.PackedCsr):  # X_cnv of a device-resident call: read where it lies, nothing is uploaded
+        row_abs = _engine.csr_row_abs_sum(x)
+    elif sp.issparse(x):  # what tl.infercnv writes: CSR float64 -- only the stored values travel, in float64
+        row_abs = _engine.csr_row_abs_sum(x)
     else:
         x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
-        row_abs = _engine.row_abs_sum(torch.from_numpy(x).cuda()).cpu().numpy()
+        row_abs = _engine.row_abs_sum(torch.from_numpy(x).cuda())
 
+    # group sums on the device in a fixed order (icv_group_sums): K sums and counts come back, and a host X_cnv and a
+    # device-resident one give the same bits
     labels = adata.obs[groupby]
     values = np.asarray(labels.values if hasattr(labels, "values") else labels)
-    cluster_score = {}
-    for cluster in labels.unique():
-        sel = values == cluster
-        cluster_score[cluster] = np.float64(row_abs[sel].sum() / (int(sel.sum()) * n_win))
+    clusters = list(labels.unique())
+    codes = np.full(values.shape[0], -1, dtype=np.int32)
+    for gi, cluster in enumerate(clusters):
+        codes[values == cluster] = gi
+    sums, counts = _engine.group_sums(row_abs, codes, len(clusters))
+    cluster_score = {cluster: np.float64(sums[gi] / (int(counts[gi]) * n_win)) for gi, cluster in enumerate(clusters)}
 
     if inplace:
         adata.obs[key_added] = np.array([cluster_score[c] for c in adata.obs[groupby]])
@@ -58,12 +66,17 @@ def _group_iqr(adata, groupby, get_matrix, key_added, inplace):
     for group in groups:
         sel = values == group
         X = get_matrix(sel)
-        if sp.issparse(X):
-            X = X.toarray()
-        X = np.asarray(X)
+        if torch.is_tensor(X):  # rows of a device-resident PackedCsr, densified on the GPU (float32 tile)
+            xd = X
+        else:
+            if sp.issparse(X):
+                X = X.toarray()
+            X = np.asarray(X)
+            xd = None
         if X.shape[0] <= 1:
             continue
-        xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
+        if xd is None:
+            xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).cuda()
         scores[group] = np.float64(_engine.corr_iqr(xd))
     if inplace:
         obs = np.empty(adata.shape[0])
@@ -99,4 +112,9 @@ def ithcna(adata, groupby: str, *, use_rep: str = "X_cnv", key_added: str = "ith
 
     Drop-in for ``infercnvpy.tl.ithcna`` (reference tl/_scores.py:154-221).
     """
-    return _group_iqr(adata, groupby, lambda sel: adata.obsm[use_rep][sel], key_added, inplace)
+    def get(sel):
+        x = adata.obsm[use_rep]
+        # X_cnv left on the device by tl.infercnv: the group's rows become a float32 tile without leaving HBM
+        return x.dense_rows(sel) if isinstance(x, _engine.PackedCsr) else x[sel]
+
+    return _group_iqr(adata, groupby, get, key_added, inplace)

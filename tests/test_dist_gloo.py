@@ -384,3 +384,92 @@ def test_ward_layout_is_balanced_and_complete():
         assert len(seen) == ns * (ns + 1) // 2
         assert max(counts) - min(counts) <= ns, (n, world, counts)
         assert sum(L.k) == ns and max(L.k) - min(L.k) <= 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference-order chains handed from rank to rank, pipelined over column groups (dist.reference_means_chained)
+# ----------------------------------------------------------------------------------------------------------------------
+def test_chain_column_groups_cover_whole_lines():
+    for n_cols, esz, t in [(20000, 4, 4), (20000, 4, 1), (20000, 8, 4), (1330, 4, 4), (33, 4, 4), (31, 4, 8), (5, 8, 3)]:
+        g = icd.chain_column_groups(n_cols, esz, t)
+        assert g[0][0] == 0 and g[-1][1] == n_cols and len(g) <= t
+        for (a0, a1), (b0, b1) in zip(g, g[1:]):
+            assert a1 == b0 and a0 < a1
+        for c0, _ in g:
+            assert c0 % (128 // esz) == 0  # groups start on 128-byte lines (the tile unit of k_colchain)
+    assert icd.chain_column_groups(20000, 4, 4) == [(0, 4992), (4992, 9984), (9984, 14976), (14976, 20000)]
+
+
+class _FakeShard:
+    """Stands in for _engine.DeviceMatrix on the CPU: the rows of one rank as a torch tensor."""
+
+    def __init__(self, x):
+        self.x = torch.from_numpy(np.ascontiguousarray(x))
+        self.shape = tuple(x.shape)
+        self.dtype = self.x.dtype
+        self.device = torch.device("cpu")
+        self.format = 0  # _lib.ICV_DENSE
+
+
+def _cpu_column_chain(dm, acc, rows, count, row0=0, row1=None, cols=None):
+    """icv_colchain restated: one sequential chain per column in the matrix dtype, rows ascending."""
+    c0, c1 = (0, dm.shape[1]) if cols is None else cols
+    a = acc.numpy()
+    x = dm.x.numpy()
+    for r in (range(dm.shape[0]) if rows is None else rows):
+        a[c0:c1] = a[c0:c1] + x[r, c0:c1]
+    return acc
+
+
+def _chain_worker(rank, world, port, members, t_groups, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from infercnvpy_amd import _engine
+
+        _engine.column_chain = _cpu_column_chain
+        _engine.chain_mean = lambda acc, count, is_csr: acc / float(count)  # (float32 tensor / python float: float32)
+        group = None if members is None else dist.new_group(ranks=members)
+        order = list(range(world)) if members is None else sorted(members)  # (new_group sorts its ranks)
+        n_obs, n_genes = 1000, 333
+        X = cases.synthetic_expr(n_obs, n_genes, seed=5)
+        labels = np.array(["a", "b", "c"])[np.random.RandomState(2).randint(0, 3, n_obs)]
+        bounds = icd.shard_bounds(n_obs, len(order), 100)
+        if rank in order:
+            r0, r1 = bounds[order.index(rank)]
+            dm = _FakeShard(X[r0:r1])
+            ll = labels[r0:r1]
+            means = icd.reference_means_chained(dm, [n_obs], group=group, n_col_groups=t_groups).numpy()
+            np.testing.assert_array_equal(means[0], X.mean(axis=0))  # numpy's own order: the whole matrix at once
+            cats = ["a", "b"]
+            means = icd.reference_means_chained(dm, [int((labels == c).sum()) for c in cats],
+                                                [np.nonzero(ll == c)[0] for c in cats], group=group,
+                                                n_col_groups=t_groups).numpy()
+            for gi, c in enumerate(cats):
+                np.testing.assert_array_equal(means[gi], X[labels == c].mean(axis=0))
+        q.put((rank, "ok", None))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,members,t_groups", [(2, None, 1), (3, None, 4), (3, [2, 0], 3)])
+def test_chained_means_over_ranks_are_numpys_bits(world, members, t_groups):
+    """Every rank ends up with np.mean(X, axis=0) of the WHOLE matrix bit for bit: the float32 chains continue from
+    rank to rank, pipelined over column groups; with a subgroup the peers are the group's members in group order
+    (the default group's ranks were used)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, world, port, members, t_groups, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"
