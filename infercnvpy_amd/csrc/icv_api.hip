@@ -21,6 +21,7 @@
 #include "icv_kernel_x16.hpp"
 #include "icv_kernel_se.hpp"
 #include "icv_kernel_chain.hpp"
+#include "icv_kernel_chainq.hpp"
 #include "icv_kernel_pack.hpp"
 #include "icv_kernel_util.hpp"
 #include "icv_corr.hpp"
@@ -50,8 +51,9 @@ int fail(int code, const std::string& msg) {
 // getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
-    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring;
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues;
     int wgs_per_cu;        // 0 = not set
+    int chain_far;         // ICV_CHAIN_FAR: entries a buffer offset may span in k_colchain_csrq (tests: a small value)
     double ward_compact_x; // 0 = not set
     void load() {
         force_generic = std::getenv("ICV_FORCE_GENERIC") != nullptr;
@@ -61,8 +63,11 @@ struct Knobs {
         ward_in_place = std::getenv("ICV_WARD_IN_PLACE") != nullptr;
         no_mask_ring = std::getenv("ICV_NO_MASK_RING") != nullptr;
         no_fill_ring = std::getenv("ICV_NO_FILL_RING") != nullptr;
+        no_chain_queues = std::getenv("ICV_NO_CHAIN_QUEUES") != nullptr;
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
+        e = std::getenv("ICV_CHAIN_FAR");
+        chain_far = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_WARD_COMPACT_X");
         ward_compact_x = e ? std::atof(e) : 0.0;
     }
@@ -880,6 +885,33 @@ int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double
     if (L.grid > 65535) return fail(ICV_ERR_UNSUPPORTED, "icv_colchain: more than 65535 column tiles");
     AsyncBuf lt_b, bounds_b;
     HIP_TRY(lt_b.alloc((size_t)L.n_lines * sizeof(uint16_t), st));
+    const int esz_shift_q = sizeof(T) == 4 ? 2 : 3;
+    const size_t tab_lds = (size_t)icv::kQTabRows * (size_t)((L.grid + 2) | 1) * sizeof(uint16_t);
+    if (m->n_cols <= 65535 && tab_lds <= 160 * 1024 && !knobs().no_chain_queues) {
+        // per-column queues (csrc/icv_kernel_chainq.hpp): 16-bit tile-major bounds table + the streamed chain
+        hipLaunchKernelGGL(k_chain_line_tiles, dim3((L.grid + 255) / 256), dim3(256), 0, st, L.n_lines, L.grid,
+                           lt_b.as<uint16_t>());
+        const int64_t n_tb = (n_sel + icv::kQTabRows - 1) / icv::kQTabRows;
+        HIP_TRY(bounds_b.alloc((size_t)n_tb * (L.grid + 1) * icv::kQTabRows * sizeof(uint16_t), st));
+        typedef void (*tb_t)(const int64_t*, const int32_t*, const int32_t*, int64_t, const uint16_t*, int, int, uint32_t*);
+        const tb_t tb = rows ? (tb_t)icv::k_csr_tile_bounds16<true> : (tb_t)icv::k_csr_tile_bounds16<false>;
+        if (tab_lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tb), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tab_lds));
+        hipLaunchKernelGGL(tb, dim3((unsigned)n_tb), dim3(256), tab_lds, st, m->indptr, m->indices, rows, n_sel,
+                           lt_b.as<uint16_t>(), esz_shift_q, L.grid, bounds_b.as<uint32_t>());
+        typedef void (*kq_t)(const T*, const int64_t*, const int32_t*, int64_t, const int32_t*, int64_t, int, int, int,
+                             const uint16_t*, T, int, T*);
+        const kq_t kq = rows ? (kq_t)icv::k_colchain_csrq<T, true> : (kq_t)icv::k_colchain_csrq<T, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    icv::kChLdsFull));
+        hipLaunchKernelGGL(kq, dim3(L.grid), dim3(icv::kChThreads), L.lds_bytes, st, (const T*)m->values, m->indptr,
+                           m->indices, m->n_rows, rows, n_sel, m->n_cols, L.n_lines, L.lds_bytes,
+                           (const uint16_t*)bounds_b.as<uint16_t>(), (T)scale,
+                           knobs().chain_far > 0 ? knobs().chain_far : icv::kQFar, acc);
+        HIP_TRY(hipGetLastError());
+        return ICV_OK;
+    }
     const int64_t n_blk = (n_sel + icv::kCcBlock - 1) / icv::kCcBlock;
     HIP_TRY(bounds_b.alloc((size_t)n_blk * (L.grid + 1) * icv::kCcBlock * sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_chain_line_tiles, dim3((L.grid + 255) / 256), dim3(256), 0, st, L.n_lines, L.grid,

@@ -1,0 +1,400 @@
+// Reference-order column sums of a CSR matrix whose work FOLLOWS THE STORED ENTRIES (reference tl/_infercnv.py:385, :400:
+// scipy's `(X * (1/n)).sum(axis=0)` = per column one sequential chain acc = fl(acc + fl(x * fl(1/n))) over the rows).
+//
+// k_colchain_csr (icv_kernel_chain.hpp, round 4) rebuilt 60-row slices of a column tile DENSELY in LDS and let the chain
+// wavefront add every LDS row: 37 LDS rows per 60 input rows at 7 % density whatever the merging, and 704 uncoalesced
+// line accesses of the CU's texture path per round (lane = row: every 16-byte load of a wavefront touched 64 lines).
+// Here a round of 64 input rows becomes PER-COLUMN QUEUES:
+//
+//   * rank of an entry (row r, column c) inside its round = number of earlier rows of the round that store column c.
+//     The producer ORs bit r into a 64-bit row mask per column (LDS `ds_or_b64`: commutative, so the landing order of the
+//     atomics does not matter), then rank = popcount(mask[c] & (bit(r) - 1)).  Deterministic by construction.
+//   * LDS row j of the round holds the j-th stored entry of every column (zero where a column has fewer): adding a zero
+//     is exact, so the chain's sums are the reference's -- and the round needs max_c count(c) LDS rows, ~11 instead of 64
+//     at 7 % density (a column stored in every row degrades gracefully to the dense chain: 64 rows).
+//   * the LDS rows of all rounds form ONE continuous stream in a ring (160 KB: ~380 rows of 384 B): producers allocate
+//     their rows in round order (a two-word hand-over), fill them, publish in round order; the chain wavefront adds
+//     whatever is published in chunks of ten rows, never looking at round boundaries.  ~30 rounds are in flight.
+//   * loads: lane = (row, piece): four lanes share a row's run of the tile's entries (16 bytes of indices / values each),
+//     so a load instruction touches ~16-20 lines instead of 64; the rows' bounds come from a TILE-MAJOR table of 16-bit
+//     offsets (blocks of 32 rows: the 64 rows of a round read two 64-byte runs per tile boundary) written by
+//     k_csr_tile_bounds16 through an LDS transpose (the table is half the size of round 4's and its lines are written whole).
+//
+// Needs n_cols <= 65535 (16-bit offsets inside a row); wider matrices keep the round-4 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "icv_kernel_chain.hpp"
+
+namespace icv {
+
+constexpr int kQRows = 64;      // input rows per round (one bit each in a column's row mask)
+constexpr int kQTabRows = 32;   // rows per block of the bounds table
+constexpr int kQCtl = 256;      // control words at the end of the LDS
+constexpr int kQCmBytes = 1024; // row masks of one producer wavefront: 128 columns x 8 bytes
+constexpr int kQFar = 1 << 28;  // entries a buffer offset can span (far_limit); rows further apart take the guarded loads
+
+__host__ __device__ inline int64_t q_tab_index(int64_t i, int t, int n_tiles) {
+    return ((i / kQTabRows) * (int64_t)(n_tiles + 1) + t) * kQTabRows + (i % kQTabRows);
+}
+
+// tab[q_tab_index(i, t)] = number of entries of selected row i in the tiles before t (t = 0 .. n_tiles), 16 bits each.
+// One workgroup (four wavefronts) per block of 32 rows; a wavefront takes one row at a time (lane = entry, 256 entries in
+// flight); the block's table is collected in LDS (row-major, odd stride) and written out tile-major in whole lines.
+template <bool LIST>
+__global__ void __launch_bounds__(256) k_csr_tile_bounds16(const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const int32_t* __restrict__ sel, int64_t n_sel,
+                                                           const uint16_t* __restrict__ line_tile, int esz_shift,
+                                                           int n_tiles, uint32_t* __restrict__ tab32) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
+    uint16_t* lt = reinterpret_cast<uint16_t*>(q_smem);
+    const int stride = (n_tiles + 2) | 1;  // 16-bit elements per row: odd, so the transposed reads spread over the banks
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < kQTabRows; r += 4) {
+        const int64_t i = (int64_t)blockIdx.x * kQTabRows + r;
+        uint16_t* row_t = lt + r * stride;
+        if (i >= n_sel) {  // (uniform) rows past the end: zeros, never read
+            for (int t = lane; t <= n_tiles; t += 64) row_t[t] = 0;
+            continue;
+        }
+        const int64_t row = LIST ? sel[i] : i;
+        const int64_t e0 = indptr[row];
+        const int64_t len = indptr[row + 1] - e0;
+        int carry = -1;  // tile of the entry before this chunk
+        for (int64_t base = 0; base <= len; base += 256) {
+            int col[4], T[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                col[u] = pos < len ? indices[e0 + pos] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                // pos == len: the terminator closes every remaining tile at `len`
+                T[u] = pos < len ? (int)line_tile[((unsigned)col[u] << esz_shift) >> 7] : n_tiles;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pos = base + u * 64 + lane;
+                int P = __shfl_up(T[u], 1);
+                if (lane == 0) P = carry;
+                carry = __shfl(T[u], 63);
+                if (pos <= len)
+                    for (int t = P + 1; t <= T[u]; ++t) row_t[t] = (uint16_t)pos;
+            }
+        }
+    }
+    __syncthreads();
+    // tile-major: word w of the block = rows 2q, 2q + 1 of tile boundary t (w = 16 t + q)
+    const int n_words = (n_tiles + 1) * (kQTabRows / 2);
+    uint32_t* out = tab32 + (int64_t)blockIdx.x * n_words;
+    for (int w = threadIdx.x; w < n_words; w += 256) {
+        const int t = w >> 4, q = w & 15;
+        out[w] = (uint32_t)lt[(2 * q) * stride + t] | ((uint32_t)lt[(2 * q + 1) * stride + t] << 16);
+    }
+}
+
+__device__ __forceinline__ unsigned q_load(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void q_store(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The chain wavefront: adds the published LDS rows of the ring in order, ten at a time (the hand-scheduled chunk of
+// k_colchain), whatever round they belong to.  ctl: [3] rounds published, [4] rows published, [5] rows consumed.
+template <typename T, int NL>
+__device__ __forceinline__ void chain_stream(const unsigned char* smem, int n_ring, unsigned n_rounds, int lane,
+                                             typename ChainLane<T>::type& a, unsigned* ctl) {
+    typedef typename ChainLane<T>::type lane_t;
+    constexpr int RB = 128 * NL;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)lane * 8u;
+    unsigned done = 0;  // rows consumed (wraps with the counters)
+    int pos = 0;        // ring position of row `done`: a multiple of ten
+    for (;;) {
+        const unsigned rr = q_load(ctl + 3);
+        const unsigned rrow = q_load(ctl + 4);
+        int avail = (int)(rrow - done);
+        if (avail >= 10) {
+            int n_chunks = avail / 10;
+            const int to_end = (n_ring - pos) / 10;
+            if (n_chunks > to_end) n_chunks = to_end;
+            asm volatile("" ::: "memory");  // rows written by other wavefronts: read them now
+            const unsigned p0 = lds0 + (unsigned)pos * (unsigned)RB;
+            lane_t va[10], vb[10];
+#define ICV_Q_BODY(RBS, OP)                                                \
+    ICV_CH_LOAD(RBS, va, p0);                                              \
+    int c = 0;                                                             \
+    for (; c + 2 < n_chunks; c += 2) {                                     \
+        const unsigned p1 = p0 + (unsigned)((c + 1) * 10 * RB);            \
+        ICV_CH_STEP(RBS, OP, a, vb, va, p1);                               \
+        const unsigned p2 = p0 + (unsigned)((c + 2) * 10 * RB);            \
+        ICV_CH_STEP(RBS, OP, a, va, vb, p2);                               \
+    }                                                                      \
+    if (c + 1 < n_chunks) {                                                \
+        const unsigned p1 = p0 + (unsigned)((c + 1) * 10 * RB);            \
+        ICV_CH_STEP(RBS, OP, a, vb, va, p1);                               \
+        ICV_CH_ADDS(OP, a, vb);                                            \
+    } else {                                                               \
+        ICV_CH_ADDS(OP, a, va);                                            \
+    }
+            if constexpr (sizeof(T) == 4) {
+                if constexpr (NL == 1) { ICV_Q_BODY("128", "v_pk_add_f32") }
+                else if constexpr (NL == 2) { ICV_Q_BODY("256", "v_pk_add_f32") }
+                else if constexpr (NL == 3) { ICV_Q_BODY("384", "v_pk_add_f32") }
+                else { ICV_Q_BODY("512", "v_pk_add_f32") }
+            } else {
+                if constexpr (NL == 1) { ICV_Q_BODY("128", "v_add_f64") }
+                else if constexpr (NL == 2) { ICV_Q_BODY("256", "v_add_f64") }
+                else if constexpr (NL == 3) { ICV_Q_BODY("384", "v_add_f64") }
+                else { ICV_Q_BODY("512", "v_add_f64") }
+            }
+#undef ICV_Q_BODY
+            done += 10u * (unsigned)n_chunks;
+            pos += 10 * n_chunks;
+            if (pos >= n_ring) pos = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads have returned: the rows may be reused)
+            if (lane == 0) q_store(ctl + 5, done);
+        } else if (rr == n_rounds) {
+            // every round is published: what q_load(ctl + 4) returns now is final
+            const unsigned last = q_load(ctl + 4);
+            avail = (int)(last - done);
+            if (avail >= 10) continue;
+            asm volatile("" ::: "memory");
+            const lane_t* rows = reinterpret_cast<const lane_t*>(smem + (size_t)pos * RB) + lane;
+            for (int i = 0; i < avail; ++i) chain_add(a, rows[i * (RB / 8)]);
+            break;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// acc[c] += fl(x * scale) over the stored entries of rows sel[0..n_sel) (nullptr: rows 0..n_sel), rows ascending.
+// grid = the column tiles of ChainLaunch (= n_tiles of the table), 1024 threads: 15 producer wavefronts + the chain.
+template <typename T, bool LIST>
+__global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restrict__ vals,
+                                                              const int64_t* __restrict__ indptr,
+                                                              const int32_t* __restrict__ indices, int64_t n_rows_all,
+                                                              const int32_t* __restrict__ sel, int64_t n_sel, int n_cols,
+                                                              int n_lines, int lds_bytes,
+                                                              const uint16_t* __restrict__ tab, T scale,
+                                                              int far_limit, T* __restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename ChainLane<T>::type lane_t;
+    constexpr int CPL = 8 / (int)sizeof(T);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    // XCD x takes a contiguous eighth of the tiles (as k_colchain_csr): the runs its workgroups gather from a row's
+    // entry list share their cache lines in ONE L2
+    const int n_tiles = gridDim.x;
+    const int xcd = blockIdx.x & 7, q_in_xcd = blockIdx.x >> 3;
+    const int tile = xcd * (n_tiles >> 3) + (xcd < (n_tiles & 7) ? xcd : (n_tiles & 7)) + q_in_xcd;
+    const int line0 = (int)((int64_t)tile * n_lines / n_tiles);
+    const int nl = (int)((int64_t)(tile + 1) * n_lines / n_tiles) - line0;
+    const int c0 = line0 * (128 / (int)sizeof(T));
+    const int row_bytes = 128 * nl;
+    const int n_tcols = row_bytes / (int)sizeof(T);  // columns of the tile (<= 128)
+    // LDS: [ring: n_ring rows][row masks: 15 x 1 KB][control words]
+    const int n_ring = (lds_bytes - kChLoaders * kQCmBytes - kQCtl) / row_bytes / 10 * 10;
+    unsigned char* cm_base = smem + (lds_bytes - kQCtl - kChLoaders * kQCmBytes);
+    // ctl: [0] next round to allocate, [1] rows allocated (wrapping counter), [2] ring position of the next row,
+    //      [3] rounds published, [4] rows published, [5] rows consumed
+    unsigned* ctl = reinterpret_cast<unsigned*>(smem + lds_bytes - kQCtl);
+    const unsigned n_rounds = (unsigned)((n_sel + kQRows - 1) / kQRows);
+    for (int o = threadIdx.x * 16; o < kChLoaders * kQCmBytes + kQCtl; o += kChThreads * 16)
+        *reinterpret_cast<uint4*>(cm_base + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    if (wave < kChLoaders) {
+        unsigned long long* cm = reinterpret_cast<unsigned long long*>(cm_base + wave * kQCmBytes);
+        const int64_t e_end = indptr[n_rows_all];
+        const int piece = lane & 3, sub = lane >> 2;  // lane = (row 16 v + sub of the round, piece) in load vector v
+        // stage A (lane = row of the round): the three loaded words are kept RAW until the next turn (arithmetic on
+        // them here would make the compiler wait for the loads issued just before)
+        int64_t a_rp = 0;
+        unsigned a_lo = 0, a_hi = 0;
+        // stage B: lane = row: where the row's entries of the tile start, how many; lane = (row, piece): four entries
+        int64_t b_base = 0;
+        int b_cnt = 0;
+        bool b_more = false;  // (uniform) a row with more than 16 entries in the tile, or too far for a buffer offset
+        bool b_slow = false;  // this row's entries from `b_from` on go through the guarded loads
+        int b_from = 0;
+        int b_nv[4];
+        u32x4 b_idx[4];
+        T b_val[4][4];
+        const auto fetch_a = [&](unsigned k) {
+            const int64_t i = (int64_t)k * kQRows + lane;
+            a_rp = 0;
+            a_lo = a_hi = 0;
+            if (k < n_rounds && i < n_sel) {
+                const int64_t row = LIST ? sel[i] : i;
+                a_lo = tab[q_tab_index(i, tile, n_tiles)];
+                a_hi = tab[q_tab_index(i, tile + 1, n_tiles)];
+                a_rp = indptr[row];
+            }
+        };
+        const auto fetch_b = [&]() {
+            b_base = a_rp + (int64_t)a_lo;
+            b_cnt = (int)(a_hi - a_lo);
+            // range-checked 16-byte loads relative to the round's first entry (rows ascend, so it is the first row
+            // with entries): lanes without entries and reads past the end of the arrays return zeros
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(b_cnt > 0);
+            const int first = has ? (int)__builtin_ctzll(has) : 0;
+            int64_t e_first = ((int64_t)__builtin_amdgcn_readlane((int)(b_base >> 32), first) << 32) |
+                              (unsigned)__builtin_amdgcn_readlane((int)b_base, first);
+            if (!has) e_first = e_end;
+            const int64_t left = e_end - e_first;
+            const unsigned rec = (unsigned)(left < (int64_t)far_limit + 16 ? left : (int64_t)far_limit + 16);
+            const __amdgpu_buffer_rsrc_t i_rs = make_rsrc(indices + e_first, rec * 4u);
+            const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vals + e_first, rec * (unsigned)sizeof(T));
+            const int64_t rel64 = b_base - e_first;
+            const bool far = b_cnt > 0 && rel64 >= (int64_t)far_limit;
+            b_slow = far || b_cnt > 16;
+            b_from = far ? 0 : 16;
+            b_more = __builtin_amdgcn_ballot_w64(b_slow) != 0ull;
+            const int rel = far || b_cnt <= 0 ? -1 : (int)rel64;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int src = 16 * v + sub;
+                const int cnt_v = __shfl(b_cnt, src);
+                const int rel_v = __shfl(rel, src);
+                int nv = cnt_v - 4 * piece;
+                nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+                if (rel_v < 0) nv = 0;
+                b_nv[v] = nv;
+                const unsigned off = nv > 0 ? (unsigned)(rel_v + 4 * piece) : 0x3fffffffu;  // (no entries: out of range)
+                b_idx[v] = __builtin_amdgcn_raw_buffer_load_b128(i_rs, off * 4u, 0, 0);
+                if constexpr (sizeof(T) == 4) {
+                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(v_rs, off * 4u, 0, 0);
+                    b_val[v][0] = __uint_as_float(w.x), b_val[v][1] = __uint_as_float(w.y);
+                    b_val[v][2] = __uint_as_float(w.z), b_val[v][3] = __uint_as_float(w.w);
+                } else {
+                    const unsigned offb = nv > 0 ? off * 8u : 0xfffffff0u;
+                    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(v_rs, offb, 0, 0);
+                    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(v_rs, offb, 16, 0);
+                    b_val[v][0] = __hiloint2double((int)w0.y, (int)w0.x);
+                    b_val[v][1] = __hiloint2double((int)w0.w, (int)w0.z);
+                    b_val[v][2] = __hiloint2double((int)w1.y, (int)w1.x);
+                    b_val[v][3] = __hiloint2double((int)w1.w, (int)w1.z);
+                }
+            }
+        };
+        // round k: row masks -> LDS rows needed -> allocation in round order -> zero + scatter -> publication in round order
+        const auto write_round = [&](unsigned k) {
+            // 1. row masks of the tile's columns
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned long long bit = 1ull << (16 * v + sub);
+                const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < b_nv[v])
+                        __hip_atomic_fetch_or(cm + (idx[j] - c0), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            if (b_more && b_slow)  // long or far rows: lane = row, guarded loads
+                for (int j = b_from; j < b_cnt; ++j)
+                    __hip_atomic_fetch_or(cm + (indices[b_base + j] - c0), 1ull << lane, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // 2. LDS rows of the round = the longest column queue
+            int n = 0;
+            for (int c = lane; c < n_tcols; c += 64) {
+                const int cn = __popcll(cm[c]);
+                n = cn > n ? cn : n;
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const int other = __shfl_xor(n, o);
+                n = other > n ? other : n;
+            }
+            n = __builtin_amdgcn_readfirstlane(n);
+            // 3. rows [start, start + n) of the stream, in round order
+            while (q_load(ctl + 0) != k) __builtin_amdgcn_s_sleep(1);
+            const unsigned start = __builtin_amdgcn_readfirstlane(ctl[1]);
+            const int pos0 = __builtin_amdgcn_readfirstlane((int)ctl[2]);
+            if (lane == 0) {
+                int p = pos0 + n;
+                if (p >= n_ring) p -= n_ring;
+                ctl[1] = start + (unsigned)n;
+                ctl[2] = (unsigned)p;
+                q_store(ctl + 0, k + 1u);
+            }
+            // the chain must be done with what these ring rows held a lap ago
+            const unsigned need = start + (unsigned)n - (unsigned)n_ring;
+            while ((int)(q_load(ctl + 5) - need) < 0) __builtin_amdgcn_s_sleep(1);
+            // 4. zeros (two contiguous runs when the rows wrap around the ring)
+            const int n1 = n < n_ring - pos0 ? n : n_ring - pos0;
+            unsigned char* z1 = smem + (size_t)pos0 * row_bytes;
+            for (int o = lane * 16; o < n1 * row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(z1 + o) = make_uint4(0, 0, 0, 0);
+            for (int o = lane * 16; o < (n - n1) * row_bytes; o += 64 * 16)
+                *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+            // 5. every entry into LDS row rank(entry) of the round (LDS executes a wavefront's operations in order: the
+            // zeros above are in place)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned long long below = (1ull << (16 * v + sub)) - 1ull;
+                const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < b_nv[v]) {
+                        const int c = idx[j] - c0;
+                        int p = pos0 + __popcll(cm[c] & below);
+                        if (p >= n_ring) p -= n_ring;
+                        *reinterpret_cast<T*>(smem + (size_t)p * row_bytes + (size_t)c * sizeof(T)) = b_val[v][j] * scale;
+                    }
+            }
+            if (b_more && b_slow) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                for (int j = b_from; j < b_cnt; ++j) {
+                    const int c = indices[b_base + j] - c0;
+                    int p = pos0 + __popcll(cm[c] & below);
+                    if (p >= n_ring) p -= n_ring;
+                    *reinterpret_cast<T*>(smem + (size_t)p * row_bytes + (size_t)c * sizeof(T)) = vals[b_base + j] * scale;
+                }
+            }
+            // 6. masks back to zero for this wavefront's next round
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(cm) + lane * 16) = make_uint4(0, 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows are complete)
+            // 7. publish, in round order
+            while (q_load(ctl + 3) != k) __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) {
+                ctl[4] = start + (unsigned)n;
+                q_store(ctl + 3, k + 1u);
+            }
+        };
+        unsigned mine = (unsigned)wave;  // this wavefront's next round
+        fetch_a(mine);
+        fetch_b();
+        fetch_a(mine + kChLoaders);
+        for (; mine < n_rounds; mine += kChLoaders) {
+            write_round(mine);
+            fetch_b();
+            fetch_a(mine + 2 * kChLoaders);
+        }
+    } else {
+        const int col = lane * 8 < row_bytes ? c0 + lane * CPL : n_cols;
+        lane_t a;
+        if constexpr (sizeof(T) == 4) {
+            a.x = col < n_cols ? acc[col] : 0.f;
+            a.y = col + 1 < n_cols ? acc[col + 1] : 0.f;
+        } else {
+            a = col < n_cols ? acc[col] : 0.0;
+        }
+        const int rl = lane * 8 < row_bytes ? lane : 0;  // idle lanes read lane 0's bytes (never stored)
+        if (nl == 1) chain_stream<T, 1>(smem, n_ring, n_rounds, rl, a, ctl);
+        else if (nl == 2) chain_stream<T, 2>(smem, n_ring, n_rounds, rl, a, ctl);
+        else if (nl == 3) chain_stream<T, 3>(smem, n_ring, n_rounds, rl, a, ctl);
+        else chain_stream<T, 4>(smem, n_ring, n_rounds, rl, a, ctl);
+        if constexpr (sizeof(T) == 4) {
+            if (col < n_cols) acc[col] = a.x;
+            if (col + 1 < n_cols) acc[col + 1] = a.y;
+        } else {
+            if (col < n_cols) acc[col] = a;
+        }
+    }
+}
+
+}  // namespace icv

@@ -91,6 +91,42 @@ def test_csr_means_are_scipy_bit_for_bit(shape, density, dtype):
         np.testing.assert_array_equal(got, _oracle_means(X, labels, ["t", "n"]))
 
 
+def test_csr_chain_routes_agree(monkeypatch):
+    """The per-column-queue kernel (k_colchain_csrq), its guarded-load path for rows too far apart for a buffer offset
+    (forced with a small ICV_CHAIN_FAR), the round-4 kernel (ICV_NO_CHAIN_QUEUES, also what matrices wider than 65 535
+    columns take) -- all scipy's bits."""
+    from infercnvpy_amd import _lib
+
+    lib = _lib.load()
+    X = sp.csr_matrix(_expr(1500, 3001, seed=12, density=0.1))
+    labels = np.array(["n", "t", "u"])[np.random.RandomState(1).randint(0, 3, 1500)]
+    exp_all, exp_cat = _oracle_means(X), _oracle_means(X, labels, ["t", "n"])
+    for env in ({}, {"ICV_CHAIN_FAR": "700"}, {"ICV_CHAIN_FAR": "1"}, {"ICV_NO_CHAIN_QUEUES": "1"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        lib.icv_developer_knobs_reload()
+        np.testing.assert_array_equal(_gpu_means(X), exp_all)
+        np.testing.assert_array_equal(_gpu_means(X, labels, ["t", "n"], pieces=3), exp_cat)
+        for k in env:
+            monkeypatch.delenv(k)
+    lib.icv_developer_knobs_reload()
+    wide = sp.csr_matrix(_expr(300, 70001, seed=13, density=0.01))  # > 65 535 columns: 16-bit row offsets do not apply
+    np.testing.assert_array_equal(_gpu_means(wide), _oracle_means(wide))
+
+
+@pytest.mark.parametrize("n,g,density", [(64, 96, 0.9), (63, 96, 0.9), (65, 40, 0.5), (129, 31, 1.0), (640, 2000, 0.25),
+                                         (10_000, 300, 0.07), (3000, 96, 0.001)])
+def test_csr_queue_kernel_edges(n, g, density):
+    """Round boundaries (64 rows), full columns (64 LDS rows a round), tiles narrower than a cache line, rows with more
+    than 16 entries in a tile, rounds without any entry."""
+    for dtype in (np.float32, np.float64):
+        X = sp.csr_matrix(_expr(n, g, seed=n + g, dtype=dtype, density=density))
+        np.testing.assert_array_equal(_gpu_means(X), _oracle_means(X))
+    labels = np.array(["n", "t"])[np.random.RandomState(2).randint(0, 2, n)]
+    X = sp.csr_matrix(_expr(n, g, seed=n + g, density=density))
+    np.testing.assert_array_equal(_gpu_means(X, labels, ["t", "n"], pieces=2), _oracle_means(X, labels, ["t", "n"]))
+
+
 def test_csr_integer_counts_and_long_rows():
     rs = np.random.RandomState(3)
     Xi = rs.poisson(0.3, (900, 3000)).astype(np.int64)
