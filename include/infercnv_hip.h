@@ -146,7 +146,8 @@ int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, 
  *   - np.mean(X, axis=0) of a C-contiguous matrix (reference :385, :400) is, per column, the sequential chain
  *     acc = fl(acc + x[r][g]) over the rows in order, in the matrix dtype (float32 stays float32), then acc / n;
  *   - scipy's CSR mean is the same chain over fl(x * fl(1/n)) (no division afterwards);
- *   - scipy's CSC mean is np.add.reduceat per column: first stored entry + numpy's pairwise sum of the others.
+ *   - scipy's CSC mean is np.add.reduceat per column: first stored entry + numpy's pairwise sum of the others;
+ *   - np.mean(X, axis=0) of a dense matrix stored column-major: pairwise per column (icv_colsum_pairwise below).
  * icv_colchain continues the chains: `acc` (device, n_cols values of the MATRIX dtype; zero before the first call) is
  * read, the rows `rows[0..n_sel)` of `m` (device int32, ascending; NULL = all rows of m) are added in order, and the
  * new accumulators are written back -- row pieces, slabs and shards are chained by calling in row order with the same
@@ -158,6 +159,13 @@ int icv_colsum(const icv_matrix *m, const int32_t *row_group, int32_t n_groups, 
  * icv_colmean_csc: means of a CSC matrix (colptr n_cols + 1 int64, row_idx int32, values), entries of rows with
  * row_group[row] == group only (row_group NULL: all), scale = 1 / n as above; `mean` n_cols values of the dtype. */
 int icv_colchain(const icv_matrix *m, const int32_t *rows, int64_t n_sel, double scale, void *acc, void *stream);
+/* The all-cell sums of a dense matrix stored COLUMN-major (numpy puts the axis with the smaller stride innermost:
+ * np.mean(X, axis=0) of an F-ordered array reduces every column with its contiguous inner loop = pairwise summation,
+ * over pieces of 8 192 elements, the iterator's buffer): `xt` holds n_cols columns of n_rows contiguous values each,
+ * `ld` elements apart (the caller uploads column blocks as they lie in host memory); sums[c] = that reduction, in the
+ * dtype (icv_colchain_mean divides). */
+int icv_colsum_pairwise(const void *xt, int32_t dtype, int64_t n_rows, int32_t n_cols, int64_t ld, void *sums,
+                        void *stream);
 int icv_colchain_mean(const void *acc, int32_t dtype, int32_t n_cols, int64_t count, void *mean, void *stream);
 int icv_colmean_csc(const void *values, int32_t dtype, const int64_t *colptr, const int32_t *row_idx, int32_t n_cols,
                     const int32_t *row_group, int32_t group, double scale, void *mean, void *stream);

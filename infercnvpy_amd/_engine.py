@@ -255,6 +255,30 @@ def csc_column_means(X, row_group=None, n_groups=1, counts=None, np_dtype=None, 
     return out
 
 
+def fortran_column_means(X, np_dtype=None, max_bytes=1 << 30):
+    """All-cell column means of a dense HOST matrix stored column-major (``X.strides[0] < X.strides[1]``: an
+    F-ordered array, the transposed view of a genes x cells matrix) in numpy's own order: numpy reduces such a matrix
+    column by column with its contiguous inner loop -- pairwise summation over pieces of 8 192 elements -- where a
+    C-ordered matrix gets one sequential chain per column (reference tl/_infercnv.py:385).  The columns travel to the GPU
+    in blocks as they lie in host memory (``icv_colsum_pairwise``); host array of ``np_dtype``."""
+    torch = _torch()
+    lib = _lib.load()
+    n, g = X.shape
+    np_dtype = np.dtype(np_dtype or (np.float32 if X.dtype == np.float32 else np.float64))
+    tdt = torch.float32 if np_dtype == np.float32 else torch.float64
+    code = _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64
+    XT = X.T
+    out = np.empty(g, dtype=np_dtype)
+    per = int(max(1, max_bytes // max(1, n * np_dtype.itemsize)))
+    for c0 in range(0, g, per):
+        c1 = min(g, c0 + per)
+        blk = torch.from_numpy(np.ascontiguousarray(XT[c0:c1].astype(np_dtype, copy=False))).cuda()
+        sums = torch.empty(c1 - c0, dtype=tdt, device="cuda")
+        _lib.check(lib.icv_colsum_pairwise(_ptr(blk), code, n, c1 - c0, n, _ptr(sums), _stream_ptr(torch)))
+        out[c0:c1] = chain_mean(sums, n, False).cpu().numpy()
+    return out
+
+
 def alloc_out(rows, n_windows):
     """Device float32 ``rows x n_windows`` result buffer whose rows start on 16-byte boundaries (row stride padded
     to a multiple of 4): the smoothing kernel then writes x_res with 16-byte stores."""

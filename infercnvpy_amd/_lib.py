@@ -27,7 +27,7 @@ ICV_FLAG_NO_APPLY = 4
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
     "icv_plan_last_kernel", "icv_plan_se_tables",
-    "icv_colsum", "icv_colchain", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
+    "icv_colsum", "icv_colchain", "icv_colsum_pairwise", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_pack_geometry", "icv_threshold_pack", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
@@ -98,6 +98,7 @@ def load():
     lib.icv_plan_se_tables.argtypes = [vp, P(i32), vp, vp, vp, vp, vp]
     lib.icv_colsum.argtypes = [P(Matrix), vp, i32, vp, vp]
     lib.icv_colchain.argtypes = [P(Matrix), vp, i64, dbl, vp, vp]
+    lib.icv_colsum_pairwise.argtypes = [vp, i32, i64, i32, i64, vp, vp]
     lib.icv_colchain_mean.argtypes = [vp, i32, i32, i64, vp, vp]
     lib.icv_colmean_csc.argtypes = [vp, i32, vp, vp, i32, vp, i32, dbl, vp, vp]
     lib.icv_infercnv_smooth.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, vp, vp, vp]

@@ -886,27 +886,31 @@ int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double
     AsyncBuf lt_b, bounds_b;
     HIP_TRY(lt_b.alloc((size_t)L.n_lines * sizeof(uint16_t), st));
     const int esz_shift_q = sizeof(T) == 4 ? 2 : 3;
-    const size_t tab_lds = (size_t)icv::kQTabRows * (size_t)((L.grid + 2) | 1) * sizeof(uint16_t);
+    const size_t tab_lds = (size_t)icv::kQTabRows * (size_t)((L.grid + 2) | 1) * sizeof(uint16_t) +
+                           (size_t)L.n_lines * sizeof(uint16_t);
     if (m->n_cols <= 65535 && tab_lds <= 160 * 1024 && !knobs().no_chain_queues) {
         // per-column queues (csrc/icv_kernel_chainq.hpp): 16-bit tile-major bounds table + the streamed chain
         hipLaunchKernelGGL(k_chain_line_tiles, dim3((L.grid + 255) / 256), dim3(256), 0, st, L.n_lines, L.grid,
                            lt_b.as<uint16_t>());
         const int64_t n_tb = (n_sel + icv::kQTabRows - 1) / icv::kQTabRows;
         HIP_TRY(bounds_b.alloc((size_t)n_tb * (L.grid + 1) * icv::kQTabRows * sizeof(uint16_t), st));
-        typedef void (*tb_t)(const int64_t*, const int32_t*, const int32_t*, int64_t, const uint16_t*, int, int, uint32_t*);
+        typedef void (*tb_t)(const int64_t*, const int32_t*, const int32_t*, int64_t, const uint16_t*, int, int, int,
+                             uint32_t*);
         const tb_t tb = rows ? (tb_t)icv::k_csr_tile_bounds16<true> : (tb_t)icv::k_csr_tile_bounds16<false>;
         if (tab_lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tb), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tab_lds));
         hipLaunchKernelGGL(tb, dim3((unsigned)n_tb), dim3(256), tab_lds, st, m->indptr, m->indices, rows, n_sel,
-                           lt_b.as<uint16_t>(), esz_shift_q, L.grid, bounds_b.as<uint32_t>());
+                           lt_b.as<uint16_t>(), L.n_lines, esz_shift_q, L.grid, bounds_b.as<uint32_t>());
         typedef void (*kq_t)(const T*, const int64_t*, const int32_t*, int64_t, const int32_t*, int64_t, int, int, int,
                              const uint16_t*, T, int, T*);
         const kq_t kq = rows ? (kq_t)icv::k_colchain_csrq<T, true> : (kq_t)icv::k_colchain_csrq<T, false>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     icv::kChLdsFull));
-        hipLaunchKernelGGL(kq, dim3(L.grid), dim3(icv::kChThreads), L.lds_bytes, st, (const T*)m->values, m->indptr,
-                           m->indices, m->n_rows, rows, n_sel, m->n_cols, L.n_lines, L.lds_bytes,
+        // (always the whole LDS of a CU: the ring of LDS rows is the work in flight; with more tiles than CUs the
+        // workgroups take the CUs in turns)
+        hipLaunchKernelGGL(kq, dim3(L.grid), dim3(icv::kChThreads), icv::kChLdsFull, st, (const T*)m->values, m->indptr,
+                           m->indices, m->n_rows, rows, n_sel, m->n_cols, L.n_lines, icv::kChLdsFull,
                            (const uint16_t*)bounds_b.as<uint16_t>(), (T)scale,
                            knobs().chain_far > 0 ? knobs().chain_far : icv::kQFar, acc);
         HIP_TRY(hipGetLastError());
@@ -1169,6 +1173,23 @@ int icv_colmean_csc(const void* values, int32_t dtype, const int64_t* colptr, co
     else if (dtype == ICV_F64)
         hipLaunchKernelGGL(icv::k_colpair_csc<double>, dim3((n_cols + 63) / 64), dim3(64), 0, st, (const double*)values,
                            colptr, row_idx, n_cols, row_group, group, scale, (double*)mean);
+    else
+        return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_colsum_pairwise(const void* xt, int32_t dtype, int64_t n_rows, int32_t n_cols, int64_t ld, void* sums,
+                        void* stream) {
+    if (!xt || !sums || n_rows < 0 || n_cols < 0 || ld < n_rows) return fail(ICV_ERR_INVALID, "bad colsum_pairwise arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_cols == 0) return ICV_OK;
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(icv::k_colpair_dense<float>, dim3((n_cols + 63) / 64), dim3(64), 0, st, (const float*)xt,
+                           n_rows, n_cols, ld, (float*)sums);
+    else if (dtype == ICV_F64)
+        hipLaunchKernelGGL(icv::k_colpair_dense<double>, dim3((n_cols + 63) / 64), dim3(64), 0, st, (const double*)xt,
+                           n_rows, n_cols, ld, (double*)sums);
     else
         return fail(ICV_ERR_INVALID, "dtype must be ICV_F32 or ICV_F64");
     HIP_TRY(hipGetLastError());

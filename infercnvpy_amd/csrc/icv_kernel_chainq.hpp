@@ -31,7 +31,9 @@ namespace icv {
 constexpr int kQRows = 64;      // input rows per round (one bit each in a column's row mask)
 constexpr int kQTabRows = 32;   // rows per block of the bounds table
 constexpr int kQCtl = 256;      // control words at the end of the LDS
-constexpr int kQCmBytes = 1024; // row masks of one producer wavefront: 128 columns x 8 bytes
+constexpr int kQCmBytes = 1040; // row masks of one producer wavefront: 128 columns x 8 bytes + a trash word (lanes
+                                // without an entry OR into it: no branches around the atomics)
+constexpr int kQTrash = 16;     // LDS bytes the lanes without an entry scatter into
 constexpr int kQFar = 1 << 28;  // entries a buffer offset can span (far_limit); rows further apart take the guarded loads
 
 __host__ __device__ inline int64_t q_tab_index(int64_t i, int t, int n_tiles) {
@@ -45,46 +47,85 @@ template <bool LIST>
 __global__ void __launch_bounds__(256) k_csr_tile_bounds16(const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices,
                                                            const int32_t* __restrict__ sel, int64_t n_sel,
-                                                           const uint16_t* __restrict__ line_tile, int esz_shift,
-                                                           int n_tiles, uint32_t* __restrict__ tab32) {
+                                                           const uint16_t* __restrict__ line_tile, int n_lines,
+                                                           int esz_shift, int n_tiles, uint32_t* __restrict__ tab32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char q_smem[];
     uint16_t* lt = reinterpret_cast<uint16_t*>(q_smem);
     const int stride = (n_tiles + 2) | 1;  // 16-bit elements per row: odd, so the transposed reads spread over the banks
+    uint16_t* l_tile = lt + kQTabRows * stride;  // line -> tile, copied to LDS (a dependent global load per chunk otherwise)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = wave; r < kQTabRows; r += 4) {
-        const int64_t i = (int64_t)blockIdx.x * kQTabRows + r;
-        uint16_t* row_t = lt + r * stride;
-        if (i >= n_sel) {  // (uniform) rows past the end: zeros, never read
+    for (int l = threadIdx.x; l < n_lines; l += 256) l_tile[l] = line_tile[l];
+    // this wavefront's rows: wave, wave + 4, ... (eight of them); lane j < 8 holds the entry range of row j
+    int64_t my_e0 = 0, my_len = -1;  // (-1: row past the end)
+    if (lane < kQTabRows / 4) {
+        const int64_t i = (int64_t)blockIdx.x * kQTabRows + wave + 4 * lane;
+        if (i < n_sel) {
+            const int64_t row = LIST ? sel[i] : i;
+            my_e0 = indptr[row];
+            my_len = indptr[row + 1] - my_e0;
+        }
+    }
+    __syncthreads();
+    const auto row_of = [&](int j, int64_t& e0, int64_t& len) {
+        e0 = ((int64_t)__builtin_amdgcn_readlane((int)(my_e0 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_e0, j);
+        len = ((int64_t)__builtin_amdgcn_readlane((int)(my_len >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_len, j);
+    };
+    // chunks of 256 entries (one row at a time, the terminator position `len` included); the column indices of the NEXT
+    // chunk -- of this row or of the wavefront's next row -- are in flight while the current chunk is processed
+    int col_next[4];
+    const auto load_chunk = [&](int64_t e0, int64_t len, int64_t base) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pos = base + u * 64 + lane;
+            col_next[u] = pos < len ? indices[e0 + pos] : 0;
+        }
+    };
+    int j = 0, jn = 0;
+    int64_t e0 = 0, len = -1, base = 0, e0n = 0, lenn = -1, basen = 0;
+    row_of(0, e0n, lenn);
+    if (lenn >= 0) load_chunk(e0n, lenn, 0);
+    int carry = -1;  // tile of the entry before this chunk
+    for (;;) {
+        j = jn, e0 = e0n, len = lenn, base = basen;
+        if (j >= kQTabRows / 4) break;
+        uint16_t* row_t = lt + (wave + 4 * j) * stride;
+        if (len < 0) {  // rows past the end: zeros, never read
             for (int t = lane; t <= n_tiles; t += 64) row_t[t] = 0;
+            jn = j + 1;
+            if (jn < kQTabRows / 4) row_of(jn, e0n, lenn);
+            basen = 0;
+            if (jn < kQTabRows / 4 && lenn >= 0) load_chunk(e0n, lenn, 0);
+            carry = -1;
             continue;
         }
-        const int64_t row = LIST ? sel[i] : i;
-        const int64_t e0 = indptr[row];
-        const int64_t len = indptr[row + 1] - e0;
-        int carry = -1;  // tile of the entry before this chunk
-        for (int64_t base = 0; base <= len; base += 256) {
-            int col[4], T[4];
+        int col[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t pos = base + u * 64 + lane;
-                col[u] = pos < len ? indices[e0 + pos] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t pos = base + u * 64 + lane;
-                // pos == len: the terminator closes every remaining tile at `len`
-                T[u] = pos < len ? (int)line_tile[((unsigned)col[u] << esz_shift) >> 7] : n_tiles;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t pos = base + u * 64 + lane;
-                int P = __shfl_up(T[u], 1);
-                if (lane == 0) P = carry;
-                carry = __shfl(T[u], 63);
-                if (pos <= len)
-                    for (int t = P + 1; t <= T[u]; ++t) row_t[t] = (uint16_t)pos;
-            }
+        for (int u = 0; u < 4; ++u) col[u] = col_next[u];
+        // the next chunk
+        basen = base + 256;
+        if (basen > len) {
+            jn = j + 1;
+            basen = 0;
+            if (jn < kQTabRows / 4) row_of(jn, e0n, lenn);
         }
+        if (jn < kQTabRows / 4 && lenn >= 0) load_chunk(e0n, lenn, basen);
+        int T[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pos = base + u * 64 + lane;
+            // pos == len: the terminator closes every remaining tile at `len`
+            T[u] = pos < len ? (int)l_tile[((unsigned)col[u] << esz_shift) >> 7] : n_tiles;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pos = base + u * 64 + lane;
+            int P = __shfl_up(T[u], 1);
+            if (lane == 0) P = carry;
+            carry = __shfl(T[u], 63);
+            if (pos <= len)
+                for (int t = P + 1; t <= T[u]; ++t) row_t[t] = (uint16_t)pos;
+        }
+        if (jn != j) carry = -1;
     }
     __syncthreads();
     // tile-major: word w of the block = rows 2q, 2q + 1 of tile boundary t (w = 16 t + q)
@@ -94,6 +135,18 @@ __global__ void __launch_bounds__(256) k_csr_tile_bounds16(const int64_t* __rest
         const int t = w >> 4, q = w & 15;
         out[w] = (uint32_t)lt[(2 * q) * stride + t] | ((uint32_t)lt[(2 * q + 1) * stride + t] << 16);
     }
+}
+
+// max over the 64 lanes of a non-negative int, DPP only (six dependent VALU steps instead of six LDS round trips)
+__device__ __forceinline__ int wave_max_nonneg_dpp(int v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;  // row_shr:1
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;  // row_shr:2
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;  // row_shr:4
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;  // row_shr:8
+    t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;  // row_bcast:15 -> rows 1, 3
+    t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;  // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ unsigned q_load(const unsigned* p) {
@@ -282,77 +335,85 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                 }
             }
         };
-        // round k: row masks -> LDS rows needed -> allocation in round order -> zero + scatter -> publication in round order
+        // round k: row masks -> LDS rows needed -> allocation in round order -> zero + scatter -> publication in round
+        // order.  The per-entry code has NO branches: a lane without an entry ORs into the trash word behind the masks
+        // and scatters into the trash bytes behind them (exec-mask juggling around 32 atomics / stores cost as much as
+        // the work itself in the first version).
+        const unsigned trash_off = (unsigned)(lds_bytes - kQCtl - kQTrash);  // byte offset in LDS of the trash bytes
         const auto write_round = [&](unsigned k) {
             // 1. row masks of the tile's columns
+            unsigned c8[4][4];  // 8 x (column inside the tile); 8 x 128 = the trash word
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const unsigned long long bit = 1ull << (16 * v + sub);
                 const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < b_nv[v])
-                        __hip_atomic_fetch_or(cm + (idx[j] - c0), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                for (int j = 0; j < 4; ++j) {
+                    c8[v][j] = j < b_nv[v] ? (unsigned)(idx[j] - c0) * 8u : 1024u;
+                    __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(cm) + c8[v][j]),
+                                          bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
-            if (b_more && b_slow)  // long or far rows: lane = row, guarded loads
-                for (int j = b_from; j < b_cnt; ++j)
-                    __hip_atomic_fetch_or(cm + (indices[b_base + j] - c0), 1ull << lane, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (b_more) {  // (uniform, rare) long or far rows: lane = row, guarded loads
+                if (b_slow)
+                    for (int j = b_from; j < b_cnt; ++j)
+                        __hip_atomic_fetch_or(cm + (indices[b_base + j] - c0), 1ull << lane, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // 2. LDS rows of the round = the longest column queue
-            int n = 0;
-            for (int c = lane; c < n_tcols; c += 64) {
-                const int cn = __popcll(cm[c]);
-                n = cn > n ? cn : n;
+            int n = __popcll(cm[lane]);
+            if (n_tcols > 64) {
+                const int n2 = __popcll(cm[64 + lane]);
+                n = n2 > n ? n2 : n;
             }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const int other = __shfl_xor(n, o);
-                n = other > n ? other : n;
-            }
-            n = __builtin_amdgcn_readfirstlane(n);
-            // 3. rows [start, start + n) of the stream, in round order
+            n = wave_max_nonneg_dpp(n);
+            // 3. rows of the stream, in round order.  A round never wraps around the ring: if its rows do not fit
+            // before the end, the rest of the ring becomes zero rows (adding zeros is exact) and the round starts at 0.
             while (q_load(ctl + 0) != k) __builtin_amdgcn_s_sleep(1);
             const unsigned start = __builtin_amdgcn_readfirstlane(ctl[1]);
             const int pos0 = __builtin_amdgcn_readfirstlane((int)ctl[2]);
+            const int pad = pos0 + n > n_ring ? n_ring - pos0 : 0;
+            const int posd = pad ? 0 : pos0;  // first LDS row of the round's entries
             if (lane == 0) {
-                int p = pos0 + n;
+                int p = posd + n;
                 if (p >= n_ring) p -= n_ring;
-                ctl[1] = start + (unsigned)n;
+                ctl[1] = start + (unsigned)(pad + n);
                 ctl[2] = (unsigned)p;
                 q_store(ctl + 0, k + 1u);
             }
             // the chain must be done with what these ring rows held a lap ago
-            const unsigned need = start + (unsigned)n - (unsigned)n_ring;
+            const unsigned need = start + (unsigned)(pad + n) - (unsigned)n_ring;
             while ((int)(q_load(ctl + 5) - need) < 0) __builtin_amdgcn_s_sleep(1);
-            // 4. zeros (two contiguous runs when the rows wrap around the ring)
-            const int n1 = n < n_ring - pos0 ? n : n_ring - pos0;
+            // 4. zeros: the padding rows up to the end of the ring, the round's rows
             unsigned char* z1 = smem + (size_t)pos0 * row_bytes;
-            for (int o = lane * 16; o < n1 * row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(z1 + o) = make_uint4(0, 0, 0, 0);
-            for (int o = lane * 16; o < (n - n1) * row_bytes; o += 64 * 16)
-                *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+            for (int o = lane * 16; o < pad * row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(z1 + o) = make_uint4(0, 0, 0, 0);
+            unsigned char* z2 = smem + (size_t)posd * row_bytes;
+            for (int o = lane * 16; o < n * row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(z2 + o) = make_uint4(0, 0, 0, 0);
             // 5. every entry into LDS row rank(entry) of the round (LDS executes a wavefront's operations in order: the
             // zeros above are in place)
+            const unsigned base_off = (unsigned)posd * (unsigned)row_bytes;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const unsigned long long below = (1ull << (16 * v + sub)) - 1ull;
-                const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < b_nv[v]) {
-                        const int c = idx[j] - c0;
-                        int p = pos0 + __popcll(cm[c] & below);
-                        if (p >= n_ring) p -= n_ring;
-                        *reinterpret_cast<T*>(smem + (size_t)p * row_bytes + (size_t)c * sizeof(T)) = b_val[v][j] * scale;
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long m =
+                        *reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(cm) + c8[v][j]);
+                    const unsigned rank = (unsigned)__popcll(m & below);
+                    unsigned a = base_off + rank * (unsigned)row_bytes + c8[v][j] / (8u / (unsigned)sizeof(T));
+                    a = j < b_nv[v] ? a : trash_off;
+                    *reinterpret_cast<T*>(smem + a) = b_val[v][j] * scale;
+                }
             }
-            if (b_more && b_slow) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                for (int j = b_from; j < b_cnt; ++j) {
-                    const int c = indices[b_base + j] - c0;
-                    int p = pos0 + __popcll(cm[c] & below);
-                    if (p >= n_ring) p -= n_ring;
-                    *reinterpret_cast<T*>(smem + (size_t)p * row_bytes + (size_t)c * sizeof(T)) = vals[b_base + j] * scale;
+            if (b_more) {
+                if (b_slow) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    for (int j = b_from; j < b_cnt; ++j) {
+                        const int c = indices[b_base + j] - c0;
+                        const int p = posd + __popcll(cm[c] & below);
+                        *reinterpret_cast<T*>(smem + (size_t)p * row_bytes + (size_t)c * sizeof(T)) = vals[b_base + j] * scale;
+                    }
                 }
             }
             // 6. masks back to zero for this wavefront's next round
@@ -361,7 +422,7 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
             // 7. publish, in round order
             while (q_load(ctl + 3) != k) __builtin_amdgcn_s_sleep(1);
             if (lane == 0) {
-                ctl[4] = start + (unsigned)n;
+                ctl[4] = start + (unsigned)(pad + n);
                 q_store(ctl + 3, k + 1u);
             }
         };

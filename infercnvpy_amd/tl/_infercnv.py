@@ -460,9 +460,10 @@ def infercnv(
     matrix row by row in the matrix dtype, scipy adds ``x * (1 / n)`` row by row for CSR and reduces CSC columns
     pairwise (reference :385, :400) -- so the means, and with them ``X_cnv``, equal the reference's bit for bit.  A
     float32 chain is sequential per column: with several GPUs shard k continues the accumulators of shard k - 1 (R x G
-    values travel through the host); the uploads of all shards still overlap.  Not reproduced: the order numpy uses
-    for a dense matrix that is not C-contiguous (it is treated as C-contiguous) and scipy's order for sparse formats
-    other than CSR / CSC (converted to CSR).
+    values travel through the host); the uploads of all shards still overlap.  A dense matrix stored column-major
+    (``np.asfortranarray``, a transposed genes x cells array) gets numpy's order for THAT layout (pairwise per column
+    over 8 192-element pieces), formed on the first GPU before the shards start.  Not reproduced: scipy's order for
+    sparse formats other than CSR / CSC (converted to CSR; a warning says so).
     ``_timings`` (not part of the reference API): a dict that receives the wall-clock seconds of the stages (plan,
     host -> HBM copy, kernels, CSR pack + copy back; per shard under ``"shards"`` when there are several).
 
@@ -539,6 +540,14 @@ def infercnv(
     if isinstance(X, np.matrix):
         X = np.asarray(X)
     X_csc = X if (sp.issparse(X) and X.format == "csc") else None  # scipy reduces CSC columns in another order
+    # a dense matrix stored column-major (np.asfortranarray, the transposed view of a genes x cells array): numpy puts the
+    # axis with the smaller stride innermost and reduces every column pairwise instead of as one chain (:385)
+    X_fortran = X if (isinstance(X, np.ndarray) and X.ndim == 2 and X.shape[0] > 1 and X.shape[1] > 1
+                      and abs(X.strides[0]) < abs(X.strides[1])) else None
+    if sp.issparse(X) and X.format not in ("csr", "csc") and reference is None and mean_order == "reference":
+        log.warning(f"tl.infercnv: a {X.format.upper()} matrix is converted to CSR; scipy's own summation order for this "
+                    "format is not reproduced, so the reference means (and entries of X_cnv next to the noise "
+                    "threshold) may differ from infercnvpy's in the last bit.  Convert with .tocsr() for exact parity.")
     if sp.issparse(X):
         X = X.tocsr()
         if not X.has_canonical_format:  # the kernels expect unique, sorted column indices per row
@@ -607,6 +616,15 @@ def infercnv(
             cnt = [int(n_obs)] if cats is None else [int(c) for c in counts]
             means = _engine.csc_column_means(X_csc, groups, n_groups, cnt, np_dtype=mean_dtype)
         given = _means_from_chains(list(means), counts, cats, True)
+        need_means = False
+        tm["reference_pass"] = _time.perf_counter() - t0
+
+    if need_means and X_fortran is not None and groups is None and not f64_means:
+        # F-ordered input, all-cell mean: whole columns are needed -- formed on the first GPU before the shards start
+        # (per-category means go through X[rows, :], which numpy returns C-ordered: the chains below)
+        t0 = _time.perf_counter()
+        with torch.cuda.device(devs[0]):
+            given = _engine.fortran_column_means(X_fortran, np_dtype=mean_dtype)[np.newaxis, :]
         need_means = False
         tm["reference_pass"] = _time.perf_counter() - t0
 

@@ -40,6 +40,10 @@ class GoldenCase:
         self.in_dtype = str(z["in_dtype"])
         if "X" in z.files:
             self.X_dense = z["X"]
+        elif "in_seed" in z.files:  # stored by seed (tests/golden/make_golden.py: in_seed)
+            shape = tuple(int(v) for v in z["in_shape"])
+            self.X_dense = cases.synthetic_expr(shape[0], shape[1], seed=int(z["in_seed"]))
+            assert cases.checksum(self.X_dense) == str(z["in_checksum"]), "seeded input drifted"
         else:
             self.X_dense = self._rebuild(tuple(int(v) for v in z["in_shape"]))
             assert cases.checksum(self.X_dense) == str(z["in_checksum"]), "seeded input drifted"
@@ -57,6 +61,8 @@ class GoldenCase:
             return sp.csr_matrix(self.X_dense)
         if self.fmt == "csc":
             return sp.csc_matrix(self.X_dense)
+        if self.fmt == "dense_f":
+            return np.asfortranarray(self.X_dense)
         return self.X_dense
 
     def api_kwargs(self):

@@ -66,7 +66,7 @@ def make_adata(X, var, obs_labels=None):
     return DuckAnnData(X, obs, vdf)
 
 
-def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="dense"):
+def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="dense", in_seed=None):
     if ONLY is not None and not name.startswith(ONLY):
         return
     Xin = X
@@ -74,6 +74,8 @@ def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="
         Xin = sp.csr_matrix(X)
     elif fmt == "csc":
         Xin = sp.csc_matrix(X)
+    elif fmt == "dense_f":  # column-major storage: numpy reduces np.mean(X, axis=0) pairwise per column (:385)
+        Xin = np.asfortranarray(X)
     adata = make_adata(Xin, var, obs_labels)
     kw = dict(kwargs)
     kw["inplace"] = False
@@ -92,6 +94,8 @@ def run_case(ref, name, X, var, kwargs, obs_labels=None, store_input=True, fmt="
     )
     if store_input:
         out["X"] = X
+    elif in_seed is not None:
+        out["in_seed"] = np.array(in_seed)
     if obs_labels is not None:
         out["obs"] = np.array(obs_labels)
     if per_gene is not None:
@@ -190,7 +194,20 @@ def main():
     # float32 matrix with a float64 reference -> numpy promotes the subtraction to float64
     run_case(ref, "m_dense_f32_ref64", Xf, var_m, dict(reference=Xf.mean(axis=0, dtype=np.float64)))
 
+    # column-major dense input (np.asfortranarray / a transposed genes x cells array): numpy's all-cell mean is pairwise
+    # per column, over 8 192-element pieces of the iterator's buffer (the 9 000-cell case crosses a piece boundary);
+    # per-category means go through X[rows, :], which numpy returns C-ordered
+    run_case(ref, "m_densef_f32_allmean", Xf, var_m, dict(), fmt="dense_f")
+    run_case(ref, "m_densef_f64_allmean", Xd_f := cases.synthetic_expr(C, G, seed=4, dtype=np.float64), var_m, dict(),
+             fmt="dense_f")
+    run_case(ref, "m_densef_f32_r2", Xf, var_m, dict(reference_key="group", reference_cat=["normalA", "normalB"]),
+             obs_labels=labels, fmt="dense_f")
+    var_f = cases.synthetic_var([230, 110, 101], names=["chr1", "chr2", "chr3"], seed_start=30, seed_perm=31)
+    Xbig = cases.synthetic_expr(9000, len(var_f["names"]), seed=14)
+    run_case(ref, "m_densef_f32_9000", Xbig, var_f, dict(chunksize=3000), fmt="dense_f", store_input=False, in_seed=14)
+
     Xi = cases.synthetic_counts(C, G, seed=5)
+    run_case(ref, "m_densef_i64_allmean", Xi, var_m, dict(), fmt="dense_f")
     run_case(ref, "m_dense_i64_allmean", Xi, var_m, dict())
     run_case(ref, "m_dense_i64_r2", Xi, var_m, dict(reference_key="group", reference_cat=["normalA", "normalB"]),
              obs_labels=labels)

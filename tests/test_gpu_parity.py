@@ -514,7 +514,8 @@ def test_csr_long_windows_do_not_depend_on_entry_order():
         def run(ix, dv):
             dm = _engine.DeviceMatrix(indptr=torch.from_numpy(csr.indptr.astype(np.int64)).cuda(),
                                       indices=torch.from_numpy(ix.astype(np.int32)).cuda(),
-                                      data=torch.from_numpy(dv.astype(np.float32)).cuda(), shape=csr.shape)
+                                      data=torch.from_numpy(dv.astype(np.float32)).cuda(), shape=csr.shape,
+                                      validate=False)  # (unsorted on purpose: the public constructor refuses it)
             res = _engine.run_hot_path(plan, dm, ref, chunksize=100, cell_stats=True)
             torch.cuda.synchronize()
             return res

@@ -161,3 +161,53 @@ def test_csc_means_are_scipy_bit_for_bit(dtype):
         counts.append(int((labels == c).sum()))
     got = _engine.csc_column_means(X, groups, 2, counts, np_dtype=np_dtype)
     np.testing.assert_array_equal(got, _oracle_means(X, labels, ["u", "n"]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 50_001])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_column_major_dense_mean_is_numpys_pairwise_order(n, dtype):
+    """np.mean(X, axis=0) of an F-ordered matrix (reference :385 on the matrix as stored): numpy reduces every column with
+    its contiguous inner loop -- pairwise summation over pieces of 8 192 elements -- not as the sequential chain a
+    C-ordered matrix gets; icv_colsum_pairwise restates it."""
+    from infercnvpy_amd import _engine
+
+    g = 37
+    X = np.asfortranarray(_expr(n, g, seed=n, dtype=dtype, density=0.6))
+    got = _engine.fortran_column_means(X, max_bytes=max(1, n) * X.itemsize * 10)  # several column blocks
+    exp = np.mean(X, axis=0)
+    assert got.dtype == exp.dtype
+    np.testing.assert_array_equal(got, exp)
+    if n >= 129:  # the two layouts really are different sums
+        Xs = np.asfortranarray(X[::2])  # and a row-sliced view keeps the layout rule (smaller stride innermost)
+        np.testing.assert_array_equal(_engine.fortran_column_means(X[::2]), np.mean(X[::2], axis=0))
+        np.testing.assert_array_equal(_engine.fortran_column_means(Xs), np.mean(Xs, axis=0))
+
+
+def test_public_call_on_column_major_input_matches_numpy_order():
+    """The whole call: an F-ordered adata.X (a transposed genes x cells array) gives the X_cnv of the oracle run on the
+    same array (numpy's own mean), on one shard and on three; integer counts too; per-category means (X[rows, :] is
+    C-ordered in numpy) unchanged."""
+    import pandas as pd
+
+    import cases
+    import infercnvpy_amd as cnv
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var([300, 120, 101, 60])
+    n = 9000
+    XT = np.ascontiguousarray(cases.synthetic_expr(n, len(v["names"]), seed=3).T)  # genes x cells, C-ordered
+    X = XT.T  # cells x genes: column-major
+    assert X.strides[0] < X.strides[1]
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    labels = np.array(["n", "t"])[np.random.RandomState(0).randint(0, 2, n)]
+    obs = pd.DataFrame({"group": labels}, index=[f"c{i}" for i in range(n)])
+    for Xin in (X, np.asfortranarray(np.random.RandomState(1).poisson(0.4, X.shape).astype(np.int64))):
+        _, exp, _, _ = O.infercnv(Xin, v["chromosome"], v["start"], chunksize=3000)
+        for kw in (dict(), dict(devices=[0, 0, 0])):
+            _, got, _ = cnv.tl.infercnv(cnv.SimpleAnnData(Xin, obs=obs, var=var), inplace=False, chunksize=3000, **kw)
+            np.testing.assert_array_equal(got.toarray() == 0, exp.toarray() == 0)
+            np.testing.assert_allclose(got.toarray(), exp.toarray(), rtol=0, atol=1e-6)
+    _, exp, _, _ = O.infercnv(X, v["chromosome"], v["start"], chunksize=3000, obs_col=labels, reference_cat=["n"])
+    _, got, _ = cnv.tl.infercnv(cnv.SimpleAnnData(X, obs=obs, var=var), inplace=False, chunksize=3000,
+                                reference_key="group", reference_cat=["n"])
+    np.testing.assert_array_equal(got.toarray() == 0, exp.toarray() == 0)

@@ -63,8 +63,9 @@ def test_chain_on_resident_adata_equals_host_chain_bit_for_bit(fmt):
     i_h = cnv.tl.ithcna(ad_h, "clone", inplace=False)
     i_d = cnv.tl.ithcna(ad_d, "clone", inplace=False)
     assert "solo" not in i_h and i_h.keys() == i_d.keys() and len(i_h) == 4
-    for k in i_h:
-        assert i_h[k] == i_d[k], (k, i_h[k], i_d[k])
+    for k in i_h:  # (bit for bit; NaN -- a group with a constant row, as np.corrcoef gives -- equals NaN)
+        np.testing.assert_array_equal(i_h[k], i_d[k], err_msg=str(k))
+    assert np.isfinite(list(i_h.values())).any()
 
     # cell_linkage (config 5's input never leaves the GPU)
     z_h = cnv.tl.cell_linkage(ad_h, inplace=False)
