@@ -420,6 +420,21 @@ int icv_csr_check(const int64_t *indptr, const int32_t *indices, int64_t n_rows,
 int icv_csr_densify(const void *data, int32_t dtype, const int64_t *indptr, const int32_t *indices, const int64_t *rows,
                     int64_t n_sel, int32_t n_cols, float *out, int64_t ldo, void *stream);
 
+/* ---- upload path of a mostly-zero DENSE host matrix (reference tl/_infercnv.py:115-116, :422-423: a dense adata.X of
+ * log-counts is ~80 % zeros; PCIe is what a host-input call waits for) -- HOST functions (h_ pointers), no GPU needed:
+ * icv_host_dense_row_nnz counts the stored entries (bit pattern != 0: NaN and -0.0 count) of every row of a row-major
+ * float32 / float64 matrix on n_threads threads; the caller forms indptr (prefix sums, indptr[0] = 0);
+ * icv_host_dense_pack writes the rows' column indices (int32, ascending) and values at indptr[r].  The arrays then cross
+ * PCIe (8 or 12 bytes per stored entry instead of 4 or 8 per element) and icv_csr_scatter_dense (device pointers)
+ * rebuilds the dense rows in HBM: out[r * ldo + c] = value, zeros elsewhere -- bit for bit the matrix a dense upload
+ * would have delivered, so everything downstream is unchanged. */
+int icv_host_dense_row_nnz(const void *h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                           int64_t *h_row_nnz, int32_t n_threads);
+int icv_host_dense_pack(const void *h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                        const int64_t *h_indptr, int32_t *h_indices, void *h_values, int32_t n_threads);
+int icv_csr_scatter_dense(const void *data, int32_t dtype, const int64_t *indptr, const int32_t *indices, int64_t n_rows,
+                          int32_t n_cols, void *out, int64_t ldo, void *stream);
+
 /* ---- misc --------------------------------------------------------------------------------- */
 const char *icv_last_error(void);
 int icv_version(void);

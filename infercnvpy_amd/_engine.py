@@ -296,6 +296,28 @@ class SmoothResult:
         self.profile = profile
 
 
+def _default_pack_threads():
+    return int(max(1, min(48, (os.cpu_count() or 2) // 2)))
+
+
+def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3, probe_rows=256):
+    """Dense host rows go up as stored entries when they are mostly zeros: a C-ordered float matrix of the compute
+    dtype, at least 1024 columns, fewer than ``max_density`` non-zeros in a probe of the first rows.
+    ``ICV_NO_SPARSE_UPLOAD`` switches it off (A/B timing)."""
+    if os.environ.get("ICV_NO_SPARSE_UPLOAD"):
+        return False
+    if not isinstance(X, np.ndarray) or X.ndim != 2 or X.dtype != np_dtype or X.shape[1] < 1024 or row1 <= row0:
+        return False
+    if X.strides[1] != X.itemsize or X.strides[0] < X.shape[1] * X.itemsize or X.strides[0] % X.itemsize:
+        return False
+    n = min(probe_rows, row1 - row0)
+    xs = X[row0:row0 + n]
+    cnt = np.zeros(n, dtype=np.int64)
+    _lib.check(_lib.load().icv_host_dense_row_nnz(xs.ctypes.data, _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64,
+                                                  n, X.shape[1], X.strides[0] // X.itemsize, cnt.ctypes.data, 1))
+    return float(cnt.sum()) < max_density * n * X.shape[1]
+
+
 class SlabStream:
     """Upload the rows of a host matrix piece by piece on a side stream while the caller computes.
 
@@ -305,9 +327,11 @@ class SlabStream:
     ``dm`` is the DeviceMatrix of the whole slab (valid row ranges: the pieces yielded so far).
     """
 
-    def __init__(self, X, tdtype, piece_rows, row0=0, row1=None):
+    def __init__(self, X, tdtype, piece_rows, row0=0, row1=None, host_pack_threads=None):
         """Rows [row0, row1) of the host matrix ``X`` (the parent's arrays are read in place: slicing a scipy CSR
-        matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded)."""
+        matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded).
+        ``host_pack_threads``: host threads of the sparse upload of a mostly-zero dense matrix (default: half the
+        logical CPUs, at most 48; callers with several shards divide them)."""
         import queue
         import threading
 
@@ -321,6 +345,8 @@ class SlabStream:
         creator_stream = torch.cuda.current_stream()
         self._err = None
         self._cancel = threading.Event()
+        self.sparse_upload = False
+        self._packer = None
         # one uploader thread (and stream) per host array: a CSR slab is two arrays, and two threads keep the link
         # busy where one thread alternating between them does not (measured with cold pages and a device -> host
         # copy beside them: 54 against 39 GB/s, tools/exp_h2d_csr.py)
@@ -351,10 +377,80 @@ class SlabStream:
         else:
             dense = torch.empty((self.n_rows, X.shape[1]), dtype=tdtype, device="cuda")
             self.dm = DeviceMatrix(dense=dense)
+            self.sparse_upload = _wants_sparse_upload(X, np_dtype, row0, row1)
 
             def copy_piece(r0, r1):
                 dense[r0:r1].copy_(torch.from_numpy(
                     np.ascontiguousarray(X[row0 + r0:row0 + r1].astype(np_dtype, copy=False))))
+
+            if self.sparse_upload:
+                # A dense matrix of log-counts is ~80 % zeros and PCIe is what the call waits for: a packer thread turns
+                # every piece into (indptr, indices, values) on host threads (icv_host_dense_pack: 8 bytes per stored
+                # entry instead of 4 per element), the copier thread sends the three arrays and rebuilds the dense rows
+                # in HBM (icv_csr_scatter_dense) -- the slab is bit for bit what the dense copy would have delivered.
+                lib = _lib.load()
+                code = _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64
+                n_cols = X.shape[1]
+                ld = X.strides[0] // X.itemsize
+                n_thr = host_pack_threads if host_pack_threads else _default_pack_threads()
+                packed_q = queue.Queue(maxsize=2)  # packed pieces waiting for the link
+                free_q = queue.Queue()             # recycled host buffers (pages stay mapped)
+                for _ in range(3):
+                    free_q.put([np.empty(0, np.int32), np.empty(0, np_dtype)])
+
+                def pack_all():
+                    try:
+                        for r0, r1 in self.bounds:
+                            if self._cancel.is_set():
+                                break
+                            xs = X[row0 + r0:row0 + r1]
+                            ip = np.zeros(r1 - r0 + 1, dtype=np.int64)
+                            _lib.check(lib.icv_host_dense_row_nnz(xs.ctypes.data, code, r1 - r0, n_cols, ld,
+                                                                  ip[1:].ctypes.data, n_thr))
+                            np.cumsum(ip, out=ip)
+                            nnz = int(ip[-1])
+                            bufs = None
+                            while bufs is None:  # (a copier that has failed or been cancelled returns nothing)
+                                try:
+                                    bufs = free_q.get(timeout=0.1)
+                                except queue.Empty:
+                                    if self._cancel.is_set() or self._err is not None:
+                                        return
+                            if bufs[0].shape[0] < nnz:
+                                cap = int(nnz * 1.15) + 1024
+                                bufs[0], bufs[1] = np.empty(cap, np.int32), np.empty(cap, np_dtype)
+                            _lib.check(lib.icv_host_dense_pack(xs.ctypes.data, code, r1 - r0, n_cols, ld, ip.ctypes.data,
+                                                               bufs[0].ctypes.data, bufs[1].ctypes.data, n_thr))
+                            while True:
+                                try:
+                                    packed_q.put((ip, nnz, bufs), timeout=0.1)
+                                    break
+                                except queue.Full:
+                                    if self._cancel.is_set() or self._err is not None:
+                                        return
+                    except BaseException as e:  # surfaced by the copier
+                        try:
+                            packed_q.put(e, timeout=5)
+                        except queue.Full:
+                            self._err = e
+
+                def copy_piece(r0, r1):  # noqa: F811 -- the sparse form replaces the dense copy
+                    item = packed_q.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    ip, nnz, bufs = item
+                    d_ip = torch.from_numpy(ip).cuda()
+                    d_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device="cuda")
+                    d_val = torch.empty(max(nnz, 1), dtype=tdtype, device="cuda")
+                    if nnz:
+                        d_idx[:nnz].copy_(torch.from_numpy(bufs[0][:nnz]))
+                        d_val[:nnz].copy_(torch.from_numpy(bufs[1][:nnz]))
+                    free_q.put(bufs)  # (pageable copies have left the host buffers when copy_ returns)
+                    _lib.check(lib.icv_csr_scatter_dense(_ptr(d_val), code, _ptr(d_ip), _ptr(d_idx), r1 - r0, n_cols,
+                                                         C.c_void_p(dense[r0:r1].data_ptr()), dense.stride(0),
+                                                         _stream_ptr(torch)))
+
+                self._packer = threading.Thread(target=pack_all, daemon=True)
 
             copiers = [copy_piece]
 
@@ -387,6 +483,8 @@ class SlabStream:
             self._busy[k] = time.perf_counter() - t0
 
         self._threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(len(copiers))]
+        if getattr(self, "_packer", None) is not None:
+            self._threads.append(self._packer)
         for th in self._threads:
             th.start()
 

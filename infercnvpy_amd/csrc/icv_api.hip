@@ -13,6 +13,10 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <memory>
 #include <vector>
 
@@ -2339,6 +2343,226 @@ int icv_csr_densify(const void* data, int32_t dtype, const int64_t* indptr, cons
     else
         hipLaunchKernelGGL(icv::k_csr_densify<double>, grid, block, 0, st, static_cast<const double*>(data), indptr,
                            indices, rows, n_sel, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+}  // extern "C"
+
+// ---- host-side packing of a mostly-zero dense matrix (the upload path of tl.infercnv for dense host input) ---------------
+namespace {
+template <typename T, typename B>
+void host_count_rows(const T* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, int64_t* row_nnz) {
+    for (int64_t r = r0; r < r1; ++r) {
+        const B* b = reinterpret_cast<const B*>(x + r * ld);
+        int64_t c = 0;
+        for (int64_t j = 0; j < n_cols; ++j) c += b[j] != 0;  // bit pattern: NaN and -0.0 are stored entries
+        row_nnz[r] = c;
+    }
+}
+// elements [j, n_cols) of one row, entries from cursor k on (k < end while there is something to find): branch-free,
+// every element is written at the cursor and the cursor moves on for stored ones; never writes at or past `end`
+template <typename T, typename B>
+inline void host_pack_tail(const T* xr, int64_t j, int64_t n_cols, int64_t k, int64_t end, int32_t* indices, T* values) {
+    const B* b = reinterpret_cast<const B*>(xr);
+    for (; j < n_cols && k < end; ++j) {
+        indices[k] = (int32_t)j;
+        values[k] = xr[j];
+        k += b[j] != 0;
+    }
+}
+template <typename T, typename B>
+void host_pack_rows(const T* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, const int64_t* indptr,
+                    int32_t* indices, T* values) {
+    for (int64_t r = r0; r < r1; ++r) {
+        const T* xr = x + r * ld;
+        const int64_t k = indptr[r], end = indptr[r + 1];
+        if (end - k == n_cols) {  // a full row: no test per element
+            for (int64_t j = 0; j < n_cols; ++j) indices[k + j] = (int32_t)j, values[k + j] = xr[j];
+            continue;
+        }
+        host_pack_tail<T, B>(xr, 0, n_cols, k, end, indices, values);
+    }
+}
+
+// AVX-512 forms (chosen at run time: the library is built on one machine and runs on another).  Register compress +
+// full-width store (the memory-destination compress is microcoded on some cores); a vector is only stored while 16 (8)
+// slots of THIS row are left, the last entries of a row go through the scalar tail -- nothing is written outside
+// [indptr[r], indptr[r + 1]), so rows can be packed by different threads.
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+void host_count_rows_avx512_f32(const float* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, int64_t* row_nnz) {
+    for (int64_t r = r0; r < r1; ++r) {
+        const float* xr = x + r * ld;
+        int64_t c = 0, j = 0;
+        for (; j + 16 <= n_cols; j += 16) {
+            const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+            c += _mm_popcnt_u32((unsigned)_mm512_test_epi32_mask(v, v));
+        }
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(xr);
+        for (; j < n_cols; ++j) c += b[j] != 0;
+        row_nnz[r] = c;
+    }
+}
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+void host_count_rows_avx512_f64(const double* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, int64_t* row_nnz) {
+    for (int64_t r = r0; r < r1; ++r) {
+        const double* xr = x + r * ld;
+        int64_t c = 0, j = 0;
+        for (; j + 8 <= n_cols; j += 8) {
+            const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+            c += _mm_popcnt_u32((unsigned)_mm512_test_epi64_mask(v, v));
+        }
+        const uint64_t* b = reinterpret_cast<const uint64_t*>(xr);
+        for (; j < n_cols; ++j) c += b[j] != 0;
+        row_nnz[r] = c;
+    }
+}
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+void host_pack_rows_avx512_f32(const float* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, const int64_t* indptr,
+                               int32_t* indices, float* values) {
+    const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    for (int64_t r = r0; r < r1; ++r) {
+        const float* xr = x + r * ld;
+        int64_t k = indptr[r];
+        const int64_t end = indptr[r + 1];
+        int64_t j = 0;
+        for (; j + 16 <= n_cols && k + 16 <= end; j += 16) {
+            const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+            const __mmask16 m = _mm512_test_epi32_mask(v, v);
+            _mm512_storeu_si512((void*)(values + k), _mm512_maskz_compress_epi32(m, v));
+            _mm512_storeu_si512((void*)(indices + k),
+                                _mm512_maskz_compress_epi32(m, _mm512_add_epi32(iota, _mm512_set1_epi32((int)j))));
+            k += _mm_popcnt_u32((unsigned)m);
+        }
+        host_pack_tail<float, uint32_t>(xr, j, n_cols, k, end, indices, values);
+    }
+}
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+void host_pack_rows_avx512_f64(const double* x, int64_t r0, int64_t r1, int64_t n_cols, int64_t ld, const int64_t* indptr,
+                               int32_t* indices, double* values) {
+    const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    for (int64_t r = r0; r < r1; ++r) {
+        const double* xr = x + r * ld;
+        int64_t k = indptr[r];
+        const int64_t end = indptr[r + 1];
+        int64_t j = 0;
+        for (; j + 8 <= n_cols && k + 8 <= end; j += 8) {
+            const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+            const __mmask8 m = _mm512_test_epi64_mask(v, v);
+            _mm512_storeu_si512((void*)(values + k), _mm512_maskz_compress_epi64(m, v));
+            _mm256_storeu_si256((__m256i*)(indices + k),
+                                _mm256_maskz_compress_epi32(m, _mm256_add_epi32(iota, _mm256_set1_epi32((int)j))));
+            k += _mm_popcnt_u32((unsigned)m);
+        }
+        host_pack_tail<double, uint64_t>(xr, j, n_cols, k, end, indices, values);
+    }
+}
+bool host_has_avx512() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                           __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("popcnt") &&
+                           std::getenv("ICV_NO_AVX512") == nullptr;
+    return ok;
+}
+#else
+bool host_has_avx512() { return false; }
+#endif
+template <typename F>
+void host_parallel_rows(int64_t n_rows, int n_threads, F&& fn) {
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n_rows) n_threads = (int)(n_rows > 0 ? n_rows : 1);
+    if (n_threads == 1) {
+        fn((int64_t)0, n_rows);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(n_threads);
+    for (int t = 0; t < n_threads; ++t) {
+        const int64_t a = n_rows * t / n_threads, b = n_rows * (t + 1) / n_threads;
+        pool.emplace_back([&fn, a, b] { fn(a, b); });
+    }
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+extern "C" {
+
+int icv_host_dense_row_nnz(const void* h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                           int64_t* h_row_nnz, int32_t n_threads) {
+    if (!h_x || !h_row_nnz || n_rows < 0 || n_cols < 0 || ld < n_cols || (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad host_dense_row_nnz arguments");
+    try {
+        const bool vec = host_has_avx512();
+        if (dtype == ICV_F32)
+            host_parallel_rows(n_rows, n_threads, [&](int64_t a, int64_t b) {
+#if defined(__x86_64__)
+                if (vec) return host_count_rows_avx512_f32((const float*)h_x, a, b, n_cols, ld, h_row_nnz);
+#endif
+                host_count_rows<float, uint32_t>((const float*)h_x, a, b, n_cols, ld, h_row_nnz);
+            });
+        else
+            host_parallel_rows(n_rows, n_threads, [&](int64_t a, int64_t b) {
+#if defined(__x86_64__)
+                if (vec) return host_count_rows_avx512_f64((const double*)h_x, a, b, n_cols, ld, h_row_nnz);
+#endif
+                host_count_rows<double, uint64_t>((const double*)h_x, a, b, n_cols, ld, h_row_nnz);
+            });
+    } catch (const std::exception& e) {
+        return fail(ICV_ERR_NOMEM, std::string("host_dense_row_nnz: ") + e.what());
+    }
+    return ICV_OK;
+}
+
+int icv_host_dense_pack(const void* h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                        const int64_t* h_indptr, int32_t* h_indices, void* h_values, int32_t n_threads) {
+    if (!h_x || !h_indptr || !h_indices || !h_values || n_rows < 0 || n_cols < 0 || ld < n_cols ||
+        (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad host_dense_pack arguments");
+    try {
+        const bool vec = host_has_avx512();
+        if (dtype == ICV_F32)
+            host_parallel_rows(n_rows, n_threads, [&](int64_t a, int64_t b) {
+#if defined(__x86_64__)
+                if (vec)
+                    return host_pack_rows_avx512_f32((const float*)h_x, a, b, n_cols, ld, h_indptr, h_indices,
+                                                     (float*)h_values);
+#endif
+                host_pack_rows<float, uint32_t>((const float*)h_x, a, b, n_cols, ld, h_indptr, h_indices, (float*)h_values);
+            });
+        else
+            host_parallel_rows(n_rows, n_threads, [&](int64_t a, int64_t b) {
+#if defined(__x86_64__)
+                if (vec)
+                    return host_pack_rows_avx512_f64((const double*)h_x, a, b, n_cols, ld, h_indptr, h_indices,
+                                                     (double*)h_values);
+#endif
+                host_pack_rows<double, uint64_t>((const double*)h_x, a, b, n_cols, ld, h_indptr, h_indices,
+                                                 (double*)h_values);
+            });
+    } catch (const std::exception& e) {
+        return fail(ICV_ERR_NOMEM, std::string("host_dense_pack: ") + e.what());
+    }
+    return ICV_OK;
+}
+
+int icv_csr_scatter_dense(const void* data, int32_t dtype, const int64_t* indptr, const int32_t* indices, int64_t n_rows,
+                          int32_t n_cols, void* out, int64_t ldo, void* stream) {
+    if (!indptr || !out || n_rows < 0 || n_cols < 0 || ldo < n_cols || (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad csr_scatter_dense arguments");
+    if (n_rows == 0 || n_cols == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t esz = dtype == ICV_F32 ? 4 : 8;
+    if (ldo == n_cols)
+        HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_rows * n_cols * esz, st));
+    else
+        HIP_TRY(hipMemset2DAsync(out, (size_t)ldo * esz, 0, (size_t)n_cols * esz, (size_t)n_rows, st));
+    dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    if (dtype == ICV_F32)
+        hipLaunchKernelGGL(icv::k_csr_scatter_rows<float>, grid, block, 0, st, static_cast<const float*>(data), indptr,
+                           indices, n_rows, static_cast<float*>(out), ldo);
+    else
+        hipLaunchKernelGGL(icv::k_csr_scatter_rows<double>, grid, block, 0, st, static_cast<const double*>(data), indptr,
+                           indices, n_rows, static_cast<double*>(out), ldo);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

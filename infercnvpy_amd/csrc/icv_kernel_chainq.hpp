@@ -31,9 +31,11 @@ namespace icv {
 constexpr int kQRows = 64;      // input rows per round (one bit each in a column's row mask)
 constexpr int kQTabRows = 32;   // rows per block of the bounds table
 constexpr int kQCtl = 256;      // control words at the end of the LDS
-constexpr int kQCmBytes = 1040; // row masks of one producer wavefront: 128 columns x 8 bytes + a trash word (lanes
-                                // without an entry OR into it: no branches around the atomics)
-constexpr int kQTrash = 16;     // LDS bytes the lanes without an entry scatter into
+constexpr int kQCmBytes = 1536; // row masks of one producer wavefront: 128 columns x 8 bytes + one trash word PER LANE
+                                // (lanes without an entry OR into theirs: no branches around the atomics, and no two
+                                // lanes on one address -- a single shared trash word serialised 37 lanes per atomic:
+                                // 6.1 ms instead of 2.6)
+constexpr int kQTrash = 512;    // LDS bytes the lanes without an entry scatter into (8 per lane)
 constexpr int kQFar = 1 << 28;  // entries a buffer offset can span (far_limit); rows further apart take the guarded loads
 
 __host__ __device__ inline int64_t q_tab_index(int64_t i, int t, int n_tiles) {
@@ -250,8 +252,8 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
     const int c0 = line0 * (128 / (int)sizeof(T));
     const int row_bytes = 128 * nl;
     const int n_tcols = row_bytes / (int)sizeof(T);  // columns of the tile (<= 128)
-    // LDS: [ring: n_ring rows][row masks: 15 x 1 KB][control words]
-    const int n_ring = (lds_bytes - kChLoaders * kQCmBytes - kQCtl) / row_bytes / 10 * 10;
+    // LDS: [ring: n_ring rows][trash bytes of the scatter: 8 per lane][row masks + trash words: 15 x 1.5 KB][control words]
+    const int n_ring = (lds_bytes - kChLoaders * kQCmBytes - kQCtl - kQTrash) / row_bytes / 10 * 10;
     unsigned char* cm_base = smem + (lds_bytes - kQCtl - kChLoaders * kQCmBytes);
     // ctl: [0] next round to allocate, [1] rows allocated (wrapping counter), [2] ring position of the next row,
     //      [3] rounds published, [4] rows published, [5] rows consumed
@@ -339,17 +341,19 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
         // order.  The per-entry code has NO branches: a lane without an entry ORs into the trash word behind the masks
         // and scatters into the trash bytes behind them (exec-mask juggling around 32 atomics / stores cost as much as
         // the work itself in the first version).
-        const unsigned trash_off = (unsigned)(lds_bytes - kQCtl - kQTrash);  // byte offset in LDS of the trash bytes
+        // byte offset in LDS of this lane's trash bytes (the scatter of lanes without an entry; behind the ring)
+        const unsigned trash_off = (unsigned)(lds_bytes - kQCtl - kChLoaders * kQCmBytes - kQTrash) + 8u * (unsigned)lane;
         const auto write_round = [&](unsigned k) {
             // 1. row masks of the tile's columns
-            unsigned c8[4][4];  // 8 x (column inside the tile); 8 x 128 = the trash word
+            unsigned c8[4][4];  // 8 x (column inside the tile); 1024 + 8 x lane = the lane's trash word
+            const unsigned my_trash = 1024u + 8u * (unsigned)lane;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const unsigned long long bit = 1ull << (16 * v + sub);
                 const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    c8[v][j] = j < b_nv[v] ? (unsigned)(idx[j] - c0) * 8u : 1024u;
+                    c8[v][j] = j < b_nv[v] ? (unsigned)(idx[j] - c0) * 8u : my_trash;
                     __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(cm) + c8[v][j]),
                                           bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }

@@ -51,6 +51,20 @@ __global__ void __launch_bounds__(256) k_csr_densify(const T* __restrict__ data,
     for (int64_t k = indptr[row] + (threadIdx.x & 63); k < e1; k += 64) o[indices[k]] = (float)data[k];
 }
 
+// out[r][c] = value of the stored entry (r, c) in the matrix dtype; `out` was zeroed by the caller.  The device half of
+// the sparse upload of a mostly-zero dense host matrix: the dense slab the smoothing kernels read is rebuilt in HBM from
+// 8 bytes per stored entry instead of crossing PCIe as 4 bytes per element.
+template <typename T>
+__global__ void __launch_bounds__(256) k_csr_scatter_rows(const T* __restrict__ data, const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices, int64_t n_rows,
+                                                          T* __restrict__ out, int64_t ldo) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    T* o = out + row * ldo;
+    const int64_t e1 = indptr[row + 1];
+    for (int64_t k = indptr[row] + (threadIdx.x & 63); k < e1; k += 64) o[indices[k]] = data[k];
+}
+
 // sums[g] = sum of values[i] over i with group[i] == g, counts[g] = how many: thread t adds its rows t, t + 1024, ... in
 // order, then a fixed tree over the 1024 partial sums (the result depends on nothing but the inputs)
 __global__ void __launch_bounds__(1024) k_group_sums(const double* __restrict__ values,

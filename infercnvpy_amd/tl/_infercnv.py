@@ -496,7 +496,9 @@ def infercnv(
     than in the reference).
 
     Data movement: the rows are copied to HBM in pieces of a few chunks by a helper thread on a side stream
-    while the pieces that have landed are smoothed (reference means: chained); the noise threshold and the CSR
+    while the pieces that have landed are smoothed (reference means: chained); a dense float matrix that is mostly
+    zeros (fewer than 30 % non-zeros in a probe of its first rows -- log-counts usually are) crosses PCIe as its stored
+    entries (8 bytes each, packed by host threads) and is rebuilt as the same dense rows in HBM; the noise threshold and the CSR
     packing of X_cnv run on the GPU from the un-thresholded result and a keep-mask (x_res is never
     rewritten) and only the packed arrays cross PCIe on the way back.
     """
@@ -679,7 +681,9 @@ def infercnv(
                     retire(k)
                 r0, r1 = slabs[i]
                 # (the parent's arrays are read in place: no host copy of the shard or the slab)
-                streams[i] = _engine.SlabStream(X, tdtype, piece_rows, s.g0 + r0, s.g0 + r1)
+                streams[i] = _engine.SlabStream(X, tdtype, piece_rows, s.g0 + r0, s.g0 + r1,
+                                                host_pack_threads=max(2, _engine._default_pack_threads() // len(shards)))
+                s.tm["sparse_upload"] = bool(streams[i].sparse_upload)
             return streams[i]
 
         try:

@@ -59,13 +59,19 @@ def test_chain_on_resident_adata_equals_host_chain_bit_for_bit(fmt):
     for k in s_h:
         assert s_d[k] == pytest.approx(np.mean(np.abs(dense[(obs["clone"] == k).values])), rel=1e-12)
 
-    # ithcna: the group's rows become a float32 tile in HBM (icv_csr_densify) -> the same MFMA contraction
-    i_h = cnv.tl.ithcna(ad_h, "clone", inplace=False)
-    i_d = cnv.tl.ithcna(ad_d, "clone", inplace=False)
+    # ithcna: the group's rows become a float32 tile in HBM (icv_csr_densify) -> the same MFMA contraction.  On the
+    # un-thresholded profiles (a cell whose X_cnv row is all zeros has no correlation: NaN, in the reference as well)
+    cnv.tl.infercnv(ad_h, key_added="raw", dynamic_threshold=None, **kw)
+    cnv.tl.infercnv(ad_d, key_added="raw", dynamic_threshold=None, **kw)
+    i_h = cnv.tl.ithcna(ad_h, "clone", use_rep="X_raw", inplace=False)
+    i_d = cnv.tl.ithcna(ad_d, "clone", use_rep="X_raw", inplace=False)
     assert "solo" not in i_h and i_h.keys() == i_d.keys() and len(i_h) == 4
-    for k in i_h:  # (bit for bit; NaN -- a group with a constant row, as np.corrcoef gives -- equals NaN)
-        np.testing.assert_array_equal(i_h[k], i_d[k], err_msg=str(k))
-    assert np.isfinite(list(i_h.values())).any()
+    for k in i_h:
+        assert np.isfinite(i_h[k]) and i_h[k] == i_d[k], (k, i_h[k], i_d[k])
+    n_h = cnv.tl.ithcna(ad_h, "clone", inplace=False)  # thresholded X_cnv: NaN where a group has an all-zero cell
+    n_d = cnv.tl.ithcna(ad_d, "clone", inplace=False)
+    for k in n_h:
+        np.testing.assert_array_equal(n_h[k], n_d[k], err_msg=str(k))
 
     # cell_linkage (config 5's input never leaves the GPU)
     z_h = cnv.tl.cell_linkage(ad_h, inplace=False)
