@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import time as _time
 
 import numpy as np
 import scipy.sparse as sp
@@ -297,7 +298,42 @@ class SmoothResult:
 
 
 def _default_pack_threads():
-    return int(max(1, min(48, (os.cpu_count() or 2) // 2)))
+    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the logical CPUs, at most 64."""
+    env = os.environ.get("ICV_PACK_THREADS")
+    if env:
+        return max(1, int(env))
+    return int(max(1, min(64, (os.cpu_count() or 2) // 2)))
+
+
+# Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as
+# the packing itself): at most _PACK_POOL_MAX buffer pairs, handed out largest first.
+_PACK_POOL = []
+_PACK_POOL_LOCK = None
+_PACK_POOL_MAX = 6
+
+
+def _pack_pool_take(np_dtype):
+    import threading
+
+    global _PACK_POOL_LOCK
+    if _PACK_POOL_LOCK is None:
+        _PACK_POOL_LOCK = threading.Lock()
+    with _PACK_POOL_LOCK:
+        best = None
+        for k, b in enumerate(_PACK_POOL):
+            if b[1].dtype == np_dtype and (best is None or b[0].shape[0] > _PACK_POOL[best][0].shape[0]):
+                best = k
+        if best is not None:
+            return _PACK_POOL.pop(best)
+    return [np.empty(0, np.int32), np.empty(0, np_dtype)]
+
+
+def _pack_pool_give(bufs):
+    if _PACK_POOL_LOCK is None or bufs[0].shape[0] == 0:
+        return
+    with _PACK_POOL_LOCK:
+        if len(_PACK_POOL) < _PACK_POOL_MAX:
+            _PACK_POOL.append(bufs)
 
 
 def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3, probe_rows=256):
@@ -394,9 +430,12 @@ class SlabStream:
                 ld = X.strides[0] // X.itemsize
                 n_thr = host_pack_threads if host_pack_threads else _default_pack_threads()
                 packed_q = queue.Queue(maxsize=2)  # packed pieces waiting for the link
-                free_q = queue.Queue()             # recycled host buffers (pages stay mapped)
-                for _ in range(3):
-                    free_q.put([np.empty(0, np.int32), np.empty(0, np_dtype)])
+                free_q = queue.Queue()             # recycled host buffers: their pages stay mapped, within the call and
+                for _ in range(3):                 # (through the process-wide pool) between calls
+                    free_q.put(_pack_pool_take(np_dtype))
+                self._pack_bufs = free_q
+                self.pack_stats = {"count_s": 0.0, "pack_s": 0.0, "wait_buffer_s": 0.0, "wait_link_s": 0.0, "threads": n_thr}
+                stats = self.pack_stats
 
                 def pack_all():
                     try:
@@ -405,10 +444,12 @@ class SlabStream:
                                 break
                             xs = X[row0 + r0:row0 + r1]
                             ip = np.zeros(r1 - r0 + 1, dtype=np.int64)
+                            t0 = _time.perf_counter()
                             _lib.check(lib.icv_host_dense_row_nnz(xs.ctypes.data, code, r1 - r0, n_cols, ld,
                                                                   ip[1:].ctypes.data, n_thr))
                             np.cumsum(ip, out=ip)
                             nnz = int(ip[-1])
+                            t1 = _time.perf_counter()
                             bufs = None
                             while bufs is None:  # (a copier that has failed or been cancelled returns nothing)
                                 try:
@@ -419,8 +460,10 @@ class SlabStream:
                             if bufs[0].shape[0] < nnz:
                                 cap = int(nnz * 1.15) + 1024
                                 bufs[0], bufs[1] = np.empty(cap, np.int32), np.empty(cap, np_dtype)
+                            t2 = _time.perf_counter()
                             _lib.check(lib.icv_host_dense_pack(xs.ctypes.data, code, r1 - r0, n_cols, ld, ip.ctypes.data,
                                                                bufs[0].ctypes.data, bufs[1].ctypes.data, n_thr))
+                            t3 = _time.perf_counter()
                             while True:
                                 try:
                                     packed_q.put((ip, nnz, bufs), timeout=0.1)
@@ -428,6 +471,10 @@ class SlabStream:
                                 except queue.Full:
                                     if self._cancel.is_set() or self._err is not None:
                                         return
+                            stats["count_s"] += t1 - t0
+                            stats["wait_buffer_s"] += t2 - t1
+                            stats["pack_s"] += t3 - t2
+                            stats["wait_link_s"] += _time.perf_counter() - t3
                     except BaseException as e:  # surfaced by the copier
                         try:
                             packed_q.put(e, timeout=5)
@@ -517,6 +564,14 @@ class SlabStream:
         if cancel:
             self._cancel.set()
         self._join()
+        bufs_q = getattr(self, "_pack_bufs", None)
+        if bufs_q is not None:  # the host buffers of the sparse upload go back to the process-wide pool
+            self._pack_bufs = None
+            while True:
+                try:
+                    _pack_pool_give(bufs_q.get_nowait())
+                except Exception:
+                    break
         if self.dm is not None:
             # kernels of the consumer's stream may still read the slab: the caching allocator must not hand the
             # blocks (allocated on the creator's stream) to anyone before those kernels have run
@@ -806,8 +861,10 @@ class _PinnedRing:
 
 
 def release_pinned_buffers():
-    """Free the pinned staging rings of the device -> host copies (128 MB per GPU used so far, kept between calls)."""
+    """Free the pinned staging rings of the device -> host copies (128 MB per GPU used so far, kept between calls) and the
+    host buffers of the sparse upload."""
     _PinnedRing.release_all()
+    del _PACK_POOL[:]
 
 
 class CsrDrain:

@@ -673,6 +673,9 @@ def infercnv(
             ss = streams.pop(k)
             ss.close()
             t_h2d[0] += ss.h2d_seconds
+            if getattr(ss, "pack_stats", None):
+                for kk, vv in ss.pack_stats.items():
+                    s.tm["pack_" + kk] = vv if kk == "threads" else s.tm.get("pack_" + kk, 0.0) + vv
 
         def slab_stream(i):
             """Start (or return) the upload of slab i; the previous slab is released first (one slab resident)."""
