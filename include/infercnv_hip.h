@@ -432,6 +432,14 @@ int icv_host_dense_row_nnz(const void *h_x, int32_t dtype, int64_t n_rows, int64
                            int64_t *h_row_nnz, int32_t n_threads);
 int icv_host_dense_pack(const void *h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
                         const int64_t *h_indptr, int32_t *h_indices, void *h_values, int32_t n_threads);
+/* The same in ONE pass over the input (what tl.infercnv uses: the host memory system is the bottleneck of the upload):
+ * threads claim blocks of 16 rows in order, pack into their own staging area, take their place in the output through a
+ * ticket handed on in block order and copy the block there; h_indptr (n_rows + 1) is written as well, *h_nnz = the
+ * number of stored entries.  `capacity` = entries h_indices / h_values hold: ICV_ERR_NOMEM if the matrix has more
+ * (h_indptr and *h_nnz are complete then; the entry arrays are not: call again with larger buffers). */
+int icv_host_dense_pack_fused(const void *h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                              int64_t *h_indptr, int32_t *h_indices, void *h_values, int64_t capacity,
+                              int32_t n_threads, int64_t *h_nnz);
 int icv_csr_scatter_dense(const void *data, int32_t dtype, const int64_t *indptr, const int32_t *indices, int64_t n_rows,
                           int32_t n_cols, void *out, int64_t ldo, void *stream);
 

@@ -298,11 +298,12 @@ class SmoothResult:
 
 
 def _default_pack_threads():
-    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the logical CPUs, at most 64."""
+    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the logical CPUs (= the physical cores
+    of an SMT-2 box), at most 128."""
     env = os.environ.get("ICV_PACK_THREADS")
     if env:
         return max(1, int(env))
-    return int(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    return int(max(1, min(128, (os.cpu_count() or 2) // 2)))
 
 
 # Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as
@@ -336,7 +337,17 @@ def _pack_pool_give(bufs):
             _PACK_POOL.append(bufs)
 
 
-def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3, probe_rows=256):
+def _probe_density(X, np_dtype, row0, row1, probe_rows=256):
+    """Stored entries per element in the first ``probe_rows`` rows of X[row0:row1] (a C-ordered float matrix)."""
+    n = min(probe_rows, row1 - row0)
+    xs = X[row0:row0 + n]
+    cnt = np.zeros(n, dtype=np.int64)
+    _lib.check(_lib.load().icv_host_dense_row_nnz(xs.ctypes.data, _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64,
+                                                  n, X.shape[1], X.strides[0] // X.itemsize, cnt.ctypes.data, 1))
+    return float(cnt.sum()) / float(max(1, n * X.shape[1]))
+
+
+def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3):
     """Dense host rows go up as stored entries when they are mostly zeros: a C-ordered float matrix of the compute
     dtype, at least 1024 columns, fewer than ``max_density`` non-zeros in a probe of the first rows.
     ``ICV_NO_SPARSE_UPLOAD`` switches it off (A/B timing)."""
@@ -346,12 +357,7 @@ def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3, probe_rows=25
         return False
     if X.strides[1] != X.itemsize or X.strides[0] < X.shape[1] * X.itemsize or X.strides[0] % X.itemsize:
         return False
-    n = min(probe_rows, row1 - row0)
-    xs = X[row0:row0 + n]
-    cnt = np.zeros(n, dtype=np.int64)
-    _lib.check(_lib.load().icv_host_dense_row_nnz(xs.ctypes.data, _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64,
-                                                  n, X.shape[1], X.strides[0] // X.itemsize, cnt.ctypes.data, 1))
-    return float(cnt.sum()) < max_density * n * X.shape[1]
+    return _probe_density(X, np_dtype, row0, row1) < max_density
 
 
 class SlabStream:
@@ -367,7 +373,7 @@ class SlabStream:
         """Rows [row0, row1) of the host matrix ``X`` (the parent's arrays are read in place: slicing a scipy CSR
         matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded).
         ``host_pack_threads``: host threads of the sparse upload of a mostly-zero dense matrix (default: half the
-        logical CPUs, at most 48; callers with several shards divide them)."""
+        logical CPUs, at most 128; callers with several shards divide them)."""
         import queue
         import threading
 
@@ -434,8 +440,9 @@ class SlabStream:
                 for _ in range(3):                 # (through the process-wide pool) between calls
                     free_q.put(_pack_pool_take(np_dtype))
                 self._pack_bufs = free_q
-                self.pack_stats = {"count_s": 0.0, "pack_s": 0.0, "wait_buffer_s": 0.0, "wait_link_s": 0.0, "threads": n_thr}
+                self.pack_stats = {"pack_s": 0.0, "wait_buffer_s": 0.0, "wait_link_s": 0.0, "threads": n_thr}
                 stats = self.pack_stats
+                dens = [max(_probe_density(X, np_dtype, row0, row1), 1e-4)]  # stored entries per element (estimate)
 
                 def pack_all():
                     try:
@@ -443,12 +450,7 @@ class SlabStream:
                             if self._cancel.is_set():
                                 break
                             xs = X[row0 + r0:row0 + r1]
-                            ip = np.zeros(r1 - r0 + 1, dtype=np.int64)
-                            t0 = _time.perf_counter()
-                            _lib.check(lib.icv_host_dense_row_nnz(xs.ctypes.data, code, r1 - r0, n_cols, ld,
-                                                                  ip[1:].ctypes.data, n_thr))
-                            np.cumsum(ip, out=ip)
-                            nnz = int(ip[-1])
+                            ip = np.empty(r1 - r0 + 1, dtype=np.int64)
                             t1 = _time.perf_counter()
                             bufs = None
                             while bufs is None:  # (a copier that has failed or been cancelled returns nothing)
@@ -457,12 +459,24 @@ class SlabStream:
                                 except queue.Empty:
                                     if self._cancel.is_set() or self._err is not None:
                                         return
-                            if bufs[0].shape[0] < nnz:
-                                cap = int(nnz * 1.15) + 1024
-                                bufs[0], bufs[1] = np.empty(cap, np.int32), np.empty(cap, np_dtype)
+                            want = int(dens[0] * 1.25 * (r1 - r0) * n_cols) + 4096
+                            if bufs[0].shape[0] < want:
+                                bufs[0], bufs[1] = np.empty(want, np.int32), np.empty(want, np_dtype)
                             t2 = _time.perf_counter()
-                            _lib.check(lib.icv_host_dense_pack(xs.ctypes.data, code, r1 - r0, n_cols, ld, ip.ctypes.data,
-                                                               bufs[0].ctypes.data, bufs[1].ctypes.data, n_thr))
+                            # one pass over the piece (icv_host_dense_pack_fused); more entries than the buffers hold
+                            # (the probe under-estimated the density): grow them and pack again
+                            nnz_c = C.c_int64(0)
+                            for _ in range(2):
+                                rc = lib.icv_host_dense_pack_fused(xs.ctypes.data, code, r1 - r0, n_cols, ld, ip.ctypes.data,
+                                                                   bufs[0].ctypes.data, bufs[1].ctypes.data,
+                                                                   bufs[0].shape[0], n_thr, C.byref(nnz_c))
+                                if rc != _lib.ICV_ERR_NOMEM or nnz_c.value <= bufs[0].shape[0]:
+                                    break
+                                cap = int(nnz_c.value * 1.1) + 4096
+                                bufs[0], bufs[1] = np.empty(cap, np.int32), np.empty(cap, np_dtype)
+                                dens[0] = max(dens[0], nnz_c.value / float(max(1, (r1 - r0) * n_cols)))
+                            _lib.check(rc)
+                            nnz = int(nnz_c.value)
                             t3 = _time.perf_counter()
                             while True:
                                 try:
@@ -471,7 +485,6 @@ class SlabStream:
                                 except queue.Full:
                                     if self._cancel.is_set() or self._err is not None:
                                         return
-                            stats["count_s"] += t1 - t0
                             stats["wait_buffer_s"] += t2 - t1
                             stats["pack_s"] += t3 - t2
                             stats["wait_link_s"] += _time.perf_counter() - t3

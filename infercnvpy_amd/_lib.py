@@ -32,7 +32,7 @@ EXPORTS = (
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_pack_geometry", "icv_threshold_pack", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
     "icv_ward_create", "icv_ward_destroy", "icv_ward_merge", "icv_ward_gather", "icv_ward_scatter", "icv_ward_scan", "icv_ward_pack_nn",
-    "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_group_sums", "icv_csr_check", "icv_csr_densify", "icv_host_dense_row_nnz", "icv_host_dense_pack", "icv_csr_scatter_dense", "icv_last_error", "icv_version",
+    "icv_ward_unpack_nn", "icv_ward_pairs", "icv_ward_round_pairs", "icv_ward_finish", "icv_row_abs_sum", "icv_csr_row_abs_sum", "icv_group_sums", "icv_csr_check", "icv_csr_densify", "icv_host_dense_row_nnz", "icv_host_dense_pack", "icv_host_dense_pack_fused", "icv_csr_scatter_dense", "icv_last_error", "icv_version",
     "icv_device_count", "icv_developer_knobs_reload",
 )
 
@@ -139,6 +139,7 @@ def load():
     lib.icv_csr_densify.argtypes = [vp, i32, vp, vp, vp, i64, i32, vp, i64, vp]
     lib.icv_host_dense_row_nnz.argtypes = [vp, i32, i64, i64, i64, vp, i32]
     lib.icv_host_dense_pack.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp, i32]
+    lib.icv_host_dense_pack_fused.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp, i64, i32, vp]
     lib.icv_csr_scatter_dense.argtypes = [vp, i32, vp, vp, i64, i32, vp, i64, vp]
     lib.icv_developer_knobs_reload.restype = None
     lib.icv_developer_knobs_reload.argtypes = []

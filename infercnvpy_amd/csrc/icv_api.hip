@@ -2458,6 +2458,47 @@ void host_pack_rows_avx512_f64(const double* x, int64_t r0, int64_t r1, int64_t 
         host_pack_tail<double, uint64_t>(xr, j, n_cols, k, end, indices, values);
     }
 }
+// one row into a staging area with 16 slots of slack behind the row's worst case: no bound to respect, returns the count
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+int64_t host_pack_row_avx512_f32(const float* xr, int64_t n_cols, int32_t* indices, float* values) {
+    const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    int64_t k = 0, j = 0;
+    for (; j + 16 <= n_cols; j += 16) {
+        const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+        const __mmask16 m = _mm512_test_epi32_mask(v, v);
+        _mm512_storeu_si512((void*)(values + k), _mm512_maskz_compress_epi32(m, v));
+        _mm512_storeu_si512((void*)(indices + k),
+                            _mm512_maskz_compress_epi32(m, _mm512_add_epi32(iota, _mm512_set1_epi32((int)j))));
+        k += _mm_popcnt_u32((unsigned)m);
+    }
+    const uint32_t* b = reinterpret_cast<const uint32_t*>(xr);
+    for (; j < n_cols; ++j) {
+        indices[k] = (int32_t)j;
+        values[k] = xr[j];
+        k += b[j] != 0;
+    }
+    return k;
+}
+__attribute__((target("avx512f,avx512vl,avx512bw,popcnt")))
+int64_t host_pack_row_avx512_f64(const double* xr, int64_t n_cols, int32_t* indices, double* values) {
+    const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    int64_t k = 0, j = 0;
+    for (; j + 8 <= n_cols; j += 8) {
+        const __m512i v = _mm512_loadu_si512((const void*)(xr + j));
+        const __mmask8 m = _mm512_test_epi64_mask(v, v);
+        _mm512_storeu_si512((void*)(values + k), _mm512_maskz_compress_epi64(m, v));
+        _mm256_storeu_si256((__m256i*)(indices + k),
+                            _mm256_maskz_compress_epi32(m, _mm256_add_epi32(iota, _mm256_set1_epi32((int)j))));
+        k += _mm_popcnt_u32((unsigned)m);
+    }
+    const uint64_t* b = reinterpret_cast<const uint64_t*>(xr);
+    for (; j < n_cols; ++j) {
+        indices[k] = (int32_t)j;
+        values[k] = xr[j];
+        k += b[j] != 0;
+    }
+    return k;
+}
 bool host_has_avx512() {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
                            __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("popcnt") &&
@@ -2467,6 +2508,90 @@ bool host_has_avx512() {
 #else
 bool host_has_avx512() { return false; }
 #endif
+template <typename T, typename B>
+int64_t host_pack_row_scalar(const T* xr, int64_t n_cols, int32_t* indices, T* values) {
+    const B* b = reinterpret_cast<const B*>(xr);
+    int64_t k = 0;
+    for (int64_t j = 0; j < n_cols; ++j) {
+        indices[k] = (int32_t)j;
+        values[k] = xr[j];
+        k += b[j] != 0;
+    }
+    return k;
+}
+
+// ONE pass over the input: threads claim blocks of kFusedRows rows in order, pack a block into their own staging area
+// (cache resident at log-count densities), take the block's place in the output through a ticket that is handed on in
+// block order (a running entry count), and copy the block there.  The input is read once; the two-pass form (count,
+// prefix sums, pack) reads it twice, and the host memory system is what the upload of a 16 GB matrix waits for.
+constexpr int64_t kFusedRows = 16;
+template <typename T, typename B>
+int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t* indptr, int32_t* indices, T* values,
+                    int64_t capacity, int n_threads, int64_t* total_out) {
+    const int64_t n_blocks = (n_rows + kFusedRows - 1) / kFusedRows;
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n_blocks) n_threads = (int)(n_blocks > 0 ? n_blocks : 1);
+    std::atomic<int64_t> next_claim{0}, next_commit{0};
+    int64_t total = 0;  // written by the ticket holder only
+    std::atomic<bool> overflow{false};
+    const bool vec = host_has_avx512();
+    indptr[0] = 0;
+    auto worker = [&]() {
+        const size_t cap = (size_t)kFusedRows * (size_t)n_cols + 32;
+        std::unique_ptr<int32_t[]> s_idx(new int32_t[cap]);
+        std::unique_ptr<T[]> s_val(new T[cap]);
+        int64_t cnt[kFusedRows];
+        for (;;) {
+            const int64_t k = next_claim.fetch_add(1, std::memory_order_relaxed);
+            if (k >= n_blocks) return;
+            const int64_t r0 = k * kFusedRows, r1 = r0 + kFusedRows < n_rows ? r0 + kFusedRows : n_rows;
+            int64_t n = 0;
+            for (int64_t r = r0; r < r1; ++r) {
+                const T* xr = x + r * ld;
+                int64_t c;
+#if defined(__x86_64__)
+                if (vec) {
+                    if constexpr (sizeof(T) == 4) c = host_pack_row_avx512_f32((const float*)xr, n_cols, s_idx.get() + n, (float*)s_val.get() + n);
+                    else c = host_pack_row_avx512_f64((const double*)xr, n_cols, s_idx.get() + n, (double*)s_val.get() + n);
+                } else
+#endif
+                    c = host_pack_row_scalar<T, B>(xr, n_cols, s_idx.get() + n, s_val.get() + n);
+                cnt[r - r0] = c;
+                n += c;
+            }
+            while (next_commit.load(std::memory_order_acquire) != k) {
+#if defined(__x86_64__)
+                _mm_pause();
+#endif
+            }
+            const int64_t off = total;
+            total = off + n;
+            int64_t run = off;
+            for (int64_t r = r0; r < r1; ++r) {
+                run += cnt[r - r0];
+                indptr[r + 1] = run;
+            }
+            const bool fits = off + n <= capacity;
+            if (!fits) overflow.store(true, std::memory_order_relaxed);
+            next_commit.store(k + 1, std::memory_order_release);
+            if (fits && n) {
+                std::memcpy(indices + off, s_idx.get(), (size_t)n * sizeof(int32_t));
+                std::memcpy(values + off, s_val.get(), (size_t)n * sizeof(T));
+            }
+        }
+    };
+    if (n_threads == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        pool.reserve(n_threads);
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    *total_out = total;
+    return overflow.load() ? 1 : 0;
+}
+
 template <typename F>
 void host_parallel_rows(int64_t n_rows, int n_threads, F&& fn) {
     if (n_threads < 1) n_threads = 1;
@@ -2541,6 +2666,29 @@ int icv_host_dense_pack(const void* h_x, int32_t dtype, int64_t n_rows, int64_t 
             });
     } catch (const std::exception& e) {
         return fail(ICV_ERR_NOMEM, std::string("host_dense_pack: ") + e.what());
+    }
+    return ICV_OK;
+}
+
+int icv_host_dense_pack_fused(const void* h_x, int32_t dtype, int64_t n_rows, int64_t n_cols, int64_t ld,
+                              int64_t* h_indptr, int32_t* h_indices, void* h_values, int64_t capacity,
+                              int32_t n_threads, int64_t* h_nnz) {
+    if (!h_x || !h_indptr || !h_nnz || n_rows < 0 || n_cols < 0 || ld < n_cols || capacity < 0 ||
+        (capacity > 0 && (!h_indices || !h_values)) || (dtype != ICV_F32 && dtype != ICV_F64))
+        return fail(ICV_ERR_INVALID, "bad host_dense_pack_fused arguments");
+    try {
+        int over;
+        if (dtype == ICV_F32)
+            over = host_pack_fused<float, uint32_t>((const float*)h_x, n_rows, n_cols, ld, h_indptr, h_indices,
+                                                    (float*)h_values, capacity, n_threads, h_nnz);
+        else
+            over = host_pack_fused<double, uint64_t>((const double*)h_x, n_rows, n_cols, ld, h_indptr, h_indices,
+                                                     (double*)h_values, capacity, n_threads, h_nnz);
+        if (over)
+            return fail(ICV_ERR_NOMEM, "host_dense_pack_fused: the matrix holds more stored entries than `capacity` "
+                                       "(*h_nnz has the count: call again with larger buffers)");
+    } catch (const std::exception& e) {
+        return fail(ICV_ERR_NOMEM, std::string("host_dense_pack_fused: ") + e.what());
     }
     return ICV_OK;
 }

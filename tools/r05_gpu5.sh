@@ -1,0 +1,29 @@
+#!/bin/bash
+set -u
+REPO=$PWD
+O=$REPO/gpurun_out/r05e; mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_sparse_upload.py tests/test_gpu_parity.py -q -k "sparse or multi_slab or sweep or shards_on_one" 2>&1 | tail -4 | tee $O/pytest.txt
+for thr in 32 64 128; do
+  ICV_PACK_THREADS=$thr timeout 600 python - > $O/e2e_pack_$thr.txt 2>&1 <<PY
+import sys, time, json
+sys.path.insert(0, "."); sys.path.insert(0, "tests/golden")
+import numpy as np, pandas as pd, torch
+import bench, cases
+import infercnvpy_amd as cnv
+X = bench.synth_rows(torch, 0, 200000, 20000).cpu().numpy()
+torch.cuda.empty_cache()
+v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+ref = np.asarray(X[:2000].mean(axis=0), dtype=np.float64).astype(np.float32)
+for rep in range(4):
+    tm = {}
+    t0 = time.perf_counter()
+    kw = dict(reference=ref) if rep < 3 else dict()
+    cnv.tl.infercnv(cnv.SimpleAnnData(X, var=var), devices=[0], _timings=tm, **kw)
+    dt = time.perf_counter() - t0
+    print(rep, round(dt, 4), round(200000 / dt), {k: (round(x, 4) if isinstance(x, float) else x) for k, x in tm.items() if k.startswith("pack_") or k in ("h2d", "stream_and_kernels", "sparse_upload", "reference_pass")})
+PY
+  tail -4 $O/e2e_pack_$thr.txt
+done
+echo done
