@@ -297,13 +297,38 @@ class SmoothResult:
         self.profile = profile
 
 
+def _usable_cpus():
+    """Logical CPUs this process may really use: the affinity mask, capped by a cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def _default_pack_threads():
-    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the logical CPUs (= the physical cores
-    of an SMT-2 box), at most 128."""
+    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the usable logical CPUs, at most 32 --
+    measured on the 2 x 64-core box of the GPU pool (tools/bench_host_pack.py, profiles/r05_host_pack.txt): 124 GB/s of
+    input with 8 threads, 162 with 16, 173 with 32, and a collapse beyond (46 GB/s with 64, 20 with 128: the threads
+    wait on each other's memory traffic and on the block tickets)."""
     env = os.environ.get("ICV_PACK_THREADS")
     if env:
         return max(1, int(env))
-    return int(max(1, min(128, (os.cpu_count() or 2) // 2)))
+    return int(max(1, min(32, _usable_cpus() // 2)))
 
 
 # Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as
@@ -373,7 +398,7 @@ class SlabStream:
         """Rows [row0, row1) of the host matrix ``X`` (the parent's arrays are read in place: slicing a scipy CSR
         matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded).
         ``host_pack_threads``: host threads of the sparse upload of a mostly-zero dense matrix (default: half the
-        logical CPUs, at most 128; callers with several shards divide them)."""
+        usable logical CPUs, at most 32; callers with several shards divide them)."""
         import queue
         import threading
 

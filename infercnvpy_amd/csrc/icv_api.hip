@@ -2525,6 +2525,45 @@ int64_t host_pack_row_scalar(const T* xr, int64_t n_cols, int32_t* indices, T* v
 // block order (a running entry count), and copy the block there.  The input is read once; the two-pass form (count,
 // prefix sums, pack) reads it twice, and the host memory system is what the upload of a 16 GB matrix waits for.
 constexpr int64_t kFusedRows = 16;
+
+// Staging areas of the packing threads, kept between calls: 128 threads that each map (and fault in) 2.5 MB per call
+// serialise on the process's address-space lock -- the first version of the one-pass form was slower with 128 threads
+// (0.6 - 1.7 s per 16 GB) than with 32 (0.23 - 0.35 s).
+struct HostStagePool {
+    std::mutex mu;
+    std::vector<std::pair<unsigned char*, size_t>> idle;
+    size_t idle_bytes = 0;
+    unsigned char* take(size_t bytes, size_t* got) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].second >= bytes) {
+                    unsigned char* p = idle[i].first;
+                    *got = idle[i].second;
+                    idle_bytes -= idle[i].second;
+                    idle[i] = idle.back();
+                    idle.pop_back();
+                    return p;
+                }
+        }
+        *got = bytes;
+        return static_cast<unsigned char*>(std::malloc(bytes));
+    }
+    void give(unsigned char* p, size_t bytes) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle_bytes + bytes <= (size_t)1 << 30 && idle.size() < 512) {
+                idle.emplace_back(p, bytes);
+                idle_bytes += bytes;
+                return;
+            }
+        }
+        std::free(p);
+    }
+};
+HostStagePool g_stage_pool;
+
 template <typename T, typename B>
 int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int64_t* indptr, int32_t* indices, T* values,
                     int64_t capacity, int n_threads, int64_t* total_out) {
@@ -2533,36 +2572,55 @@ int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int6
     if ((int64_t)n_threads > n_blocks) n_threads = (int)(n_blocks > 0 ? n_blocks : 1);
     std::atomic<int64_t> next_claim{0}, next_commit{0};
     int64_t total = 0;  // written by the ticket holder only
-    std::atomic<bool> overflow{false};
+    std::atomic<bool> overflow{false}, failed{false};
     const bool vec = host_has_avx512();
     indptr[0] = 0;
     auto worker = [&]() {
         const size_t cap = (size_t)kFusedRows * (size_t)n_cols + 32;
-        std::unique_ptr<int32_t[]> s_idx(new int32_t[cap]);
-        std::unique_ptr<T[]> s_val(new T[cap]);
+        size_t got = 0;
+        unsigned char* raw = g_stage_pool.take(cap * (sizeof(int32_t) + sizeof(T)) + 64, &got);
+        if (!raw) {
+            overflow.store(true);  // (reported as out of memory by the caller; the tickets below must still be passed on)
+            failed.store(true);
+        }
+        struct Give {
+            unsigned char* p;
+            size_t n;
+            ~Give() { g_stage_pool.give(p, n); }
+        } give_back{raw, got};
+        T* s_val_p = reinterpret_cast<T*>(raw);  // (values first: 8-byte aligned)
+        int32_t* s_idx_p = reinterpret_cast<int32_t*>(raw + cap * sizeof(T));
         int64_t cnt[kFusedRows];
         for (;;) {
             const int64_t k = next_claim.fetch_add(1, std::memory_order_relaxed);
             if (k >= n_blocks) return;
             const int64_t r0 = k * kFusedRows, r1 = r0 + kFusedRows < n_rows ? r0 + kFusedRows : n_rows;
             int64_t n = 0;
-            for (int64_t r = r0; r < r1; ++r) {
+            for (int64_t r = r0; r < r1 && raw; ++r) {
                 const T* xr = x + r * ld;
                 int64_t c;
 #if defined(__x86_64__)
                 if (vec) {
-                    if constexpr (sizeof(T) == 4) c = host_pack_row_avx512_f32((const float*)xr, n_cols, s_idx.get() + n, (float*)s_val.get() + n);
-                    else c = host_pack_row_avx512_f64((const double*)xr, n_cols, s_idx.get() + n, (double*)s_val.get() + n);
+                    if constexpr (sizeof(T) == 4) c = host_pack_row_avx512_f32((const float*)xr, n_cols, s_idx_p + n, (float*)s_val_p + n);
+                    else c = host_pack_row_avx512_f64((const double*)xr, n_cols, s_idx_p + n, (double*)s_val_p + n);
                 } else
 #endif
-                    c = host_pack_row_scalar<T, B>(xr, n_cols, s_idx.get() + n, s_val.get() + n);
+                    c = host_pack_row_scalar<T, B>(xr, n_cols, s_idx_p + n, s_val_p + n);
                 cnt[r - r0] = c;
                 n += c;
             }
-            while (next_commit.load(std::memory_order_acquire) != k) {
+            if (!raw)
+                for (int64_t r = r0; r < r1; ++r) cnt[r - r0] = 0;
+            // the ticket: blocks take their place in block order (a few loads, then the thread steps aside -- 128
+            // threads spinning on one cache line slow down the one that has to write it)
+            for (int spins = 0; next_commit.load(std::memory_order_acquire) != k; ++spins) {
+                if (spins < 64) {
 #if defined(__x86_64__)
-                _mm_pause();
+                    _mm_pause();
 #endif
+                } else {
+                    std::this_thread::yield();
+                }
             }
             const int64_t off = total;
             total = off + n;
@@ -2575,8 +2633,8 @@ int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int6
             if (!fits) overflow.store(true, std::memory_order_relaxed);
             next_commit.store(k + 1, std::memory_order_release);
             if (fits && n) {
-                std::memcpy(indices + off, s_idx.get(), (size_t)n * sizeof(int32_t));
-                std::memcpy(values + off, s_val.get(), (size_t)n * sizeof(T));
+                std::memcpy(indices + off, s_idx_p, (size_t)n * sizeof(int32_t));
+                std::memcpy(values + off, s_val_p, (size_t)n * sizeof(T));
             }
         }
     };
@@ -2589,6 +2647,7 @@ int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int6
         for (auto& th : pool) th.join();
     }
     *total_out = total;
+    if (failed.load()) throw std::bad_alloc();
     return overflow.load() ? 1 : 0;
 }
 

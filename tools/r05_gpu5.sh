@@ -4,7 +4,7 @@ REPO=$PWD
 O=$REPO/gpurun_out/r05e; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_sparse_upload.py tests/test_gpu_parity.py -q -k "sparse or multi_slab or sweep or shards_on_one" 2>&1 | tail -4 | tee $O/pytest.txt
-for thr in 32 64 128; do
+for thr in 16 32; do
   ICV_PACK_THREADS=$thr timeout 600 python - > $O/e2e_pack_$thr.txt 2>&1 <<PY
 import sys, time, json
 sys.path.insert(0, "."); sys.path.insert(0, "tests/golden")
