@@ -228,6 +228,15 @@ def cpu_baseline(window=100, step=10, cells_per_worker=400, reps=2, slice_cells=
                   f"(mean chunk {sum(busy3) / len(busy3):.1f} s, slowest {max(busy3):.1f} s), pool wall {wall3:.1f} s "
                   f"incl. start-up and building the chunks",
     }
+    try:
+        from infercnvpy_amd._engine import _usable_cpus
+
+        usable = _usable_cpus()
+    except Exception:
+        usable = logical
+    out["usable_cpus"] = usable
+    out["usable_cpus_note"] = (f"logical CPUs {logical}, physical cores {physical}; the process may use {usable} CPUs of "
+                               f"time (affinity mask / cgroup quota): pools with more workers than that share them")
     rate_l, n_l, busy_l, wall_l = _cpu_pool_rate(logical, window, step, cells_per_worker, reps)
     out["oversubscribed"] = {
         "value": rate_l, "unit": "cells/s", "cores": logical, "kind": "port",

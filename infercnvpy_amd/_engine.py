@@ -321,14 +321,14 @@ def _usable_cpus():
 
 
 def _default_pack_threads():
-    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): half the usable logical CPUs, at most 32 --
-    measured on the 2 x 64-core box of the GPU pool (tools/bench_host_pack.py, profiles/r05_host_pack.txt): 124 GB/s of
-    input with 8 threads, 162 with 16, 173 with 32, and a collapse beyond (46 GB/s with 64, 20 with 128: the threads
-    wait on each other's memory traffic and on the block tickets)."""
+    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): the usable logical CPUs (affinity mask and
+    cgroup quota), at most 32.  Measured on the GPU pool's box (2 x 64 cores, but a cgroup quota of 16 CPUs:
+    tools/bench_host_pack.py, profiles/r05_host_pack.txt): 124 GB/s of input with 8 threads, 162 with 16, 173 with 32,
+    then a collapse (46 GB/s with 64, 20 with 128: the threads are throttled and wait on each other's block tickets)."""
     env = os.environ.get("ICV_PACK_THREADS")
     if env:
         return max(1, int(env))
-    return int(max(1, min(32, _usable_cpus() // 2)))
+    return int(max(1, min(32, _usable_cpus())))
 
 
 # Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as
@@ -397,8 +397,8 @@ class SlabStream:
     def __init__(self, X, tdtype, piece_rows, row0=0, row1=None, host_pack_threads=None):
         """Rows [row0, row1) of the host matrix ``X`` (the parent's arrays are read in place: slicing a scipy CSR
         matrix would copy the shard -- 5.6 GB at BASELINE config 4 -- before the first byte is uploaded).
-        ``host_pack_threads``: host threads of the sparse upload of a mostly-zero dense matrix (default: half the
-        usable logical CPUs, at most 32; callers with several shards divide them)."""
+        ``host_pack_threads``: host threads of the sparse upload of a mostly-zero dense matrix (default: the usable
+        logical CPUs, at most 32; callers with several shards divide them)."""
         import queue
         import threading
 
