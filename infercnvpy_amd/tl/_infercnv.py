@@ -15,6 +15,7 @@ row order (``vstack``, :137).
 from __future__ import annotations
 
 import logging
+import os
 import sys
 import threading
 import time as _time
@@ -657,7 +658,8 @@ def infercnv(
         n_rows = s.g1 - s.g0
         # pieces of a slab: a few chunks each (~2 GB of input), copied by a helper thread while earlier ones compute
         per_row = per_row_bytes(plan)
-        piece_rows = max(chunksize, int(2e9 // max(per_row, 1)) // chunksize * chunksize)
+        piece_bytes = float(os.environ.get("ICV_PIECE_BYTES", 2e9))  # (developer knob: pipeline granularity)
+        piece_rows = max(chunksize, int(piece_bytes // max(per_row, 1)) // chunksize * chunksize)
         # row slabs (multiples of chunksize) sized to fit this shard's share of the GPU's free HBM, next to the packed
         # results of the pieces on their way back (worst case 12 bytes per window, three pieces at a time)
         free_b, _ = torch.cuda.mem_get_info()

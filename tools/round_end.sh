@@ -2,10 +2,10 @@
 # Evidence run on the GPU box (one gpurun call): tests, smoke, the default bench line (stages, e2e, extra legs), rocprofv3
 # kernel statistics of the bench step / config 4 / CSR window 100 / config 5, PMC passes (FETCH_SIZE and WRITE_SIZE in
 # separate runs, --kernel-trace only; instruction mix), the N-rank dry run on one GPU.
-#   ROUND=r04 tools/round_end.sh [quick]      -> gpurun_out/${ROUND}final/   (copy what is to be judged into profiles/)
+#   ROUND=r05 tools/round_end.sh [quick]      -> gpurun_out/${ROUND}final/   (copy what is to be judged into profiles/)
 set -u
 REPO=$PWD
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 O=$REPO/gpurun_out/${ROUND}final; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import torch; print(torch.cuda.get_device_name(0), torch.cuda.device_count())" > $O/box.txt 2>&1
@@ -41,4 +41,18 @@ pmc() {  # label, bench.py arguments...
 pmc dense_w100_100000_cells --steps 2 --warmup 1 $BASE
 pmc csr_w250_500000_cells --format csr --cells 500000 --window 250 --steps 2 --warmup 1 $BASE
 pmc csr_w100_200000_cells --format csr --cells 200000 --window 100 --steps 2 --warmup 1 $BASE
+# round 5: k_smooth_se at three densities, the host-side packing of the sparse upload, fuzzers and the soak on the final tree
+for d in 0.02 0.07 0.14; do
+  timeout 300 python bench.py --format csr --cells 500000 --window 250 --density $d --steps 10 --warmup 2 $BASE 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('density $d', 'ms/step', round(d['ms_per_step'],3), 'k_smooth_se ms', round(d['roofline']['kernel_ms'],3), 'frac', round(d['roofline']['frac'],3), 'stages', {k:round(v,3) for k,v in d['stages']['kernel_ms'].items()})" | tee -a $O/csr_density_lines.txt
+done
+timeout 300 python tools/bench_host_pack.py 50000 > $O/host_pack.txt 2>&1; tail -8 $O/host_pack.txt
+if [ "${1:-}" != "quick" ]; then
+  (echo "== tests/fuzz_gpu.py 11000 600"; timeout 900 python tests/fuzz_gpu.py 11000 600 2>&1 | tail -2
+   echo "== tests/fuzz_gpu_big.py 600 120"; timeout 600 python tests/fuzz_gpu_big.py 600 120 2>&1 | tail -2
+   echo "== tests/fuzz_gpu_ward.py 100 40"; timeout 300 python tests/fuzz_gpu_ward.py 100 40 2>&1 | tail -2) | tee $O/fuzz_gpu.txt
+  timeout 600 python tests/soak_gpu.py 200 2>&1 | tail -6 | tee $O/soak_public_api.txt
+fi
 find $O -name "*.db" -delete 2>/dev/null
