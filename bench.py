@@ -19,7 +19,7 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
   N > 1   one process per GPU over the rows of config 3 (dist.run_shard per rank).  TWO forms of the reference means
           are timed back to back, K steps each: `value` = the reference's own evaluation order (icv_colchain
-          accumulators handed from rank to rank, pipelined over 4 column groups, means broadcast:
+          accumulators handed from rank to rank, pipelined over 2 column groups, means broadcast:
           dist.reference_means_chained -- the same computation as the N = 1 public call, X_cnv bit-identical for any
           N); `value_allreduce_means` = float64 column sums + ONE RCCL all-reduce of [G + 1] float64 (concurrent,
           correctly rounded means: tl.infercnv(mean_order="float64")).  Both -> the same smoothing kernel -> per-chunk
@@ -846,7 +846,7 @@ def main():
                            "CSR float64 (reference-order means, smoothing, noise threshold + CSR pack)"
                            if stages is not None else
                            "; step = reference-order column means (icv_colchain accumulators handed from rank to "
-                           "rank, pipelined over 4 column groups: numpy's own bits, the computation of the N = 1 "
+                           "rank, pipelined over 2 column groups: numpy's own bits, the computation of the N = 1 "
                            "public call) + smoothing + thresholds "
                            + ("applied while X_cnv is packed to device CSR (dist.run_shard(pack=True))" if not args.engine_step
                               else "applied in place (dist.run_shard)")),
@@ -860,7 +860,7 @@ def main():
                            f"{dist.get_world_size() if dist is not None else 1}, backend "
                            f"{('gloo, ALL RANKS ON cuda:0 (dry run)' if dry else 'nccl/RCCL') if dist is not None else 'none'}), "
                            + ("row shards aligned to the chunks; value: the [G] float32 chain accumulators travel rank to "
-                              "rank point to point in 4 column groups + one broadcast of the means; value_allreduce_means: "
+                              "rank point to point in 2 column groups + one broadcast of the means; value_allreduce_means: "
                               "one all-reduce of the [G+1] float64 reference sums per step; no other collective"
                               if n_gpus > 1 else "one GPU, no collective"),
         },

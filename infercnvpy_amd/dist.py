@@ -141,7 +141,7 @@ def chain_column_groups(n_cols: int, esz: int, n_groups: int):
     return out
 
 
-def reference_means_chained(dm_local, counts_global, local_rows=None, group=None, n_col_groups=4):
+def reference_means_chained(dm_local, counts_global, local_rows=None, group=None, n_col_groups=2):
     """The reference profile in the REFERENCE'S OWN evaluation order over row-sharded ranks (bit-equal to
     ``np.mean(X, axis=0)`` / scipy's CSR mean of the whole matrix, reference :385, :400): a float32 column sum is a
     sequential chain, so rank k continues the accumulators of rank k - 1 (``icv_colchain``) and hands them to rank
@@ -149,9 +149,11 @@ def reference_means_chained(dm_local, counts_global, local_rows=None, group=None
 
     The chains of different columns are independent, so the hand-over is PIPELINED over ``n_col_groups`` column groups
     (dense matrices): rank k starts group g as soon as rank k - 1 has handed that group over, while rank k - 1 works on
-    group g + 1.  With T groups and R ranks the pass costs (T + R - 1) group passes instead of R x T: (T + R - 1) / T
-    times one rank's pass (T = 1: the ranks simply take turns).  CSR shards are handed over whole (the column tiles of
-    ``k_colchain_csr`` share one bounds pass).  The float64 :func:`reference_means` is the concurrent alternative:
+    group g + 1.  With T groups and R ranks the pass costs (T + R - 1) group passes instead of R whole passes (T = 1: the
+    ranks simply take turns).  T = 2 is the default: a group of half the columns still fills every CU with a tile, so its
+    pass takes half the time of a whole pass; narrower groups do not get faster (one 128-byte line per workgroup is the
+    narrowest tile: 0.84 / 0.69 / 0.69 ms for T = 2 / 4 / 8 on 125 000 x 20 000 float32, profiles/r05_chain_column_groups.txt).
+    CSR shards are handed over whole (the column tiles of ``k_colchain_csrq`` share one bounds pass).  The float64 :func:`reference_means` is the concurrent alternative:
     correctly rounded, one all-reduce, but not the reference's bits.
 
     ``dm_local``: this rank's rows (``_engine.DeviceMatrix``); ``counts_global``: rows per category over ALL ranks;
