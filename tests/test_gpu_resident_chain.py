@@ -298,3 +298,25 @@ def test_concurrent_resident_calls_each_get_a_plan():
     assert len(T._PLAN_CACHE) == 2
     T._clear_plan_cache()
     assert not T._PLAN_CACHE
+
+
+def test_a_real_anndata_gets_host_objects():
+    """anndata validates what goes into obsm / layers and takes neither a PackedCsr nor a device tensor:
+    handed a container of the anndata package, tl.infercnv writes the reference's host objects."""
+    import torch
+
+    import infercnvpy_amd as cnv
+
+    class AnnData(cnv.SimpleAnnData):  # stands in for anndata.AnnData (the package is not installed here)
+        pass
+
+    AnnData.__module__ = "anndata._core.anndata"
+    X, obs, var = _inputs(n=900)
+    ad = AnnData(torch.from_numpy(X).cuda(), obs=obs, var=var)
+    cnv.tl.infercnv(ad, chunksize=300, calculate_gene_values=True)
+    assert sp.issparse(ad.obsm["X_cnv"]) and ad.obsm["X_cnv"].dtype == np.float64
+    assert isinstance(ad.layers["gene_values_cnv"], np.ndarray)
+    ref = cnv.SimpleAnnData(X, obs=obs, var=var)
+    cnv.tl.infercnv(ref, chunksize=300, calculate_gene_values=True)
+    np.testing.assert_array_equal(ad.obsm["X_cnv"].toarray(), ref.obsm["X_cnv"].toarray())
+    np.testing.assert_array_equal(ad.layers["gene_values_cnv"], ref.layers["gene_values_cnv"])
