@@ -545,8 +545,9 @@ def infercnv(
     X_csc = X if (sp.issparse(X) and X.format == "csc") else None  # scipy reduces CSC columns in another order
     # a dense matrix stored column-major (np.asfortranarray, the transposed view of a genes x cells array): numpy puts the
     # axis with the smaller stride innermost and reduces every column pairwise instead of as one chain (:385)
-    X_fortran = X if (isinstance(X, np.ndarray) and X.ndim == 2 and X.shape[0] > 1 and X.shape[1] > 1
-                      and abs(X.strides[0]) < abs(X.strides[1])) else None
+    # (a single-column matrix is a 1-D contiguous reduction for numpy: the same pairwise order)
+    X_fortran = X if (isinstance(X, np.ndarray) and X.ndim == 2 and X.shape[0] > 1 and
+                      (abs(X.strides[0]) < abs(X.strides[1]) or X.shape[1] == 1)) else None
     if sp.issparse(X) and X.format not in ("csr", "csc") and reference is None and mean_order == "reference":
         log.warning(f"tl.infercnv: a {X.format.upper()} matrix is converted to CSR; scipy's own summation order for this "
                     "format is not reproduced, so the reference means (and entries of X_cnv next to the noise "

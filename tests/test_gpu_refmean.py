@@ -177,6 +177,8 @@ def test_column_major_dense_mean_is_numpys_pairwise_order(n, dtype):
     exp = np.mean(X, axis=0)
     assert got.dtype == exp.dtype
     np.testing.assert_array_equal(got, exp)
+    one = np.ascontiguousarray(X[:, :1])  # a single column: numpy reduces it as a 1-D contiguous array -- pairwise too
+    np.testing.assert_array_equal(_engine.fortran_column_means(one), np.mean(one, axis=0))
     if n >= 129:  # the two layouts really are different sums
         Xs = np.asfortranarray(X[::2])  # and a row-sliced view keeps the layout rule (smaller stride innermost)
         np.testing.assert_array_equal(_engine.fortran_column_means(X[::2]), np.mean(X[::2], axis=0))
