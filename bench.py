@@ -483,7 +483,7 @@ def _roof(bytes_, ms, extra=None):
     return r
 
 
-def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, iters=10):
+def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, iters=10, mean_traffic=None):
     """The kernels of the public call one by one (engine-level calls as tl.infercnv makes them, events on the launch
     stream): reference-order means, smoothing + chunk thresholds, threshold + CSR pack; each with its roofline.
     Two untimed iterations first (the second one finds the caching allocator warm: every iteration frees its result
@@ -517,7 +517,10 @@ def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, it
         "kernel_ms": med, "kernel_ms_min": {k: min(v) for k, v in ms.items()}, "iterations": iters,
         "sum_ms": sum(med.values()), "x_cnv_nnz": nnz,
         "roofline_k_colchain": _roof(in_bytes, med["k_colchain"], {
-            "note": "one pass over the matrix; CSR: + k_csr_tile_bounds (column indices once more, 2 B per tile and row)"}),
+            "traffic": (sum(t for t in (pmc_traffic(k, n_local) for k in mean_traffic) if t) or None) if mean_traffic else None,
+            "note": "one pass over the matrix; CSR: + k_csr_tile_bounds16 (column indices once more, 2 B per tile and "
+                    "row); traffic: HBM bytes of the stage's kernels from the committed PMC passes (profiles/"
+                    "pmc_traffic.json), scaled to the cells of this launch"}),
         "roofline_smooth_and_thresholds": _roof(
             ((4 * G if not is_csr else 8 * nnz_row + 8) + 4 * W) * n_local, med["smooth_and_thresholds"],
             {"note": "the smoothing kernel + the per-chunk threshold kernel; algorithmic bytes as the main roofline"}),
@@ -596,7 +599,8 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), window, 10, ("chrX", "chrY"),
                               torch.cuda.current_device())
         dm = T._resident_matrix(ad.X, torch)
-        st = stage_times(torch, _engine, plan, dm, cells, CHUNK, fmt, nnz_row=nnz_row, iters=10)
+        mt = ("colchain_dense",) if fmt == "dense" else (("colchain_csrq", "csr_tile_bounds16") if traffic_key else None)
+        st = stage_times(torch, _engine, plan, dm, cells, CHUNK, fmt, nnz_row=nnz_row, iters=10, mean_traffic=mt)
         return {"workload": label + "; one cnv.tl.infercnv(adata) call per step on the resident matrix, "
                                     "reference = all-cell mean (in the step), X_cnv as device CSR",
                 "ms_per_step": dt / steps * 1e3, "cells_per_s": cells / (dt / steps), "steps": steps,
@@ -778,7 +782,9 @@ def main():
                                      nnz_row=nnz_row, traffic_key=traffic_key, **kw)
         api_plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), args.window, args.step,
                                   ("chrX", "chrY"), torch.cuda.current_device())
-        stages = stage_times(torch, _engine, api_plan, dm, n_local, args.chunksize, args.format, nnz_row=nnz_row)
+        mt = ("colchain_dense",) if args.format == "dense" else (("colchain_csrq", "csr_tile_bounds16") if traffic_key else None)
+        stages = stage_times(torch, _engine, api_plan, dm, n_local, args.chunksize, args.format, nnz_row=nnz_row,
+                             mean_traffic=mt)
         stages["x_cnv_nnz_public_call"] = nnz_out
         ad = None
     else:
