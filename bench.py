@@ -534,7 +534,7 @@ def stage_times(torch, _engine, plan, dm, n_local, chunksize, fmt, nnz_row=G, it
 
 def config5_leg(torch, _engine, n=None, d=5000, clusters=30):
     if n is None:  # BASELINE config 5 is 200 000 x 5 000: 240 GB of distances with the Ward rounds' spare columns
-        free_b, _ = torch.cuda.mem_get_info()
+        free_b = _engine.free_hbm_bytes()
         n = 200_000 if free_b >= 250e9 else 100_000
     gen = torch.Generator(device="cuda").manual_seed(n)
     centres = torch.randn((clusters, d), device="cuda", generator=gen) * 0.3

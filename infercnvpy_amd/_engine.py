@@ -280,6 +280,16 @@ def fortran_column_means(X, np_dtype=None, max_bytes=1 << 30):
     return out
 
 
+def free_hbm_bytes():
+    """HBM this process can still allocate on the current device: what the driver reports free PLUS the blocks PyTorch's
+    caching allocator holds without using them (it hands those out again, or gives them back before it reports out of
+    memory) -- after a previous large call the driver's figure alone makes the next call cut its matrix into needless
+    slabs (a 1 M-cell matrix was uploaded twice for the reference pass and the smoothing)."""
+    torch = _torch()
+    free_b, _ = torch.cuda.mem_get_info()
+    return int(free_b) + max(0, int(torch.cuda.memory_reserved()) - int(torch.cuda.memory_allocated()))
+
+
 def alloc_out(rows, n_windows):
     """Device float32 ``rows x n_windows`` result buffer whose rows start on 16-byte boundaries (row stride padded
     to a multiple of 4): the smoothing kernel then writes x_res with 16-byte stores."""
@@ -1235,7 +1245,7 @@ def pairwise_sqeuclidean(x, out=None, rows=None, spare=False):
     if out is None:
         ld = (n + 3) // 4 * 4  # a multiple of 16 bytes: vector loads in the Ward rounds
         if rows is None and spare:
-            free_b, _ = torch.cuda.mem_get_info()
+            free_b = free_hbm_bytes()
             if 4 * n * spare_stride(n) + 4 * n * (x.shape[1] + 16) + (1 << 30) < free_b:
                 ld = spare_stride(n)
         out = torch.empty((r1 - r0, ld), dtype=torch.float32, device=x.device)[:, :n]

@@ -328,7 +328,7 @@ def _infercnv_resident(var, obs, dm, *, reference_key, reference_cat, reference,
             else:
                 ref_lo, ref_hi = ref.min(dim=0).values.contiguous(), ref.max(dim=0).values.contiguous()
             # pieces of whole chunks whose result buffers (4 + 12 bytes per window, worst case) fit next to the matrix
-            free_b, _ = torch.cuda.mem_get_info()
+            free_b = _engine.free_hbm_bytes()
             per_row = 16 * plan.n_windows + 64 + (8 * (n_vars + plan.n_windows) if calculate_gene_values else 0)
             if calculate_gene_values:
                 free_b = max(free_b - 8 * n_vars * n_obs, free_b // 8)  # the float64 gene matrix of ALL rows stays
@@ -663,7 +663,7 @@ def infercnv(
         piece_rows = max(chunksize, int(piece_bytes // max(per_row, 1)) // chunksize * chunksize)
         # row slabs (multiples of chunksize) sized to fit this shard's share of the GPU's free HBM, next to the packed
         # results of the pieces on their way back (worst case 12 bytes per window, three pieces at a time)
-        free_b, _ = torch.cuda.mem_get_info()
+        free_b = _engine.free_hbm_bytes()
         packed = 3 * min(piece_rows, max(n_rows, 1)) * plan.n_windows * 12
         slab_rows = int(max(0.45 * free_b / s.share - packed, 0) // per_row)
         slab_rows = max(chunksize, slab_rows // chunksize * chunksize)

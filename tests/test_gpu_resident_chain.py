@@ -167,10 +167,10 @@ def test_gene_values_on_a_resident_matrix_that_needs_several_pieces(monkeypatch)
     ref = X[:300].mean(axis=0)
     Xd = torch.from_numpy(X).cuda()
     pos_1, res_1, gv_1 = cnv.tl.infercnv_device(Xd, var, chunksize=300, reference=ref, calculate_gene_values=True)
-    real = torch.cuda.mem_get_info
+    from infercnvpy_amd import _engine
+
     per_row = 16 * 1400 + 64 + 8 * (X.shape[1] + 1400)
-    monkeypatch.setattr(torch.cuda, "mem_get_info",
-                        lambda *a: (int(8 * X.shape[1] * 2300 + 700 * per_row / 0.4), real(*a)[1]))
+    monkeypatch.setattr(_engine, "free_hbm_bytes", lambda: int(8 * X.shape[1] * 2300 + 700 * per_row / 0.4))
     tm = {}
     pos_k, res_k, gv_k = cnv.tl.infercnv_device(Xd, var, chunksize=300, reference=ref, calculate_gene_values=True,
                                                 _timings=tm)
