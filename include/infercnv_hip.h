@@ -59,7 +59,10 @@ typedef struct {
     int64_t n_rows;         /* cells                                                   */
     int32_t n_cols;         /* genes = n_cols_all of the plan                          */
     int32_t _pad;           /* dense: column offset of `values` inside its row when the matrix is a column view of a
-                               wider one (0 otherwise); only icv_colchain looks at it (which loads stay in bounds)  */
+                               wider one (0 otherwise); only icv_colchain looks at it (which loads stay in bounds).
+                               csr: optional hint, the number of stored entries MOST rows stay under (e.g. the 99.9 %
+                               quantile of the row lengths; 0 = unknown): the stored-entries kernel sizes its per-cell
+                               entry slots with it -- a performance hint only, any value gives the same results      */
     int64_t ld;             /* dense: row stride in elements (>= _pad + n_cols)        */
     const void *values;     /* dense: n_rows x ld row-major; csr: nnz values           */
     const int64_t *indptr;  /* csr: n_rows + 1                                         */

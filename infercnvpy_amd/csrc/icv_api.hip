@@ -55,7 +55,7 @@ int fail(int code, const std::string& msg) {
 // getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
-    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues;
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues, se_maxw4;
     int wgs_per_cu;        // 0 = not set
     int chain_far;         // ICV_CHAIN_FAR: entries a buffer offset may span in k_colchain_csrq (tests: a small value)
     double ward_compact_x; // 0 = not set
@@ -68,6 +68,7 @@ struct Knobs {
         no_mask_ring = std::getenv("ICV_NO_MASK_RING") != nullptr;
         no_fill_ring = std::getenv("ICV_NO_FILL_RING") != nullptr;
         no_chain_queues = std::getenv("ICV_NO_CHAIN_QUEUES") != nullptr;
+        se_maxw4 = std::getenv("ICV_SE_MAXW4") != nullptr;
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_CHAIN_FAR");
@@ -539,7 +540,8 @@ bool stored_entries_kernel(const icv_plan_t pl, const icv_matrix* m, const icv::
 }
 
 // k_smooth_se (icv_kernel_se.hpp): CSR float32 input in block form, stored entries only
-int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t kernel_done = nullptr) {
+int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t kernel_done = nullptr,
+                     int64_t csr_entries = 0, int row_len_hint = 0) {
     const icv::Plan& p = pl->p;
     int k0 = 0, k1 = 0;
     if (!se_fraction_bits(p, K.cap, &k0, &k1)) return fail(ICV_ERR_INVALID, "k_smooth_se does not apply");
@@ -573,8 +575,33 @@ int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t k
         return ICV_OK;
     }
     void (*kern)(const icv::KParams);
-    if (K.chunk_part) kern = K.bounded ? icv::k_smooth_se<4, true, true> : icv::k_smooth_se<4, true, false>;
-    else kern = K.bounded ? icv::k_smooth_se<4, false, true> : icv::k_smooth_se<4, false, false>;
+    // window registers per thread: 3 where the windows fit (<= 1 536: window 250 / step 10 at 20 000 genes has 1 472), else
+    // 4; entry slots per thread from the mean row length: PF x 512 slots should hold mean + 4 sigma (binomial) entries --
+    // longer rows take the in-phase loop, any PF gives the same bits
+    const bool w3 = p.W <= 3 * icv::NT && !knobs().se_maxw4;
+    int pf = 4;
+    if (K.chunk_part && !knobs().se_maxw4 && K.n_rows > 0) {
+        double want = 0.0;
+        if (row_len_hint > 0) {
+            want = (double)row_len_hint;  // the caller's figure: the length most rows stay under (icv_matrix._pad)
+        } else if (csr_entries > 0) {     // none: mean + 3.5 sigma of a binomial row length
+            const double mean = (double)csr_entries / (double)K.n_rows;
+            const double dens = mean / (double)(K.n_cols > 0 ? K.n_cols : 1);
+            want = mean + 3.5 * std::sqrt(mean * (dens < 1.0 ? 1.0 - dens : 0.0)) + 8.0;
+        }
+        if (want > 0.0) pf = want <= icv::NT ? 1 : want <= 2 * icv::NT ? 2 : want <= 3 * icv::NT ? 3 : 4;
+    }
+#define ICV_SE_PICK(MW, CH, BD)                                                                              \
+    (pf == 1 ? icv::k_smooth_se<MW, CH, BD, 1> : pf == 2 ? icv::k_smooth_se<MW, CH, BD, 2>                   \
+     : pf == 3 ? icv::k_smooth_se<MW, CH, BD, 3> : icv::k_smooth_se<MW, CH, BD, 4>)
+    if (K.chunk_part) {
+        if (w3) kern = K.bounded ? ICV_SE_PICK(3, true, true) : ICV_SE_PICK(3, true, false);
+        else kern = K.bounded ? ICV_SE_PICK(4, true, true) : ICV_SE_PICK(4, true, false);
+    } else {
+        if (w3) kern = K.bounded ? icv::k_smooth_se<3, false, true> : icv::k_smooth_se<3, false, false>;
+        else kern = K.bounded ? icv::k_smooth_se<4, false, true> : icv::k_smooth_se<4, false, false>;
+    }
+#undef ICV_SE_PICK
     int rc = run_kernel(kern, grid, icv::kSeLds, K, st);
     if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
     if (rc) return rc;
@@ -795,7 +822,7 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
     if (fast_allowed && m->format == ICV_CSR && m->csr_end > m->csr_begin) {
         if (stored_entries_kernel(pl, m, K, lay)) {
             if (recorded) *recorded = kernel_done != nullptr;
-            return launch_smooth_se(pl, K, st, kernel_done);
+            return launch_smooth_se(pl, K, st, kernel_done, m->csr_end - m->csr_begin, m->_pad > 0 ? m->_pad : 0);
         }
         if (pl->p.ws_ok && aligned16(K.ref_lo)) {
             const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);

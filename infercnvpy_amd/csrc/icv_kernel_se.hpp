@@ -73,8 +73,9 @@ __device__ __forceinline__ double wave_scan_f64(double v) {
 constexpr int kWsPlane = kSePlane;
 constexpr int kSdPlaneBytes = 16 * 8 * kWsPlane;
 
-constexpr int kSePF = 4;  // stored entries prefetched per thread (rows with <= 2048 entries; longer rows fetch the
-                          // rest inside phase 1)
+// PF (template parameter, 1 .. 4): stored entries prefetched per thread = PF x 512 per cell; longer rows fetch the rest
+// inside phase 1.  The launcher picks it from the mean row length (+ 4 sigma of a binomial): every slot costs ~22 VALU
+// instructions per thread and cell whether it holds an entry or not, so sparser matrices run fewer of them.
 constexpr int kSeCoarse = NBIN / 64, kSeRep = 4;     // coarse histogram: 64 bins x 4 replicas (lane & 3)
 // LDS map: scratch (the wavefront totals first: offset 0) | coarse histogram | planes | fine histogram.  Everything but
 // the fine histogram lies below 64 KB, so that its base travels in the offset field of the LDS instruction
@@ -150,8 +151,10 @@ typedef __attribute__((address_space(3))) unsigned lds_u32_t;
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(OFF)), (V), __ATOMIC_RELAXED, \
                            __HIP_MEMORY_SCOPE_WORKGROUP)
 
-template <int MAXW, bool CHUNK, bool BOUNDED>
+template <int MAXW, bool CHUNK, bool BOUNDED, int PF = 4>
 __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
+    constexpr int kSePF = PF;
+    static_assert(PF >= 1 && PF <= 4, "entry slots per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double2* SP = reinterpret_cast<double2*>(smem + kSePlanesOff);
     unsigned* hist = reinterpret_cast<unsigned*>(smem + kSeHistOff);      // two 16-bit bins per word

@@ -1191,3 +1191,38 @@ def test_gene_sets_larger_than_lds_split_by_chromosome_group(dtype, genes_per_ch
     np.testing.assert_allclose(got, exp, rtol=0, atol=ATOL_TIGHT)
     if gvals:
         np.testing.assert_allclose(gv, e_gv, rtol=0, atol=1e-9, equal_nan=True)
+
+
+def test_stored_entries_kernel_gives_the_same_bits_for_any_slot_count():
+    """k_smooth_se prefetches PF x 512 stored entries per cell (template parameter, picked from the row-length hint of
+    icv_matrix._pad); rows with more take the in-phase loop.  Every choice -- also a hint far too small -- gives the same
+    x_res, medians and thresholds bit for bit (and W <= 1536 runs the three-window-register instantiation, > 1536 the
+    four-register one)."""
+    import torch
+
+    from infercnvpy_amd import _engine, _lib
+    from infercnvpy_amd._plan import GenePlan
+
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K)
+    rs = np.random.RandomState(4)
+    n = 700
+    X = rs.gamma(0.3, 1.0, (n, 20000)).astype(np.float32)
+    X[rs.rand(n, 20000) >= 0.07] = 0
+    X[3, :] = rs.gamma(0.3, 1.0, 20000)       # a row with 20 000 stored entries
+    X[5, 9000:] = 0                             # a short one
+    ref = torch.from_numpy(X.mean(axis=0)).cuda()
+    for window in (250, 100):                   # 1 472 windows (MAXW = 3) / 1 802 (MAXW = 4)
+        plan = GenePlan(v["chromosome"], v["start"], window_size=window, step=10)
+        outs = []
+        for hint in (None, 1, 600, 1100, 1600, 30000):
+            dm = _engine.to_device_matrix(sp.csr_matrix(X))
+            if hint is not None:
+                dm._row_len_hint = hint
+            res = _engine.run_hot_path(plan, dm, ref, chunksize=200, cell_stats=True)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == _lib.ICV_KERNEL_SD
+            outs.append((res.out.cpu().numpy(), res.cell_median.cpu().numpy(), res.thr.cpu().numpy()))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                np.testing.assert_array_equal(a, b)
+        plan.close()
