@@ -405,7 +405,9 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                     const unsigned long long m =
                         *reinterpret_cast<const unsigned long long*>(reinterpret_cast<unsigned char*>(cm) + c8[v][j]);
                     const unsigned rank = (unsigned)__popcll(m & below);
-                    unsigned a = base_off + rank * (unsigned)row_bytes + c8[v][j] / (8u / (unsigned)sizeof(T));
+                    // (24-bit multiply: rank < 64, row_bytes <= 512 -- a full-rate v_mad_u32_u24 where the plain product
+                    // became a quarter-rate 64-bit mad)
+                    unsigned a = base_off + __umul24(rank, (unsigned)row_bytes) + c8[v][j] / (8u / (unsigned)sizeof(T));
                     a = j < b_nv[v] ? a : trash_off;
                     *reinterpret_cast<T*>(smem + a) = b_val[v][j] * scale;
                 }
