@@ -233,12 +233,31 @@ int icv_profile_begin(icv_plan_t plan);
 int icv_profile_collect(icv_plan_t plan, icv_profile *out, int32_t max_records, int32_t *n_records);
 
 /* ---- calculate_gene_values=True (reference :247-298, :443-453) -------------------------------
- * Per-gene CNV values: mean of the kept windows that contain the gene, minus the per-cell median
- * over the covered genes, zeroed below the chunk's noise threshold (`thr` from
+ * Per-gene CNV values: mean of the kept windows that contain the gene (:274-288), minus the per-cell median
+ * over the covered genes (:443-444), zeroed below the chunk's noise threshold (:452-453; `thr` from
  * icv_chunk_thresholds / icv_infercnv_run; NULL = no thresholding).  `gene_out` (device, float64,
  * n_rows x ldg, ldg >= n_cols) is written completely: NaN for genes no kept window covers and for
- * masked genes (reference: reindex with NaN fill, :147).  Uses the generic smoothing kernel and
- * stream-ordered temporary buffers (8*(W + n_covered) bytes per row). */
+ * masked genes (reference: reindex with NaN fill, :147).
+ *
+ * The windows a gene averages are the float64 windows of step 3 BEFORE the per-cell centring -- what the
+ * smoothing kernel holds anyway.  icv_infercnv_run_windows is icv_infercnv_run that also writes them
+ * (`win_out`: device float64, n_rows x ldw, ldw >= n_windows; NULL = plain icv_infercnv_run): the same kernel
+ * as the plain call (k_smooth_x16 / k_smooth_se store them beside x_res; other geometries: the generic kernel),
+ * 8 * n_windows more bytes per cell.  icv_gene_values_from_windows turns them into the gene layer in ONE kernel:
+ * windows -> LDS, one value per run of genes that share their windows, weighted median by radix select, the
+ * row written once in input-column order.  So `calculate_gene_values=True` costs the plain call + the windows +
+ * one pass that writes 8 * n_cols bytes per cell -- no second smoothing (reference: _infercnv_chunk returns both
+ * from one pass too, :438-457).
+ *
+ * icv_gene_values (kept): smoothing + gene layer in one call for callers that do not need X_cnv;
+ * stream-ordered temporaries of 12 * n_windows bytes per row. */
+int icv_infercnv_run_windows(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
+                             double lfc_clip, double dynamic_threshold, int64_t chunksize, int64_t row_phase,
+                             int32_t flags, float *out, int64_t ldo, double *cell_median, double *cell_stats,
+                             double *thr, icv_profile *h_profile, double *win_out, int64_t ldw, void *stream);
+int icv_gene_values_from_windows(icv_plan_t plan, const double *win, int64_t ldw, int64_t n_rows,
+                                 const double *thr, int64_t chunksize, int64_t row_phase, double *gene_out,
+                                 int64_t ldg, void *stream);
 int icv_gene_values(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, const void *ref_hi,
                     double lfc_clip, int32_t flags, const double *thr, int64_t chunksize,
                     int64_t row_phase, double *gene_out, int64_t ldg, void *stream);

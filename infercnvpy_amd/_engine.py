@@ -314,6 +314,8 @@ def alloc_out(rows, n_windows):
 
 
 class SmoothResult:
+    windows = None  # float64 windows before centring (run_hot_path(windows=True))
+
     def __init__(self, out, cell_median, cell_stats, thr, profile):
         self.out = out                  # device float32 C x W (thresholded x_res)
         self.cell_median = cell_median  # device float64 C
@@ -1108,12 +1110,14 @@ class CsrDrain:
 
 def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, dynamic_threshold=1.5,
                  chunksize=5000, row_phase=0, flags=0, out=None, profile=False, row0=0, row1=None,
-                 cell_stats=False, apply=True):
+                 cell_stats=False, apply=True, windows=False):
     """Steps 1-5 of the chunk kernel for rows [row0, row1) of ``dm`` (all device-resident).
 
     ``cell_stats=True`` also returns the per-cell moments (sum, sum of squares of x_res); without them the
     library forms the noise-threshold moments per chunk inside the smoothing kernel (faster).
-    ``apply=False`` computes the thresholds but leaves ``out`` un-thresholded (for :func:`threshold_mask`)."""
+    ``apply=False`` computes the thresholds but leaves ``out`` un-thresholded (for :func:`threshold_mask`).
+    ``windows=True``: the float64 windows before the per-cell centring come back as well (``res.windows``, rows x W:
+    what ``calculate_gene_values`` averages, :func:`gene_values_from_windows`) -- written by the same kernel launch."""
     torch = _torch()
     lib = _lib.load()
     n = dm.shape[0]
@@ -1135,12 +1139,15 @@ def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_c
         assert ref_hi.dtype == dm.dtype and ref_hi.is_cuda and ref_hi.numel() == dm.shape[1]
     m = dm.c_struct(row0, row1)
     prof = _lib.Profile() if profile else None
-    _lib.check(lib.icv_infercnv_run(
+    win = torch.empty((rows, W), dtype=torch.float64, device="cuda") if windows else None
+    _lib.check(lib.icv_infercnv_run_windows(
         plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), dyn, int(chunksize), int(row_phase),
         int(flags) | (0 if apply else _lib.ICV_FLAG_NO_APPLY), _ptr(out), out.stride(0), _ptr(med), _ptr(stats),
         _ptr(thr),
-        C.byref(prof) if prof is not None else None, _stream_ptr(torch)))
-    return SmoothResult(out, med, stats, thr, prof)
+        C.byref(prof) if prof is not None else None, _ptr(win), W, _stream_ptr(torch)))
+    res = SmoothResult(out, med, stats, thr, prof)
+    res.windows = win
+    return res
 
 
 def row_abs_sum(x_cnv):
@@ -1205,6 +1212,23 @@ def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_cl
     _lib.check(lib.icv_gene_values(
         plan.handle, C.byref(m), _ptr(ref_lo), _ptr(ref_hi), float(lfc_clip), int(flags), _ptr(thr), int(chunksize),
         int(row_phase), _ptr(out), out.stride(0), _stream_ptr(torch)))
+    return out
+
+
+def gene_values_from_windows(plan: GenePlan, windows, *, thr=None, chunksize=5000, row_phase=0, n_vars=None, out=None):
+    """calculate_gene_values from the float64 windows of :func:`run_hot_path` (``windows=True``): float64
+    ``rows x n_vars`` device tensor (``out``: written in place, completely), NaN where a gene has no value.  ONE kernel
+    (``icv_gene_values_from_windows``); ``thr``: the thresholds of the chunks of those rows."""
+    torch = _torch()
+    lib = _lib.load()
+    rows = windows.shape[0]
+    assert windows.dtype == torch.float64 and windows.is_cuda and (windows.stride(1) == 1 or windows.shape[1] <= 1)
+    if out is None:
+        out = torch.empty((rows, int(n_vars)), dtype=torch.float64, device="cuda")
+    assert out.dtype == torch.float64 and out.shape[0] == rows and (out.stride(1) == 1 or out.shape[1] <= 1)
+    _lib.check(lib.icv_gene_values_from_windows(
+        plan.handle, _ptr(windows), windows.stride(0), rows, _ptr(thr), int(chunksize), int(row_phase), _ptr(out),
+        out.stride(0), _stream_ptr(torch)))
     return out
 
 

@@ -28,6 +28,7 @@
 #include "icv_kernel_chainq.hpp"
 #include "icv_kernel_pack.hpp"
 #include "icv_kernel_util.hpp"
+#include "icv_kernel_gene.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -55,7 +56,8 @@ int fail(int code, const std::string& msg) {
 // getenv per dispatch, and a production call's route must not follow an environment edited under it); a test that
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
-    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues, se_maxw4;
+    bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues, se_maxw4,
+         no_gene_fused;
     int wgs_per_cu;        // 0 = not set
     int chain_far;         // ICV_CHAIN_FAR: entries a buffer offset may span in k_colchain_csrq (tests: a small value)
     double ward_compact_x; // 0 = not set
@@ -69,6 +71,7 @@ struct Knobs {
         no_fill_ring = std::getenv("ICV_NO_FILL_RING") != nullptr;
         no_chain_queues = std::getenv("ICV_NO_CHAIN_QUEUES") != nullptr;
         se_maxw4 = std::getenv("ICV_SE_MAXW4") != nullptr;
+        no_gene_fused = std::getenv("ICV_NO_GENE_FUSED") != nullptr;  // gene values through the three round-1 kernels
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_CHAIN_FAR");
@@ -103,6 +106,7 @@ struct icv_plan_s {
     int32_t* d_wpack = nullptr;
     unsigned* d_tie_n = nullptr;  // k_thr_mask_ring's tie counter + k_thr_mask_ties' done counter (zero between calls)
     int32_t *d_cov_col = nullptr, *d_cov_j0 = nullptr, *d_cov_cnt = nullptr;
+    int32_t *d_gv_j0 = nullptr, *d_gv_cnt = nullptr, *d_gv_mult = nullptr, *d_gv_col_run = nullptr;  // k_gene_fused
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
@@ -260,6 +264,10 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.cov_col.data(), p.cov_col.size() * 4, (void**)&pl->d_cov_col));
     HIP_TRY(up(p.cov_j0.data(), p.cov_j0.size() * 4, (void**)&pl->d_cov_j0));
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
+    HIP_TRY(up(p.gv_run_j0.data(), p.gv_run_j0.size() * 4, (void**)&pl->d_gv_j0));
+    HIP_TRY(up(p.gv_run_cnt.data(), p.gv_run_cnt.size() * 4, (void**)&pl->d_gv_cnt));
+    HIP_TRY(up(p.gv_run_mult.data(), p.gv_run_mult.size() * 4, (void**)&pl->d_gv_mult));
+    HIP_TRY(up(p.gv_col_run.data(), p.gv_col_run.size() * 4, (void**)&pl->d_gv_col_run));
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
     HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
@@ -594,7 +602,13 @@ int launch_smooth_se(icv_plan_t pl, icv::KParams K, hipStream_t st, hipEvent_t k
 #define ICV_SE_PICK(MW, CH, BD)                                                                              \
     (pf == 1 ? icv::k_smooth_se<MW, CH, BD, 1> : pf == 2 ? icv::k_smooth_se<MW, CH, BD, 2>                   \
      : pf == 3 ? icv::k_smooth_se<MW, CH, BD, 3> : icv::k_smooth_se<MW, CH, BD, 4>)
-    if (K.chunk_part) {
+    if (K.win_out) {
+        // calculate_gene_values: the float64 windows leave the kernel as well (four entry slots per thread whatever
+        // the row length: any slot count gives the same bits, and this path is bound by the cells x genes output)
+        if (!K.chunk_part) return fail(ICV_ERR_INVALID, "k_smooth_se with windows needs the chunk-moment mode");
+        if (w3) kern = K.bounded ? icv::k_smooth_se<3, true, true, 4, true> : icv::k_smooth_se<3, true, false, 4, true>;
+        else kern = K.bounded ? icv::k_smooth_se<4, true, true, 4, true> : icv::k_smooth_se<4, true, false, 4, true>;
+    } else if (K.chunk_part) {
         if (w3) kern = K.bounded ? ICV_SE_PICK(3, true, true) : ICV_SE_PICK(3, true, false);
         else kern = K.bounded ? ICV_SE_PICK(4, true, true) : ICV_SE_PICK(4, true, false);
     } else {
@@ -673,10 +687,17 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         if (p.step != 10)
             xk = nullptr;  // the instantiations below assume step 10 (blocks between adjacent windows)
         else if (p.B == 10 && p.window == 100 && p.x16_fine == 4096)
-            xk = K.chunk_part ? icv::k_smooth_x16<10, 10, 1, true, 4096, true> : icv::k_smooth_x16<10, 10, 1, false, 4096, true>;
+            xk = K.win_out ? icv::k_smooth_x16<10, 10, 1, true, 4096, true, true>
+                           : (K.chunk_part ? icv::k_smooth_x16<10, 10, 1, true, 4096, true>
+                                           : icv::k_smooth_x16<10, 10, 1, false, 4096, true>);
         else if (p.B == 5 && p.window == 250 && p.x16_fine == 1024)
-            xk = K.chunk_part ? icv::k_smooth_x16<5, 50, 2, true, 1024, false> : icv::k_smooth_x16<5, 50, 2, false, 1024, false>;
+            xk = K.win_out ? icv::k_smooth_x16<5, 50, 2, true, 1024, false, true>
+                           : (K.chunk_part ? icv::k_smooth_x16<5, 50, 2, true, 1024, false>
+                                           : icv::k_smooth_x16<5, 50, 2, false, 1024, false>);
     }
+    // float64 windows requested (calculate_gene_values): only the x16 instantiations write them, in chunk-moment mode;
+    // every other geometry takes the generic kernel (ONE smoothing pass either way)
+    if (K.win_out && (!xk || !K.chunk_part)) return -1;
     if (xk) {
         icv::KParams X = K;
         X.win_off = p.x16_s01_off;
@@ -791,10 +812,15 @@ int smooth_split(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, hipS
     if (n < 1) return ICV_OK;
     const int W = pl->p.W;
     AsyncBuf win_b, med_b;
-    HIP_TRY(win_b.alloc((size_t)n * W * sizeof(double), st));
+    // (a caller that wants the float64 windows -- calculate_gene_values -- with a contiguous buffer gets them here)
+    const bool own = !(K.win_out && K.win_ld == W);
+    if (own) HIP_TRY(win_b.alloc((size_t)n * W * sizeof(double), st));
     HIP_TRY(med_b.alloc((size_t)n * sizeof(double), st));
-    double *win = win_b.as<double>(), *med = med_b.as<double>();
+    double *win = own ? win_b.as<double>() : K.win_out, *med = med_b.as<double>();
     int rc = split_windows(pl, m, K, win, st);
+    if (!rc && own && K.win_out)
+        HIP_TRY(hipMemcpy2DAsync(K.win_out, (size_t)K.win_ld * sizeof(double), win, (size_t)W * sizeof(double),
+                                 (size_t)W * sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, st));
     if (!rc) {
         hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, win, n, W, med);
         hipLaunchKernelGGL(icv::k_win_finish, dim3((unsigned)n), dim3(256), 0, st, win, n, W, med, K.out, K.ldo,
@@ -811,6 +837,7 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
         pl->last_kernel = ICV_KERNEL_SPLIT;
         return smooth_split(pl, m, K, st);
     }
+    const bool want_win = K.win_out != nullptr;
     const bool fast_allowed = m->dtype == ICV_F32 && std::isfinite(K.cap) && !knobs().force_generic;
     if (fast_allowed && m->format == ICV_DENSE && pl->p.ws_ok && K.vec_ok) {
         const int rc = launch_smooth_fast(pl, K, st, false, 0, 0, kernel_done);
@@ -820,11 +847,11 @@ int launch_smooth(icv_plan_t pl, const icv_matrix* m, const icv::KParams& K, con
         }
     }
     if (fast_allowed && m->format == ICV_CSR && m->csr_end > m->csr_begin) {
-        if (stored_entries_kernel(pl, m, K, lay)) {
+        if (stored_entries_kernel(pl, m, K, lay) && (!want_win || K.chunk_part)) {
             if (recorded) *recorded = kernel_done != nullptr;
             return launch_smooth_se(pl, K, st, kernel_done, m->csr_end - m->csr_begin, m->_pad > 0 ? m->_pad : 0);
         }
-        if (pl->p.ws_ok && aligned16(K.ref_lo)) {
+        if (pl->p.ws_ok && aligned16(K.ref_lo) && !want_win) {
             const int rc = launch_smooth_fast(pl, K, st, true, m->csr_begin, m->csr_end, kernel_done);
             if (rc >= 0) {
                 if (recorded) *recorded = kernel_done != nullptr;
@@ -1025,6 +1052,10 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_cov_col);
         (void)hipFree(pl->d_cov_j0);
         (void)hipFree(pl->d_cov_cnt);
+        (void)hipFree(pl->d_gv_j0);
+        (void)hipFree(pl->d_gv_cnt);
+        (void)hipFree(pl->d_gv_mult);
+        (void)hipFree(pl->d_gv_col_run);
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_cell_part);
@@ -1272,24 +1303,24 @@ int icv_apply_threshold(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, 
     return launch_apply(m, K, thr, chunksize, row_phase, static_cast<hipStream_t>(stream));
 }
 
-int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
-                     double dynamic_threshold, int64_t chunksize, int64_t row_phase, int32_t flags, float* out,
-                     int64_t ldo, double* cell_median, double* cell_stats, double* thr, icv_profile* prof,
-                     void* stream) {
-    int rc = check_matrix(pl, m);
-    if (rc) return rc;
-    PLAN_BUSY_GUARD(pl);
+}  // extern "C"
+
+namespace {
+// steps 1-5 of the chunk kernel (icv_infercnv_run); win_out != nullptr: the float64 windows before centring as well
+// (icv_infercnv_run_windows).  The caller holds the plan (PLAN_BUSY_GUARD + PLAN_ENTER).
+int run_steps(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+              double dynamic_threshold, int64_t chunksize, int64_t row_phase, int32_t flags, float* out, int64_t ldo,
+              double* cell_median, double* cell_stats, double* thr, icv_profile* prof, double* win_out, int64_t ldw,
+              void* stream) {
+    int rc;
     const bool do_thr = !std::isnan(dynamic_threshold);
-    if (!cell_median) return fail(ICV_ERR_INVALID, "cell_median is required");
-    if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
-        return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");
-    if ((rc = ensure_device(pl))) return rc;
-    PLAN_ENTER(stream);
     hipStream_t st = static_cast<hipStream_t>(stream);
     icv::KParams K;
     const icv::Layout* lay;
     if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out, ldo, cell_median, cell_stats, K, lay)))
         return rc;
+    K.win_out = win_out;
+    K.win_ld = ldw;
     // cell_stats == NULL: the caller only wants the thresholds.  The per-row moments then live in a plan-owned
     // buffer, and where k_smooth_x16 runs they are not formed per cell at all: the kernel accumulates them per
     // chunk (one wavefront reduction per chunk instead of per cell).
@@ -1379,6 +1410,102 @@ int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, con
     return ICV_OK;
 }
 
+// gene values of n rows from their float64 windows: the fused kernel where a cell's windows and run values fit LDS,
+// the three round-1 kernels on a cells x n_cov temporary otherwise
+int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, const double* thr, int64_t chunksize,
+                      int64_t row_phase, double* gene_out, int64_t ldg, hipStream_t st) {
+    const icv::Plan& p = pl->p;
+    if (n < 1) return ICV_OK;
+    const int W = p.W, n_cov = (int)p.cov_col.size(), R = (int)p.gv_run_j0.size();
+    const size_t lds = icv::gv_lds_bytes(W, R);
+    bool mult16 = true;
+    for (int32_t v : p.gv_run_mult) mult16 = mult16 && v <= 65535;
+    if (lds <= (size_t)icv::kLdsLimit && mult16 && !knobs().no_gene_fused) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_gene_fused),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = (int)((size_t)icv::kLdsLimit / lds);
+        if (per_cu > 8) per_cu = 8;
+        int64_t grid = (int64_t)pl->n_cu * per_cu;
+        if (grid > n) grid = n;
+        hipLaunchKernelGGL(icv::k_gene_fused, dim3((unsigned)grid), dim3(icv::kGvThreads), lds, st, win, ldw, n, W,
+                           pl->d_gv_j0, pl->d_gv_cnt, pl->d_gv_mult, R, n_cov, pl->d_gv_col_run, p.n_cols_all, thr,
+                           chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg);
+        HIP_TRY(hipGetLastError());
+        return ICV_OK;
+    }
+    AsyncBuf b_gv, b_med;
+    HIP_TRY(b_gv.alloc((size_t)n * (n_cov > 0 ? n_cov : 1) * sizeof(double), st));
+    HIP_TRY(b_med.alloc((size_t)n * sizeof(double), st));
+    double *gv = b_gv.as<double>(), *med = b_med.as<double>();
+    {
+        const int64_t total = n * ldg;
+        hipLaunchKernelGGL(icv::k_fill_nan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gene_out, total);
+    }
+    if (n_cov > 0) {
+        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
+            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
+            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
+            hipLaunchKernelGGL(icv::k_gene_means, grid, dim3(256), 0, st, win + r0 * ldw, nr, (int)ldw, pl->d_cov_j0,
+                               pl->d_cov_cnt, n_cov, gv + r0 * n_cov);
+        }
+        hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, gv, n, n_cov, med);
+        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
+            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
+            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
+            // chunk of row r0 + i: (r0 + i + row_phase) / chunksize relative to thr[0]
+            hipLaunchKernelGGL(icv::k_gene_finish, grid, dim3(256), 0, st, gv + r0 * n_cov, med + r0, thr,
+                               chunksize > 0 ? chunksize : 1, row_phase + r0, pl->d_cov_col, n_cov, gene_out + r0 * ldg,
+                               ldg);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int icv_infercnv_run(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,
+                     double dynamic_threshold, int64_t chunksize, int64_t row_phase, int32_t flags, float* out,
+                     int64_t ldo, double* cell_median, double* cell_stats, double* thr, icv_profile* prof,
+                     void* stream) {
+    return icv_infercnv_run_windows(pl, m, ref_lo, ref_hi, lfc_clip, dynamic_threshold, chunksize, row_phase, flags, out,
+                                    ldo, cell_median, cell_stats, thr, prof, nullptr, 0, stream);
+}
+
+int icv_infercnv_run_windows(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi,
+                             double lfc_clip, double dynamic_threshold, int64_t chunksize, int64_t row_phase,
+                             int32_t flags, float* out, int64_t ldo, double* cell_median, double* cell_stats,
+                             double* thr, icv_profile* prof, double* win_out, int64_t ldw, void* stream) {
+    int rc = check_matrix(pl, m);
+    if (rc) return rc;
+    PLAN_BUSY_GUARD(pl);
+    const bool do_thr = !std::isnan(dynamic_threshold);
+    if (!cell_median) return fail(ICV_ERR_INVALID, "cell_median is required");
+    if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
+        return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");
+    if (win_out && ldw < pl->p.W) return fail(ICV_ERR_INVALID, "ldw < n_windows");
+    if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
+    return run_steps(pl, m, ref_lo, ref_hi, lfc_clip, dynamic_threshold, chunksize, row_phase, flags, out, ldo,
+                     cell_median, cell_stats, thr, prof, win_out, ldw, stream);
+}
+
+int icv_gene_values_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n_rows, const double* thr,
+                                 int64_t chunksize, int64_t row_phase, double* gene_out, int64_t ldg, void* stream) {
+    if (!pl) return fail(ICV_ERR_INVALID, "null plan");
+    PLAN_BUSY_GUARD(pl);
+    if (n_rows < 0 || (n_rows > 0 && (!win || !gene_out)) || ldw < pl->p.W || ldg < pl->p.n_cols_all)
+        return fail(ICV_ERR_INVALID, "bad gene_values_from_windows arguments (null buffer, ldw < n_windows or ldg < n_cols)");
+    if (thr && (chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
+        return fail(ICV_ERR_INVALID, "chunksize / row_phase invalid");
+    int rc;
+    if ((rc = ensure_device(pl))) return rc;
+    PLAN_ENTER(stream);
+    return gene_from_windows(pl, win, ldw, n_rows, thr, chunksize, row_phase, gene_out, ldg,
+                             static_cast<hipStream_t>(stream));
+}
+
 int icv_profile_begin(icv_plan_t pl) {
     if (!pl) return fail(ICV_ERR_INVALID, "null plan");
     for (auto& e : pl->prof_events) (void)hipEventDestroy(e);
@@ -1420,58 +1547,21 @@ int icv_gene_values(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, cons
         return fail(ICV_ERR_INVALID, "chunksize / row_phase invalid");
     if ((rc = ensure_device(pl))) return rc;
     PLAN_ENTER(stream);
-    const icv::Plan& p = pl->p;
     const int64_t n = m->n_rows;
     if (n < 1) return ICV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int W = p.W, n_cov = (int)p.cov_col.size();
-    AsyncBuf b_out32, b_win, b_gv, b_med, b_cmed, b_cstat;
+    const int W = pl->p.W;
+    // ONE smoothing pass through the kernel the plain call takes (k_smooth_x16 / k_smooth_se write the float64 windows
+    // beside x_res; other geometries: the generic kernel), then the fused gene kernel.  (A caller that also wants
+    // X_cnv uses icv_infercnv_run_windows + icv_gene_values_from_windows: no second smoothing at all.)
+    AsyncBuf b_out32, b_win, b_cmed;
     HIP_TRY(b_out32.alloc((size_t)n * W * sizeof(float), st));
     HIP_TRY(b_win.alloc((size_t)n * W * sizeof(double), st));
-    HIP_TRY(b_gv.alloc((size_t)n * (n_cov > 0 ? n_cov : 1) * sizeof(double), st));
-    HIP_TRY(b_med.alloc((size_t)n * sizeof(double), st));
     HIP_TRY(b_cmed.alloc((size_t)n * sizeof(double), st));
-    HIP_TRY(b_cstat.alloc((size_t)n * 2 * sizeof(double), st));
-    float* out32 = b_out32.as<float>();
-    double *win = b_win.as<double>(), *gv = b_gv.as<double>(), *med = b_med.as<double>(), *cmed = b_cmed.as<double>(),
-           *cstat = b_cstat.as<double>();
-    icv::KParams K;
-    const icv::Layout* lay;
-    if ((rc = fill_params(pl, m, ref_lo, ref_hi, lfc_clip, flags, out32, W, cmed, cstat, K, lay))) return rc;
-    K.win_out = win;
-    K.win_ld = W;
-    pl->last_kernel = lay->fits ? ICV_KERNEL_GENERIC : ICV_KERNEL_SPLIT;
-    if (!lay->fits)
-        rc = split_windows(pl, m, K, win, st);
-    else if (m->dtype == ICV_F32)
-        rc = m->format == ICV_DENSE ? launch_smooth_t<float, false>(pl, K, *lay, st)
-                                    : launch_smooth_t<float, true>(pl, K, *lay, st);
-    else
-        rc = m->format == ICV_DENSE ? launch_smooth_t<double, false>(pl, K, *lay, st)
-                                    : launch_smooth_t<double, true>(pl, K, *lay, st);
-    if (rc) return rc;
-    {
-        const int64_t total = n * ldg;
-        hipLaunchKernelGGL(icv::k_fill_nan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, gene_out, total);
-    }
-    if (n_cov > 0) {
-        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
-            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
-            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
-            hipLaunchKernelGGL(icv::k_gene_means, grid, dim3(256), 0, st, win + r0 * W, nr, W, pl->d_cov_j0,
-                               pl->d_cov_cnt, n_cov, gv + r0 * n_cov);
-        }
-        hipLaunchKernelGGL(icv::k_row_median, dim3((unsigned)n), dim3(256), 0, st, gv, n, n_cov, med);
-        for (int64_t r0 = 0; r0 < n; r0 += 32768) {
-            const int64_t nr = (n - r0) < 32768 ? (n - r0) : 32768;
-            dim3 grid((n_cov + 255) / 256, (unsigned)nr);
-            // chunk of row r0 + i: (r0 + i + row_phase) / chunksize relative to thr[0]
-            hipLaunchKernelGGL(icv::k_gene_finish, grid, dim3(256), 0, st, gv + r0 * n_cov, med + r0, thr, chunksize,
-                               row_phase + r0, pl->d_cov_col, n_cov, gene_out + r0 * ldg, ldg);
-        }
-    }
-    HIP_TRY(hipGetLastError());
-    return ICV_OK;  // the stream-ordered temporaries are released by their guards
+    if ((rc = run_steps(pl, m, ref_lo, ref_hi, lfc_clip, std::nan(""), 1, 0, flags, b_out32.as<float>(), W,
+                        b_cmed.as<double>(), nullptr, nullptr, nullptr, b_win.as<double>(), W, stream)))
+        return rc;
+    return gene_from_windows(pl, b_win.as<double>(), W, n, thr, chunksize, row_phase, gene_out, ldg, st);
 }
 
 int icv_threshold_mask(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const void* ref_hi, double lfc_clip,

@@ -151,7 +151,9 @@ typedef __attribute__((address_space(3))) unsigned lds_u32_t;
     __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t*>(static_cast<uintptr_t>(OFF)), (V), __ATOMIC_RELAXED, \
                            __HIP_MEMORY_SCOPE_WORKGROUP)
 
-template <int MAXW, bool CHUNK, bool BOUNDED, int PF = 4>
+// WIN: the float64 windows of every cell (before centring) also go to P.win_out[cell * P.win_ld + j]
+// (calculate_gene_values, reference tl/_infercnv.py:274-288); cells handed back are rewritten by k_smooth
+template <int MAXW, bool CHUNK, bool BOUNDED, int PF = 4, bool WIN = false>
 __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
     constexpr int kSePF = PF;
     static_assert(PF >= 1 && PF <= 4, "entry slots per thread");
@@ -316,6 +318,7 @@ __global__ void __launch_bounds__(NT, 4) k_smooth_se(const KParams P) {
                 if (tl + i * NT < W) {  // (the store is range-checked by its descriptor as well)
                     const double y = wvA[i] - med;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)y), o_rs, (unsigned)tl * 4u, i * NT * 4, 0);
+                    if constexpr (WIN) P.win_out[ocell * P.win_ld + tl + i * NT] = wvA[i];
                     sum = sum + y;
                     sq = fma(y, y, sq);
                 }

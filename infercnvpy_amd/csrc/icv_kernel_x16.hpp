@@ -103,7 +103,10 @@ __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_sca
 // reduced once per chunk (P.chunk_part), instead of one 16-wavefront reduction per cell (P.cell_part)
 // REFRES: the reference row lives in registers for the whole kernel (20 VGPRs); false: re-read from L2 at the start
 // of every L phase (long windows need the registers for larger batches of {S0,S1} reads)
-template <int BT, int NBW, int SB /* blocks between adjacent windows = step / BT */, bool CHUNK, int FINE, bool REFRES>
+// WIN: the float64 windows of every cell (before centring) also go to P.win_out[cell * P.win_ld + j] -- what
+// calculate_gene_values averages (reference tl/_infercnv.py:274-288); cells handed back are rewritten by k_smooth
+template <int BT, int NBW, int SB /* blocks between adjacent windows = step / BT */, bool CHUNK, int FINE, bool REFRES,
+          bool WIN = false>
 __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     constexpr int XFINE = FINE, XCOARSE = FINE / 64;
     static_assert(FINE % 1024 == 0 && XCOARSE * XREP <= XT && FINE / 4 <= XT, "histogram cleared by one store per thread");
@@ -506,6 +509,11 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                     asm volatile("" : "+v"(js));  // address formed here, not held in a register across the loop
                     if (v0) stage[js] = yf0;
                     if (v1) stage[js + 1] = yf1;
+                }
+                if constexpr (WIN) {
+                    double* wrow = P.win_out + pcell * P.win_ld;
+                    if (v0) wrow[wj0] = wvA0;
+                    if (v1) wrow[wj0 + 1] = wvA1;
                 }
             }
         }

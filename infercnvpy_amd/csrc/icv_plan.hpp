@@ -55,6 +55,9 @@ struct Plan {
     std::vector<int32_t> pad_idx;    // padded positions without a gene
     // calculate_gene_values: genes covered by at least one kept window, in chromosome-sorted order
     std::vector<int32_t> cov_col, cov_j0, cov_cnt;  // input column, first covering window, #windows
+    // the same coverage as RUNS of consecutive covered genes that share their windows (one value per run and cell: a
+    // gene's value only depends on (j0, cnt)): run -> first window, #windows, #genes; input column -> run or -1
+    std::vector<int32_t> gv_run_j0, gv_run_cnt, gv_run_mult, gv_col_run;
     std::vector<int32_t> w_pack;     // ws path: (start block & 0xffff) | (len << 16)
     // ws path, long windows (prefix-sum form): gene offset of a window inside its chromosome; per block, the gene
     // offset of its first gene inside its chromosome
@@ -250,6 +253,18 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
             p.cov_j0.push_back(w0 + j0);
             p.cov_cnt.push_back(j1 - j0 + 1);
         }
+    }
+
+    p.gv_run_j0.clear(); p.gv_run_cnt.clear(); p.gv_run_mult.clear();
+    p.gv_col_run.assign((size_t)n_cols_all, -1);
+    for (size_t q = 0; q < p.cov_col.size(); ++q) {
+        if (p.gv_run_j0.empty() || p.gv_run_j0.back() != p.cov_j0[q] || p.gv_run_cnt.back() != p.cov_cnt[q]) {
+            p.gv_run_j0.push_back(p.cov_j0[q]);
+            p.gv_run_cnt.push_back(p.cov_cnt[q]);
+            p.gv_run_mult.push_back(0);
+        }
+        ++p.gv_run_mult.back();
+        p.gv_col_run[p.cov_col[q]] = (int32_t)p.gv_run_j0.size() - 1;
     }
 
     p.pad_idx.clear();

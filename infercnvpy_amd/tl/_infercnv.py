@@ -337,15 +337,17 @@ def _infercnv_resident(var, obs, dm, *, reference_key, reference_cat, reference,
             genes = torch.empty((n_obs, n_vars), dtype=torch.float64, device="cuda") if calculate_gene_values else None
             for r0 in range(0, max(n_obs, 1), piece):
                 r1 = min(n_obs, r0 + piece)
+                # (calculate_gene_values: the smoothing launch also writes its float64 windows -- one pass, as the
+                # reference's _infercnv_chunk returns both from one pass, :438-457)
                 res = _engine.run_hot_path(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                            dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
-                                           row0=r0, row1=r1, apply=False)
+                                           row0=r0, row1=r1, apply=False, windows=calculate_gene_values)
                 parts.append(_engine.threshold_csr(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
                                                    chunksize=chunksize, flags=flags, row0=r0, row1=r1))
                 if calculate_gene_values and r1 > r0:
                     # (pieces are whole chunks: the piece's thresholds are the thresholds of its rows' chunks)
-                    _engine.gene_values(plan, dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=res.thr, chunksize=chunksize,
-                                        flags=flags, row0=r0, row1=r1, out=genes[r0:r1])
+                    _engine.gene_values_from_windows(plan, res.windows, thr=res.thr, chunksize=chunksize,
+                                                     out=genes[r0:r1])
                 del res
             x_cnv = parts[0] if len(parts) == 1 else _engine.concat_packed(parts)
             tm["kernel"] = plan.last_kernel()
@@ -760,23 +762,23 @@ def infercnv(
             drain = _engine.CsrDrain(n_rows, plan.n_windows)  # packs and copies back finished pieces behind the kernels
             for i in range(len(slabs)):
                 ss = slab_stream(i)  # a single slab that a reference pass has already brought in is not uploaded again
-                thrs = []
                 for r0, r1 in ss.pieces():
+                    # (calculate_gene_values: the smoothing launch also writes its float64 windows; the gene layer of
+                    # the piece is formed from them in one kernel -- pieces are whole chunks, so the piece's thresholds
+                    # are those of its rows)
                     res = _engine.run_hot_path(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip,
                                                dynamic_threshold=dynamic_threshold, chunksize=chunksize, flags=flags,
-                                               row0=r0, row1=r1, apply=False)
+                                               row0=r0, row1=r1, apply=False, windows=calculate_gene_values)
                     # step 5b + csr_matrix(x_res) on the device (keep-mask, row offsets, fill); only the row offsets
                     # and the packed entries are read back by the drain
                     drain.submit(_engine.threshold_csr(plan, ss.dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip,
                                                        chunksize=chunksize, flags=flags, row0=r0, row1=r1))
-                    if res.thr is not None:
-                        thrs.append(res.thr)
+                    if calculate_gene_values and r1 > r0:
+                        gv = _engine.gene_values_from_windows(plan, res.windows, thr=res.thr, chunksize=chunksize,
+                                                              n_vars=n_vars)
+                        s.gene_pieces.append(gv.cpu().numpy())
+                        del gv
                     del res
-                if calculate_gene_values:
-                    thr_all = torch.cat(thrs) if thrs else None
-                    gv = _engine.gene_values(plan, ss.dm, ref_lo, ref_hi, lfc_clip=lfc_clip, thr=thr_all,
-                                             chunksize=chunksize, flags=flags)
-                    s.gene_pieces.append(gv.cpu().numpy())
                 ss = None
             for k in list(streams):
                 retire(k)

@@ -190,6 +190,95 @@ def test_gene_values_against_oracle_medium():
         np.testing.assert_allclose(np.nan_to_num(pg), np.nan_to_num(o_pg), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("fmt,window,kernel", [("dense", 100, "X16"), ("dense", 250, "X16"), ("csr", 250, "SD"),
+                                               ("csr", 100, "SD"), ("dense", 120, None)])
+def test_gene_values_benchmark_geometry_one_smoothing_pass(fmt, window, kernel, monkeypatch):
+    """calculate_gene_values at the 20 000-gene geometry (reference tl/_infercnv.py:247-298, :443-453): the float64
+    windows come out of the SAME launch of the fast smoothing kernel that writes x_res (k_smooth_x16 / k_smooth_se;
+    window 120: the generic kernel), the gene layer from ONE fused kernel.  Against the oracle: NaN and zero patterns
+    exact, values to 1e-12; X_cnv unchanged by the flag; the fused kernel = the three round-1 kernels bit for bit;
+    the device-resident call = the host call bit for bit."""
+    import torch
+
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd import _engine, _lib
+    from infercnvpy_amd._compat import SimpleAnnData
+    from oracle import infercnv_oracle as O
+
+    v = cases.synthetic_var(cases.GENES_PER_CHROM_20K, extra=(("chrX", 37), ("chrM", 3), (None, 4)))
+    n_genes = len(v["names"]) - len(v["names"]) % 4
+    for key in v:
+        v[key] = v[key][:n_genes]
+    n = 96
+    X = cases.synthetic_expr(n, n_genes, seed=93)
+    X[7, :] = 0.0  # a cell without stored entries
+    ref = X.mean(axis=0, dtype=np.float64).astype(np.float32)
+    Xin = sp.csr_matrix(X) if fmt == "csr" else X
+    var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
+    kw = dict(reference=ref, window_size=window, step=10, chunksize=32)
+    tm = {}
+    pos, res, pg = cnv.tl.infercnv(SimpleAnnData(Xin, var=var), calculate_gene_values=True, inplace=False, _timings=tm, **kw)
+    if kernel is not None:
+        assert tm["kernel"] == getattr(_lib, "ICV_KERNEL_" + kernel)
+    _, res_plain, none = cnv.tl.infercnv(SimpleAnnData(Xin, var=var), inplace=False, **kw)
+    assert none is None
+    for a, b in ((res.indptr, res_plain.indptr), (res.indices, res_plain.indices), (res.data, res_plain.data)):
+        np.testing.assert_array_equal(a, b)
+    _, o_res, o_pg, _ = O.infercnv(Xin, v["chromosome"], v["start"], calculate_gene_values=True, **kw)
+    assert pg.shape == o_pg.shape == (n, n_genes) and pg.dtype == np.float64
+    np.testing.assert_array_equal(np.isnan(pg), np.isnan(o_pg))
+    np.testing.assert_array_equal(np.nan_to_num(pg) == 0, np.nan_to_num(o_pg) == 0)
+    np.testing.assert_allclose(np.nan_to_num(pg), np.nan_to_num(o_pg), rtol=0, atol=1e-12)
+    assert np.isnan(pg).any() and (np.nan_to_num(pg) != 0).any()
+    # the round-1 kernels on the same windows: identical bits
+    monkeypatch.setenv("ICV_NO_GENE_FUSED", "1")
+    _lib.load().icv_developer_knobs_reload()
+    _, _, pg_old = cnv.tl.infercnv(SimpleAnnData(Xin, var=var), calculate_gene_values=True, inplace=False, **kw)
+    monkeypatch.delenv("ICV_NO_GENE_FUSED")
+    _lib.load().icv_developer_knobs_reload()
+    np.testing.assert_array_equal(pg_old.view(np.int64), pg.view(np.int64))
+    # HBM-resident input: the same bits, everything stays on the device
+    if fmt == "dense":
+        Xd = torch.from_numpy(X).cuda()
+    else:
+        Xd = _engine.to_device_matrix(Xin)
+    _, x_dev, pg_dev = cnv.tl.infercnv(SimpleAnnData(Xd, var=var), calculate_gene_values=True, inplace=False, **kw)
+    assert pg_dev.is_cuda
+    np.testing.assert_array_equal(pg_dev.cpu().numpy().view(np.int64), pg.view(np.int64))
+    np.testing.assert_array_equal(x_dev.to_scipy().data, res.data)
+
+
+def test_gene_values_old_entry_point_and_odd_strides():
+    """icv_gene_values (smoothing + gene layer in one call) and icv_gene_values_from_windows with an odd row stride /
+    an unaligned output (the 8-byte store path): equal to the aligned result."""
+    import torch
+
+    from infercnvpy_amd import _engine
+    from infercnvpy_amd._plan import GenePlan
+
+    v = cases.synthetic_var([700, 320, 150, 100, 61], extra=(("chrX", 40), (None, 3)))
+    n_genes = len(v["names"])
+    X = torch.from_numpy(cases.synthetic_expr(70, n_genes, seed=17)).cuda()
+    dm = _engine.DeviceMatrix(dense=X)
+    ref = X.mean(dim=0)
+    plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
+    try:
+        res = _engine.run_hot_path(plan, dm, ref, chunksize=30, apply=False, windows=True)
+        a = _engine.gene_values_from_windows(plan, res.windows, thr=res.thr, chunksize=30, n_vars=n_genes)
+        b = _engine.gene_values(plan, dm, ref, thr=res.thr, chunksize=30)
+        np.testing.assert_array_equal(a.cpu().numpy().view(np.int64), b.cpu().numpy().view(np.int64))
+        wide = torch.full((70, n_genes + 3), 7.0, dtype=torch.float64, device="cuda")
+        c = _engine.gene_values_from_windows(plan, res.windows, thr=res.thr, chunksize=30, out=wide[:, 1:1 + n_genes])
+        np.testing.assert_array_equal(c.cpu().numpy().view(np.int64), a.cpu().numpy().view(np.int64))
+        assert float(wide[:, 0].min()) == 7.0 and float(wide[:, -2:].min()) == 7.0  # nothing outside the view
+        # no thresholds
+        d = _engine.gene_values_from_windows(plan, res.windows, n_vars=n_genes)
+        e = _engine.gene_values(plan, dm, ref)
+        np.testing.assert_array_equal(d.cpu().numpy().view(np.int64), e.cpu().numpy().view(np.int64))
+    finally:
+        plan.close()
+
+
 def test_reference_fixture_through_public_api():
     """The reference's own 4 x 10 fixture (tests/conftest.py:61-108) through tl.infercnv, chunksize=2."""
     import infercnvpy_amd as cnv
