@@ -1183,9 +1183,10 @@ def csr_row_abs_sum(x_csr):
     return res
 
 
-def group_sums(values, codes, n_groups):
+def group_sums(values, codes, n_groups, want_counts=True):
     """(sums, counts) per group of a device float64 vector: ``codes`` (host int32, -1 = no group) names the group of
-    every element.  Fixed summation order on the device (``icv_group_sums``); host numpy arrays of length n_groups."""
+    every element.  Fixed summation order on the device (``icv_group_sums``); host numpy arrays of length n_groups
+    (``want_counts=False``: counts is None -- one read-back instead of two)."""
     torch = _torch()
     lib = _lib.load()
     with torch.cuda.device(values.device):
@@ -1194,7 +1195,7 @@ def group_sums(values, codes, n_groups):
         counts = torch.empty(max(n_groups, 1), dtype=torch.int64, device="cuda")
         _lib.check(lib.icv_group_sums(_ptr(values), _ptr(codes_d), values.numel(), int(n_groups), _ptr(sums),
                                       _ptr(counts), _stream_ptr(torch)))
-        return sums[:n_groups].cpu().numpy(), counts[:n_groups].cpu().numpy()
+        return sums[:n_groups].cpu().numpy(), (counts[:n_groups].cpu().numpy() if want_counts else None)
 
 
 def gene_values(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_clip=3.0, thr=None, chunksize=5000,

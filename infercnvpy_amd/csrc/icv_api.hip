@@ -60,6 +60,7 @@ struct Knobs {
          no_gene_fused;
     int wgs_per_cu;        // 0 = not set
     int chain_far;         // ICV_CHAIN_FAR: entries a buffer offset may span in k_colchain_csrq (tests: a small value)
+    int chain_pieces;      // ICV_CHAIN_PIECES: lanes per row of k_colchain_csrq (2 / 4 / 8 / 16; 0 = from the density)
     double ward_compact_x; // 0 = not set
     void load() {
         force_generic = std::getenv("ICV_FORCE_GENERIC") != nullptr;
@@ -76,6 +77,8 @@ struct Knobs {
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_CHAIN_FAR");
         chain_far = e ? std::atoi(e) : 0;
+        e = std::getenv("ICV_CHAIN_PIECES");
+        chain_pieces = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_WARD_COMPACT_X");
         ward_compact_x = e ? std::atof(e) : 0.0;
     }
@@ -106,7 +109,10 @@ struct icv_plan_s {
     int32_t* d_wpack = nullptr;
     unsigned* d_tie_n = nullptr;  // k_thr_mask_ring's tie counter + k_thr_mask_ties' done counter (zero between calls)
     int32_t *d_cov_col = nullptr, *d_cov_j0 = nullptr, *d_cov_cnt = nullptr;
-    int32_t *d_gv_j0 = nullptr, *d_gv_cnt = nullptr, *d_gv_mult = nullptr, *d_gv_col_run = nullptr;  // k_gene_fused
+    uint32_t* d_gv_pk = nullptr;  // k_gene_fused: per run, first window | #windows << 16
+    int32_t* d_gv_mult = nullptr;   //               genes per run
+    int16_t* d_gv_col16 = nullptr;  //               input column -> run or -1, padded to a multiple of 8 columns
+    bool gv_fused_ok = false;
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
@@ -264,10 +270,22 @@ int ensure_device(icv_plan_t pl) {
     HIP_TRY(up(p.cov_col.data(), p.cov_col.size() * 4, (void**)&pl->d_cov_col));
     HIP_TRY(up(p.cov_j0.data(), p.cov_j0.size() * 4, (void**)&pl->d_cov_j0));
     HIP_TRY(up(p.cov_cnt.data(), p.cov_cnt.size() * 4, (void**)&pl->d_cov_cnt));
-    HIP_TRY(up(p.gv_run_j0.data(), p.gv_run_j0.size() * 4, (void**)&pl->d_gv_j0));
-    HIP_TRY(up(p.gv_run_cnt.data(), p.gv_run_cnt.size() * 4, (void**)&pl->d_gv_cnt));
-    HIP_TRY(up(p.gv_run_mult.data(), p.gv_run_mult.size() * 4, (void**)&pl->d_gv_mult));
-    HIP_TRY(up(p.gv_col_run.data(), p.gv_col_run.size() * 4, (void**)&pl->d_gv_col_run));
+    {
+        // tables of k_gene_fused (16-bit fields: the fused kernel applies where they fit)
+        const size_t R = p.gv_run_j0.size();
+        bool ok = p.W <= 65535 && R < 32768;
+        std::vector<uint32_t> pk(R);
+        for (size_t r = 0; r < R && ok; ++r) {
+            ok = p.gv_run_cnt[r] <= 65535 && p.gv_run_mult[r] <= 65535;
+            pk[r] = (uint32_t)p.gv_run_j0[r] | ((uint32_t)p.gv_run_cnt[r] << 16);
+        }
+        std::vector<int16_t> c16(((size_t)p.n_cols_all + 7) / 8 * 8, (int16_t)-1);
+        for (int c = 0; c < p.n_cols_all && ok; ++c) c16[c] = (int16_t)p.gv_col_run[c];
+        pl->gv_fused_ok = ok;
+        HIP_TRY(up(pk.data(), pk.size() * 4, (void**)&pl->d_gv_pk));
+        HIP_TRY(up(p.gv_run_mult.data(), p.gv_run_mult.size() * 4, (void**)&pl->d_gv_mult));
+        HIP_TRY(up(c16.data(), c16.size() * 2, (void**)&pl->d_gv_col16));
+    }
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
     HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
@@ -962,7 +980,24 @@ int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double
                            lt_b.as<uint16_t>(), L.n_lines, esz_shift_q, L.grid, bounds_b.as<uint32_t>());
         typedef void (*kq_t)(const T*, const int64_t*, const int32_t*, int64_t, const int32_t*, int64_t, int, int, int,
                              const uint16_t*, T, int, T*);
-        const kq_t kq = rows ? (kq_t)icv::k_colchain_csrq<T, true> : (kq_t)icv::k_colchain_csrq<T, false>;
+        // lanes per row (= entry slots / 4) from the entries a row has in ONE tile: mean of the widest tile -- from the
+        // caller's row-length hint (icv_matrix._pad: the length most rows stay under) where there is one -- plus three
+        // sigma of a Poisson count.  Rows beyond the slots take the guarded loads: any choice gives the same bits.
+        int pieces = 4;
+        {
+            const double rows_all = m->n_rows > 0 ? (double)m->n_rows : 1.0;
+            double per_row = (double)(m->csr_end - m->csr_begin) / rows_all;
+            if (m->_pad > 0 && (double)m->_pad > per_row) per_row = (double)m->_pad;
+            const int tile_lines = (L.n_lines + L.grid - 1) / L.grid;
+            const double mu = per_row * (double)(tile_lines * (128 / (int)sizeof(T))) / (double)(m->n_cols > 0 ? m->n_cols : 1);
+            const double need = mu + 3.0 * std::sqrt(mu);
+            pieces = need <= 8.0 ? 2 : need <= 16.0 ? 4 : need <= 32.0 ? 8 : 16;
+            const int forced = knobs().chain_pieces;
+            if (forced == 2 || forced == 4 || forced == 8 || forced == 16) pieces = forced;
+        }
+#define ICV_KQ(P) (rows ? (kq_t)icv::k_colchain_csrq<T, true, P> : (kq_t)icv::k_colchain_csrq<T, false, P>)
+        const kq_t kq = pieces == 2 ? ICV_KQ(2) : pieces == 4 ? ICV_KQ(4) : pieces == 8 ? ICV_KQ(8) : ICV_KQ(16);
+#undef ICV_KQ
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     icv::kChLdsFull));
         // (always the whole LDS of a CU: the ring of LDS rows is the work in flight; with more tiles than CUs the
@@ -1052,10 +1087,9 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_cov_col);
         (void)hipFree(pl->d_cov_j0);
         (void)hipFree(pl->d_cov_cnt);
-        (void)hipFree(pl->d_gv_j0);
-        (void)hipFree(pl->d_gv_cnt);
+        (void)hipFree(pl->d_gv_pk);
         (void)hipFree(pl->d_gv_mult);
-        (void)hipFree(pl->d_gv_col_run);
+        (void)hipFree(pl->d_gv_col16);
         (void)hipFree(pl->d_row_list);
         (void)hipFree(pl->d_row_count);
         (void)hipFree(pl->d_cell_part);
@@ -1418,17 +1452,15 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
     if (n < 1) return ICV_OK;
     const int W = p.W, n_cov = (int)p.cov_col.size(), R = (int)p.gv_run_j0.size();
     const size_t lds = icv::gv_lds_bytes(W, R);
-    bool mult16 = true;
-    for (int32_t v : p.gv_run_mult) mult16 = mult16 && v <= 65535;
-    if (lds <= (size_t)icv::kLdsLimit && mult16 && !knobs().no_gene_fused) {
+    if (lds <= (size_t)icv::kLdsLimit && pl->gv_fused_ok && !knobs().no_gene_fused) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_gene_fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = (int)((size_t)icv::kLdsLimit / lds);
-        if (per_cu > 8) per_cu = 8;
+        if (per_cu > 4) per_cu = 4;  // 512-thread workgroups: 32 wavefronts per CU
         int64_t grid = (int64_t)pl->n_cu * per_cu;
         if (grid > n) grid = n;
         hipLaunchKernelGGL(icv::k_gene_fused, dim3((unsigned)grid), dim3(icv::kGvThreads), lds, st, win, ldw, n, W,
-                           pl->d_gv_j0, pl->d_gv_cnt, pl->d_gv_mult, R, n_cov, pl->d_gv_col_run, p.n_cols_all, thr,
+                           pl->d_gv_pk, pl->d_gv_mult, R, n_cov, pl->d_gv_col16, p.n_cols_all, thr,
                            chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg);
         HIP_TRY(hipGetLastError());
         return ICV_OK;

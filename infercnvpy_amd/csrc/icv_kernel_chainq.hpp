@@ -28,7 +28,17 @@
 
 namespace icv {
 
-constexpr int kQRows = 64;      // input rows per round (one bit each in a column's row mask)
+constexpr int kQRows = 64;      // input rows per round at most (one bit each in a column's row mask)
+// PIECES (template parameter of k_colchain_csrq): lanes that share a row's run of the tile's entries, four entries each =
+// 4 PIECES entry slots per row.  A load vector covers 64 / PIECES rows; a round is 4 vectors (2 for PIECES = 2):
+//   PIECES  2: 64 rows x  8 slots (2 vectors: half the slot work -- matrices with fewer than ~2 entries per row and tile)
+//   PIECES  4: 64 rows x 16 slots (round 5's shape: config 4 has 5.5 entries per row and tile)
+//   PIECES  8: 32 rows x 32 slots, PIECES 16: 16 rows x 64 slots (denser rows: round 5 sent every row with more than 16
+//              entries in the tile through per-entry guarded loads -- 62 % of the rounds at 14 % density, 8.0 ms against
+//              3.1 at 7 %: super-linear; here the time follows the entries)
+// The launcher picks PIECES from the mean and spread of the entries per (row, tile); rows beyond the slots still take
+// the guarded loads (rare by that choice), and any PIECES gives the same bits.
+__host__ __device__ constexpr int q_rows_per_round(int pieces) { return pieces <= 4 ? 64 : 256 / pieces; }
 constexpr int kQTabRows = 32;   // rows per block of the bounds table
 constexpr int kQCtl = 256;      // control words at the end of the LDS
 constexpr int kQCmBytes = 1536; // row masks of one producer wavefront: 128 columns x 8 bytes + one trash word PER LANE
@@ -229,7 +239,7 @@ __device__ __forceinline__ void chain_stream(const unsigned char* smem, int n_ri
 
 // acc[c] += fl(x * scale) over the stored entries of rows sel[0..n_sel) (nullptr: rows 0..n_sel), rows ascending.
 // grid = the column tiles of ChainLaunch (= n_tiles of the table), 1024 threads: 15 producer wavefronts + the chain.
-template <typename T, bool LIST>
+template <typename T, bool LIST, int PIECES = 4>
 __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restrict__ vals,
                                                               const int64_t* __restrict__ indptr,
                                                               const int32_t* __restrict__ indices, int64_t n_rows_all,
@@ -258,7 +268,12 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
     // ctl: [0] next round to allocate, [1] rows allocated (wrapping counter), [2] ring position of the next row,
     //      [3] rounds published, [4] rows published, [5] rows consumed
     unsigned* ctl = reinterpret_cast<unsigned*>(smem + lds_bytes - kQCtl);
-    const unsigned n_rounds = (unsigned)((n_sel + kQRows - 1) / kQRows);
+    static_assert(PIECES == 2 || PIECES == 4 || PIECES == 8 || PIECES == 16, "lanes per row");
+    constexpr int ROWS = q_rows_per_round(PIECES);  // input rows per round
+    constexpr int RPV = 64 / PIECES;                 // rows per load vector
+    constexpr int NVEC = ROWS / RPV;                 // load vectors per round
+    constexpr int SLOTS = 4 * PIECES;                // entry slots per row
+    const unsigned n_rounds = (unsigned)((n_sel + ROWS - 1) / ROWS);
     for (int o = threadIdx.x * 16; o < kChLoaders * kQCmBytes + kQCtl; o += kChThreads * 16)
         *reinterpret_cast<uint4*>(cm_base + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -266,7 +281,7 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
     if (wave < kChLoaders) {
         unsigned long long* cm = reinterpret_cast<unsigned long long*>(cm_base + wave * kQCmBytes);
         const int64_t e_end = indptr[n_rows_all];
-        const int piece = lane & 3, sub = lane >> 2;  // lane = (row 16 v + sub of the round, piece) in load vector v
+        const int piece = lane & (PIECES - 1), sub = lane / PIECES;  // lane = (row RPV v + sub of the round, piece) in load vector v
         // stage A (lane = row of the round): the three loaded words are kept RAW until the next turn (arithmetic on
         // them here would make the compiler wait for the loads issued just before)
         int64_t a_rp = 0;
@@ -277,14 +292,14 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
         bool b_more = false;  // (uniform) a row with more than 16 entries in the tile, or too far for a buffer offset
         bool b_slow = false;  // this row's entries from `b_from` on go through the guarded loads
         int b_from = 0;
-        int b_nv[4];
-        u32x4 b_idx[4];
-        T b_val[4][4];
+        int b_nv[NVEC];
+        u32x4 b_idx[NVEC];
+        T b_val[NVEC][4];
         const auto fetch_a = [&](unsigned k) {
-            const int64_t i = (int64_t)k * kQRows + lane;
+            const int64_t i = (int64_t)k * ROWS + lane;
             a_rp = 0;
             a_lo = a_hi = 0;
-            if (k < n_rounds && i < n_sel) {
+            if (k < n_rounds && i < n_sel && lane < ROWS) {
                 const int64_t row = LIST ? sel[i] : i;
                 a_lo = tab[q_tab_index(i, tile, n_tiles)];
                 a_hi = tab[q_tab_index(i, tile + 1, n_tiles)];
@@ -302,18 +317,18 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                               (unsigned)__builtin_amdgcn_readlane((int)b_base, first);
             if (!has) e_first = e_end;
             const int64_t left = e_end - e_first;
-            const unsigned rec = (unsigned)(left < (int64_t)far_limit + 16 ? left : (int64_t)far_limit + 16);
+            const unsigned rec = (unsigned)(left < (int64_t)far_limit + SLOTS ? left : (int64_t)far_limit + SLOTS);
             const __amdgpu_buffer_rsrc_t i_rs = make_rsrc(indices + e_first, rec * 4u);
             const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vals + e_first, rec * (unsigned)sizeof(T));
             const int64_t rel64 = b_base - e_first;
             const bool far = b_cnt > 0 && rel64 >= (int64_t)far_limit;
-            b_slow = far || b_cnt > 16;
-            b_from = far ? 0 : 16;
+            b_slow = far || b_cnt > SLOTS;
+            b_from = far ? 0 : SLOTS;
             b_more = __builtin_amdgcn_ballot_w64(b_slow) != 0ull;
             const int rel = far || b_cnt <= 0 ? -1 : (int)rel64;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int src = 16 * v + sub;
+            for (int v = 0; v < NVEC; ++v) {
+                const int src = RPV * v + sub;
                 const int cnt_v = __shfl(b_cnt, src);
                 const int rel_v = __shfl(rel, src);
                 int nv = cnt_v - 4 * piece;
@@ -345,11 +360,11 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
         const unsigned trash_off = (unsigned)(lds_bytes - kQCtl - kChLoaders * kQCmBytes - kQTrash) + 8u * (unsigned)lane;
         const auto write_round = [&](unsigned k) {
             // 1. row masks of the tile's columns
-            unsigned c8[4][4];  // 8 x (column inside the tile); 1024 + 8 x lane = the lane's trash word
+            unsigned c8[NVEC][4];  // 8 x (column inside the tile); 1024 + 8 x lane = the lane's trash word
             const unsigned my_trash = 1024u + 8u * (unsigned)lane;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const unsigned long long bit = 1ull << (16 * v + sub);
+            for (int v = 0; v < NVEC; ++v) {
+                const unsigned long long bit = 1ull << (RPV * v + sub);
                 const int idx[4] = {(int)b_idx[v].x, (int)b_idx[v].y, (int)b_idx[v].z, (int)b_idx[v].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -398,8 +413,8 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
             // zeros above are in place)
             const unsigned base_off = (unsigned)posd * (unsigned)row_bytes;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const unsigned long long below = (1ull << (16 * v + sub)) - 1ull;
+            for (int v = 0; v < NVEC; ++v) {
+                const unsigned long long below = (1ull << (RPV * v + sub)) - 1ull;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned long long m =

@@ -9,23 +9,37 @@
 // A gene's value depends only on WHICH windows cover it, (j0, cnt): consecutive covered genes share it in runs of
 // ~step genes (icv_plan.hpp: gv_run_*: ~2 G / step runs).  Per cell: the W windows come into LDS once, every run's
 // value is formed once (numpy's summation order), the median over the covered genes is the WEIGHTED median of the run
-// values (weights = genes per run: the same multiset the reference sorts) found by an 8-pass radix select on the
-// order-preserving 64-bit keys, and the output row is written once, in input-column order, as full 16-byte stores
-// (NaN where a column has no run).  The round-1 form (k_gene_means -> k_row_median -> k_gene_finish on a cells x n_cov
-// float64 temporary after a NaN fill of the whole layer) wrote the layer twice and read the temporary ~20 times.
+// values (weights = genes per run: the same multiset the reference sorts), and the output row is written once, in
+// input-column order, as full 16-byte stores (NaN where a column has no run).  The round-1 form (k_gene_means ->
+// k_row_median -> k_gene_finish on a cells x n_cov float64 temporary after a NaN fill of the whole layer) wrote the
+// layer twice and read the temporary ~20 times: 84 ms per 100 000 x 20 000 cells against the 3.3 ms of the plain call.
+//
+// Weighted median = an exact order statistic: a 2048-bin weighted histogram over [min, max] of the cell's run values
+// locates the bin of rank k, the bin's elements (<= 64; else the histogram is refined on the bin's own [min, max]) are
+// ranked exactly by one wavefront.  (First version: 8-pass radix select on the 64-bit keys -- its top byte is shared by
+// all values of one sign: 32-way same-address LDS atomics, 30 000 cycles per cell.)
 #pragma once
 #include "icv_kernels.hpp"
 
 namespace icv {
 
-constexpr int kGvThreads = 256;
+constexpr int kGvThreads = 512;
+constexpr int kGvWaves = kGvThreads / 64;
+constexpr int kGvBins = 2048;
+constexpr int kGvCand = 64;
 
 struct GvScratch {
-    int hist[256];
-    int sel_digit, sel_k, sel_weq, anynan;
-    double vmin[4];
+    unsigned hist[kGvBins];
+    double red[2][kGvWaves];   // min / max partials
+    double cand_v[kGvCand];
+    int cand_w[kGvCand];
+    int wsum[kGvWaves];        // per-wavefront histogram totals (scan)
+    int ncand, anynan, sel_bin, sel_below;
+    double v1, v2;
+    int found2, pad_;
 };
 
+// (the tables need W <= 65 535 windows, run lengths and window counts that fit 16 bits, fewer than 32 768 runs)
 // dynamic LDS: win[W] (float64; dead after the run values: the scratch aliases it) | val[R] | mult[R] (16-bit)
 __host__ __device__ inline size_t gv_lds_bytes(int W, int R) {
     size_t w = (size_t)W * 8;
@@ -34,11 +48,35 @@ __host__ __device__ inline size_t gv_lds_bytes(int W, int R) {
     return w + (size_t)R * 8 + ((size_t)R * 2 + 15) / 16 * 16;
 }
 
+// numpy's float64 add.reduce of a[0..n) in LDS, n <= 128 inlined (the recursion of numpy_sum above that)
+__device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int i = 8;
+        for (; i + 8 <= n; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    return numpy_sum(a, n);
+}
+
+// run_pk[r] = first window | #windows << 16 of run r; col_run16[c] = run of input column c or -1 (padded to a multiple of
+// 8 columns with -1).  Global loads are issued in batches before the dependent LDS work.
 __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
-    const double* __restrict__ win, int64_t ldw, int64_t n_rows, int W, const int32_t* __restrict__ run_j0,
-    const int32_t* __restrict__ run_cnt, const int32_t* __restrict__ run_mult, int R, int n_cov,
-    const int32_t* __restrict__ col_run, int n_cols, const double* __restrict__ thr, int64_t chunksize,
-    int64_t row_phase, double* __restrict__ out, int64_t ldg) {
+    const double* __restrict__ win, int64_t ldw, int64_t n_rows, int W, const uint32_t* __restrict__ run_pk,
+    const int32_t* __restrict__ run_mult, int R, int n_cov, const int16_t* __restrict__ col_run16, int n_cols,
+    const double* __restrict__ thr, int64_t chunksize, int64_t row_phase, double* __restrict__ out, int64_t ldg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     size_t woff = (size_t)W * 8;
     if (woff < sizeof(GvScratch)) woff = sizeof(GvScratch);
@@ -51,111 +89,248 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     const int k1 = (n_cov - 1) / 2, k2 = n_cov / 2;
     for (int i = t; i < R; i += kGvThreads) mult[i] = (unsigned short)run_mult[i];
     const bool vec2 = (ldg % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const bool win16 = (ldw % 2 == 0) && ((reinterpret_cast<uintptr_t>(win) & 15) == 0);
     const double nan = __builtin_nan("");
+    constexpr int UW = 4;  // window loads (16 bytes) in flight per thread
+    constexpr int UR = 4;  // run-table loads in flight per thread
+    constexpr int UC = 8;  // column-table loads (2 columns each) in flight per thread
 
     for (int64_t cell = blockIdx.x; cell < n_rows; cell += gridDim.x) {
         __syncthreads();  // the previous cell's output phase has read val[]; its scratch use is over
         // ---- 1. the cell's windows
         const double* wr = win + cell * ldw;
-        for (int j = t; j < W; j += kGvThreads) lwin[j] = wr[j];
-        __syncthreads();
-        // ---- 2. run values (np.mean of the covering windows: numpy's pairwise sum / count)
-        int nanl = 0;
-        for (int r = t; r < R; r += kGvThreads) {
-            const int cnt = run_cnt[r];
-            const double v = numpy_sum(lwin + run_j0[r], cnt) / (double)cnt;
-            val[r] = v;
-            nanl |= (v != v);
-        }
-        __syncthreads();  // windows dead: the scratch may be written
-        if (t == 0) sc->anynan = 0;
-        __syncthreads();
-        if (nanl) sc->anynan = 1;  // benign race
-        // ---- 3. weighted median: radix select of rank k1 on the ordered keys, most significant byte first
-        unsigned long long prefix = 0ull;
-        int k = k1, weq = 0;
-        for (int pass = 7; pass >= 0; --pass) {
-            sc->hist[t] = 0;
-            __syncthreads();
-            const int sh = pass * 8;
-            for (int r = t; r < R; r += kGvThreads) {
-                const unsigned long long key = ordered_key(val[r]);
-                const bool in = pass == 7 || ((key ^ prefix) >> (sh + 8)) == 0ull;
-                if (in) atomicAdd(&sc->hist[(int)((key >> sh) & 255ull)], (int)mult[r]);
+        if (win16) {
+            typedef double f64x2_t __attribute__((ext_vector_type(2)));
+            const int n2 = W / 2;
+            for (int j0 = t; j0 < n2; j0 += UW * kGvThreads) {
+                f64x2_t q[UW];
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    if (j0 + u * kGvThreads < n2) q[u] = *reinterpret_cast<const f64x2_t*>(wr + 2 * (j0 + u * kGvThreads));
+#pragma unroll
+                for (int u = 0; u < UW; ++u)
+                    if (j0 + u * kGvThreads < n2) *reinterpret_cast<f64x2_t*>(lwin + 2 * (j0 + u * kGvThreads)) = q[u];
             }
-            __syncthreads();
-            if (wave == 0) {
-                const int4 h = reinterpret_cast<const int4*>(sc->hist)[lane];
-                const int c = (h.x + h.y) + (h.z + h.w);
-                const int incl = wave_scan_dpp(c);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(incl > k);
-                const int L = m ? (int)__builtin_ctzll(m) : 63;
-                if (lane == L) {
-                    int run = incl - c, d = 3, kk = 0, we = h.w;
-                    if (k < run + h.x) { d = 0; kk = k - run; we = h.x; }
-                    else if (k < run + h.x + h.y) { d = 1; kk = k - run - h.x; we = h.y; }
-                    else if (k < run + h.x + h.y + h.z) { d = 2; kk = k - run - h.x - h.y; we = h.z; }
-                    else { kk = k - run - h.x - h.y - h.z; }
-                    sc->sel_digit = 4 * L + d;
-                    sc->sel_k = kk;
-                    sc->sel_weq = we;
+            if ((W & 1) && t == 0) lwin[W - 1] = wr[W - 1];
+        } else {
+            for (int j = t; j < W; j += kGvThreads) lwin[j] = wr[j];
+        }
+        __syncthreads();
+        // ---- 2. run values (np.mean of the covering windows: numpy's pairwise sum / count); min / max / NaN
+        int nanl = 0;
+        double mn = __builtin_inf(), mx = -__builtin_inf();
+        for (int r0 = t; r0 < R; r0 += UR * kGvThreads) {
+            uint32_t pk[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) pk[u] = r0 + u * kGvThreads < R ? run_pk[r0 + u * kGvThreads] : 0u;
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int r = r0 + u * kGvThreads;
+                if (r < R) {
+                    const int cnt = (int)(pk[u] >> 16);
+                    const double v = gv_numpy_sum(lwin + (pk[u] & 0xffffu), cnt) / (double)cnt;
+                    val[r] = v;
+                    nanl |= (v != v);
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
                 }
             }
-            __syncthreads();
-            prefix |= (unsigned long long)(unsigned)sc->sel_digit << sh;
-            k = sc->sel_k;
-            weq = sc->sel_weq;
-            // (no third barrier: the next pass writes hist[] -- read by wavefront 0 before the barrier above -- and
-            // sel_* only after its own second barrier)
         }
-        const double v1 = from_ordered_key(prefix);
-        double v2 = v1;
+        mn = wave_min_dpp(mn);
+        mx = wave_max_dpp(mx);
+        __syncthreads();  // windows dead: the scratch may be written
+        if (t == 0) {
+            sc->anynan = 0;
+            sc->found2 = 0;
+        }
+        if (lane == 0) {
+            sc->red[0][wave] = mn;
+            sc->red[1][wave] = mx;
+        }
+        __syncthreads();
+        if (nanl) sc->anynan = 1;  // benign race
+        double lo = sc->red[0][0], hi = sc->red[1][0];
+#pragma unroll
+        for (int i = 1; i < kGvWaves; ++i) {
+            lo = sc->red[0][i] < lo ? sc->red[0][i] : lo;
+            hi = sc->red[1][i] > hi ? sc->red[1][i] : hi;
+        }
+        __syncthreads();
         const bool anynan = sc->anynan != 0;
-        if (k2 != k1 && !(k + 1 < weq)) {
-            // rank k2 is the smallest value above v1
-            double mn = __builtin_inf();
-            for (int r = t; r < R; r += kGvThreads) {
-                const double v = val[r];
-                if (ordered_key(v) > prefix && v < mn) mn = v;
+        // ---- 3. weighted median: rank k1 (and k2 = k1 + 1 for an even count) of the multiset {val[r] x mult[r]}
+        double v1 = lo, v2 = lo;
+        if (!anynan && R > 0) {
+            int below = 0;  // weight strictly below the current [lo, hi]
+            bool need2 = k2 != k1;
+            for (int level = 0; level < 64; ++level) {
+                if (!(hi > lo)) {  // every remaining element equals lo: ranks k1 (and k2 if it is inside) are lo
+                    v1 = lo;
+                    // weight of the elements equal to lo
+                    int w = 0;
+                    for (int r = t; r < R; r += kGvThreads) w += (val[r] == lo) ? (int)mult[r] : 0;
+                    w = wave_sum_i(w);
+                    if (lane == 0) sc->wsum[wave] = w;
+                    __syncthreads();
+                    int wt = 0;
+#pragma unroll
+                    for (int i = 0; i < kGvWaves; ++i) wt += sc->wsum[i];
+                    if (need2 && k2 - below < wt) {
+                        v2 = lo;
+                        need2 = false;
+                    }
+                    break;
+                }
+                // histogram of the elements in [lo, hi]
+                for (int i = t; i < kGvBins; i += kGvThreads) sc->hist[i] = 0u;
+                if (t == 0) sc->ncand = 0;
+                __syncthreads();
+                const double scale = (double)kGvBins / (hi - lo);
+                for (int r = t; r < R; r += kGvThreads) {
+                    const double v = val[r];
+                    if (v >= lo && v <= hi) {
+                        int b = (int)((v - lo) * scale);
+                        b = b > kGvBins - 1 ? kGvBins - 1 : b;
+                        atomicAdd(&sc->hist[b], (unsigned)mult[r]);
+                    }
+                }
+                __syncthreads();
+                // the bin of rank k1 - below: every thread sums its four bins, wavefront scan, wavefront totals
+                const int kk = k1 - below;
+                const uint4 h = reinterpret_cast<const uint4*>(sc->hist)[t];
+                const int c = (int)((h.x + h.y) + (h.z + h.w));
+                const int incl = wave_scan_dpp(c);
+                if (lane == 63) sc->wsum[wave] = incl;
+                __syncthreads();
+                int wbase = 0;
+#pragma unroll
+                for (int i = 0; i < kGvWaves; ++i) wbase += i < wave ? sc->wsum[i] : 0;
+                const int excl = wbase + incl - c;
+                if (kk >= excl && kk < excl + c) {  // exactly one thread
+                    int run = excl, d = 3;
+                    if (kk < run + (int)h.x) d = 0;
+                    else if (kk < run + (int)(h.x + h.y)) { d = 1; run += (int)h.x; }
+                    else if (kk < run + (int)(h.x + h.y + h.z)) { d = 2; run += (int)(h.x + h.y); }
+                    else run += (int)(h.x + h.y + h.z);
+                    sc->sel_bin = 4 * t + d;
+                    sc->sel_below = run;
+                }
+                __syncthreads();
+                const int sb = sc->sel_bin;
+                below += sc->sel_below;
+                // the elements of that bin: candidates (<= 64) or the next level's range
+                double bmn = __builtin_inf(), bmx = -__builtin_inf();
+                for (int r = t; r < R; r += kGvThreads) {
+                    const double v = val[r];
+                    if (v >= lo && v <= hi) {
+                        int b = (int)((v - lo) * scale);
+                        b = b > kGvBins - 1 ? kGvBins - 1 : b;
+                        if (b == sb) {
+                            const int idx = atomicAdd(&sc->ncand, 1);
+                            if (idx < kGvCand) {
+                                sc->cand_v[idx] = v;
+                                sc->cand_w[idx] = (int)mult[r];
+                            }
+                            bmn = v < bmn ? v : bmn;
+                            bmx = v > bmx ? v : bmx;
+                        }
+                    }
+                }
+                bmn = wave_min_dpp(bmn);
+                bmx = wave_max_dpp(bmx);
+                if (lane == 0) {
+                    sc->red[0][wave] = bmn;
+                    sc->red[1][wave] = bmx;
+                }
+                __syncthreads();
+                const int nc = sc->ncand;
+                if (nc <= kGvCand) {
+                    if (wave == 0) {
+                        // exact ranks inside the bin: weight below / equal for every candidate
+                        const double mine = lane < nc ? sc->cand_v[lane] : __builtin_inf();
+                        int wl = 0, we = 0;
+                        for (int q = 0; q < nc; ++q) {
+                            const double o = sc->cand_v[q];
+                            const int w = sc->cand_w[q];
+                            wl += o < mine ? w : 0;
+                            we += o == mine ? w : 0;
+                        }
+                        const int ka = k1 - below, kb = k2 - below;
+                        if (lane < nc && ka >= wl && ka < wl + we) sc->v1 = mine;  // (equal candidates write the same value)
+                        if (lane < nc && kb >= wl && kb < wl + we) {
+                            sc->v2 = mine;
+                            sc->found2 = 1;
+                        }
+                    }
+                    __syncthreads();
+                    v1 = sc->v1;
+                    if (need2 && sc->found2) {
+                        v2 = sc->v2;
+                        need2 = false;
+                    }
+                    break;
+                }
+                lo = sc->red[0][0];
+                hi = sc->red[1][0];
+#pragma unroll
+                for (int i = 1; i < kGvWaves; ++i) {
+                    lo = sc->red[0][i] < lo ? sc->red[0][i] : lo;
+                    hi = sc->red[1][i] > hi ? sc->red[1][i] : hi;
+                }
+                __syncthreads();
             }
-            mn = wave_min_dpp(mn);
-            if (lane == 0) sc->vmin[wave] = mn;
-            __syncthreads();
-            v2 = sc->vmin[0];
-            for (int i = 1; i < 4; ++i) v2 = sc->vmin[i] < v2 ? sc->vmin[i] : v2;
+            if (need2) {
+                // rank k2 is the smallest value above v1
+                double m2 = __builtin_inf();
+                for (int r = t; r < R; r += kGvThreads) {
+                    const double v = val[r];
+                    if (v > v1 && v < m2) m2 = v;
+                }
+                m2 = wave_min_dpp(m2);
+                __syncthreads();
+                if (lane == 0) sc->red[0][wave] = m2;
+                __syncthreads();
+                v2 = sc->red[0][0];
+#pragma unroll
+                for (int i = 1; i < kGvWaves; ++i) v2 = sc->red[0][i] < v2 ? sc->red[0][i] : v2;
+            } else if (k2 == k1) {
+                v2 = v1;
+            }
         }
         const double med = anynan ? nan : ((k1 == k2) ? v1 : (v1 + v2) / 2.0);
         // ---- 4. the output row, input-column order: value - median, noise filter, NaN where there is no value
         const bool has_thr = thr != nullptr;
         const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
         double* orow = out + cell * ldg;
+        const auto value_of = [&](int rx) {
+            double a = rx >= 0 ? val[rx] - med : nan;
+            if (has_thr && fabs(a) < th) a = 0.0;
+            return a;
+        };
         if (vec2) {
+            // a lane = two adjacent columns, the lanes of a wavefront = 1 KB of the row: every store instruction writes
+            // whole lines (eight columns per lane -- 64-byte runs, lane stride 64 B -- measured 2.4 x slower: partial lines)
             typedef double f64x2_t __attribute__((ext_vector_type(2)));
-            const int n2 = n_cols & ~1;
-            for (int c = 2 * t; c < n2; c += 2 * kGvThreads) {
-                const int2 rr = *reinterpret_cast<const int2*>(col_run + c);
-                double a = rr.x >= 0 ? val[rr.x] - med : nan;
-                double b = rr.y >= 0 ? val[rr.y] - med : nan;
-                if (has_thr) {
-                    if (fabs(a) < th) a = 0.0;
-                    if (fabs(b) < th) b = 0.0;
+            const int n2 = (n_cols + 1) / 2;  // pairs (the table is padded with -1)
+            const uint32_t* cr2 = reinterpret_cast<const uint32_t*>(col_run16);
+            for (int g0 = t; g0 < n2; g0 += UC * kGvThreads) {
+                uint32_t rr[UC];
+#pragma unroll
+                for (int u = 0; u < UC; ++u) rr[u] = g0 + u * kGvThreads < n2 ? cr2[g0 + u * kGvThreads] : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int c = 2 * (g0 + u * kGvThreads);
+                    if (c >= n_cols) continue;
+                    const double a = value_of((int)(short)(rr[u] & 0xffffu)), b = value_of((int)(short)(rr[u] >> 16));
+                    if (c + 2 <= n_cols) {
+                        const f64x2_t q = {a, b};
+                        __builtin_nontemporal_store(q, reinterpret_cast<f64x2_t*>(orow + c));
+                    } else {
+                        orow[c] = a;
+                    }
                 }
-                const f64x2_t q = {a, b};
-                __builtin_nontemporal_store(q, reinterpret_cast<f64x2_t*>(orow + c));
-            }
-            if ((n_cols & 1) && t == 0) {
-                const int rx = col_run[n_cols - 1];
-                double a = rx >= 0 ? val[rx] - med : nan;
-                if (has_thr && fabs(a) < th) a = 0.0;
-                orow[n_cols - 1] = a;
             }
         } else {
-            for (int c = t; c < n_cols; c += kGvThreads) {
-                const int rx = col_run[c];
-                double a = rx >= 0 ? val[rx] - med : nan;
-                if (has_thr && fabs(a) < th) a = 0.0;
-                orow[c] = a;
-            }
+            for (int c = t; c < n_cols; c += kGvThreads) orow[c] = value_of((int)col_run16[c]);
         }
     }
 }

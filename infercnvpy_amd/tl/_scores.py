@@ -39,19 +39,26 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
         x = np.ascontiguousarray(np.asarray(x), dtype=np.float32)
         row_abs = _engine.row_abs_sum(torch.from_numpy(x).cuda())
 
-    # group sums on the device in a fixed order (icv_group_sums): K sums and counts come back, and a host X_cnv and a
-    # device-resident one give the same bits
+    # group sums on the device in a fixed order (icv_group_sums): K sums come back, and a host X_cnv and a
+    # device-resident one give the same bits.  Labels -> group codes in one vectorised pass (first-appearance order =
+    # the reference's `labels.unique()` loop, :65); the counts are the host's own bincount
+    import pandas as pd
+
     labels = adata.obs[groupby]
-    values = np.asarray(labels.values if hasattr(labels, "values") else labels)
-    clusters = list(labels.unique())
-    codes = np.full(values.shape[0], -1, dtype=np.int32)
-    for gi, cluster in enumerate(clusters):
-        codes[values == cluster] = gi
-    sums, counts = _engine.group_sums(row_abs, codes, len(clusters))
-    cluster_score = {cluster: np.float64(sums[gi] / (int(counts[gi]) * n_win)) for gi, cluster in enumerate(clusters)}
+    codes, uniques = pd.factorize(np.asarray(labels.values if hasattr(labels, "values") else labels),
+                                  use_na_sentinel=True)
+    codes = codes.astype(np.int32, copy=False)
+    n_groups = len(uniques)
+    sums, _ = _engine.group_sums(row_abs, codes, n_groups, want_counts=False)
+    counts = np.bincount(codes[codes >= 0], minlength=max(n_groups, 1))[:n_groups]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        scores = sums / (counts.astype(np.float64) * n_win)
+    pos = {u: gi for gi, u in enumerate(uniques)}
+    # (a missing label is a "cluster" of the reference's loop too: no row equals it, its score is nan)
+    cluster_score = {c: (np.float64(scores[pos[c]]) if c in pos else np.float64("nan")) for c in labels.unique()}
 
     if inplace:
-        adata.obs[key_added] = np.array([cluster_score[c] for c in adata.obs[groupby]])
+        adata.obs[key_added] = np.where(codes >= 0, scores[np.maximum(codes, 0)] if n_groups else np.nan, np.nan)
     else:
         return cluster_score
 

@@ -473,3 +473,52 @@ def test_chained_means_over_ranks_are_numpys_bits(world, members, t_groups):
         p.join(timeout=60)
     for rank, status, _ in results:
         assert status == "ok", f"rank {rank}: {status}"
+
+
+def _exact_blocks_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import exact_chain_proto as P
+
+        # config 3's geometry: 20 000 genes, shards aligned to 5000-cell chunks, config 2's generator
+        n_obs, n_genes = 5000 * world, 20000
+        bounds = icd.shard_bounds(n_obs, world, 5000)
+        r0, r1 = bounds[rank]
+        X_local = np.vstack([cases.synthetic_expr(5000, n_genes, seed=300 + k) for k in range(r0 // 5000, r1 // 5000)])
+        got, stats = P.sharded_chain(X_local, dist, block=64)
+        # the chained form (what dist.reference_means_chained evaluates): one sequential chain over ALL rows
+        # (numpy adds a C-contiguous matrix row by row in float32: np.add.reduce IS that chain, tests/test_exact_chain_proto.py)
+        want = np.add.reduce(np.vstack([cases.synthetic_expr(5000, n_genes, seed=300 + k) for k in range(n_obs // 5000)]),
+                             axis=0)
+        assert want.dtype == np.float32
+        np.testing.assert_array_equal(got.view(np.int32), want.view(np.int32))
+        q.put((rank, "ok", stats))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_chain_by_blocks_over_ranks_is_the_chained_result(world):
+    """the block-wise exact float32 chain (tests/exact_chain_proto.py) over row shards at config 3's
+    geometry: every rank computes its block records CONCURRENTLY from the all-gathered float64 totals, only a scan travels
+    rank to rank -- and the result is the chained means' bits (numpy's order over the whole matrix).  Ranks after the
+    first replay well under 2 % of their (block, column) pairs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_blocks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, stats in results:
+        assert status == "ok", f"rank {rank}: {status}"
+        if rank > 0:
+            assert stats["replayed"] < 0.02 * stats["blocks"], stats

@@ -127,6 +127,26 @@ def test_csr_queue_kernel_edges(n, g, density):
     np.testing.assert_array_equal(_gpu_means(X, labels, ["t", "n"], pieces=2), _oracle_means(X, labels, ["t", "n"]))
 
 
+@pytest.mark.parametrize("pieces", [2, 4, 8, 16])
+def test_csr_queue_kernel_any_lanes_per_row_gives_scipys_bits(pieces, monkeypatch):
+    """k_colchain_csrq<PIECES>: 8 / 16 / 32 / 64 entry slots per row and tile (rounds of 64 / 64 / 32 / 16 rows); the
+    launcher picks from the density, ICV_CHAIN_PIECES forces one.  Every shape gives scipy's bits whatever the density --
+    rows beyond the slots take the guarded loads -- including round edges of the short rounds and float64."""
+    from infercnvpy_amd import _lib
+
+    monkeypatch.setenv("ICV_CHAIN_PIECES", str(pieces))
+    _lib.load().icv_developer_knobs_reload()
+    for n, g, density, dtype in ((2000, 20000, 0.14, np.float32), (1000, 20000, 0.02, np.float32),
+                                 (700, 3001, 0.4, np.float32), (97, 96, 1.0, np.float32), (33, 40, 0.6, np.float64),
+                                 (1500, 9000, 0.21, np.float64), (17, 129, 0.9, np.float32)):
+        X = sp.csr_matrix(_expr(n, g, seed=n + g + pieces, dtype=dtype, density=density))
+        np.testing.assert_array_equal(_gpu_means(X), _oracle_means(X))
+        labels = np.array(["n", "t"])[np.random.RandomState(2).randint(0, 2, n)]
+        np.testing.assert_array_equal(_gpu_means(X, labels, ["t", "n"], pieces=2), _oracle_means(X, labels, ["t", "n"]))
+    monkeypatch.delenv("ICV_CHAIN_PIECES")
+    _lib.load().icv_developer_knobs_reload()
+
+
 def test_csr_integer_counts_and_long_rows():
     rs = np.random.RandomState(3)
     Xi = rs.poisson(0.3, (900, 3000)).astype(np.int64)
