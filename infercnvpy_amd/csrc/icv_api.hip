@@ -113,6 +113,7 @@ struct icv_plan_s {
     int32_t* d_gv_mult = nullptr;   //               genes per run
     int16_t* d_gv_col16 = nullptr;  //               input column -> run or -1, padded to a multiple of 8 columns
     bool gv_fused_ok = false;
+    int gv_mult_bytes = 2;  // bytes per run length in the kernel's LDS (1 where every run has at most 255 genes)
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
     int* d_row_count = nullptr;
     int64_t row_list_cap = 0;
@@ -282,6 +283,9 @@ int ensure_device(icv_plan_t pl) {
         std::vector<int16_t> c16(((size_t)p.n_cols_all + 7) / 8 * 8, (int16_t)-1);
         for (int c = 0; c < p.n_cols_all && ok; ++c) c16[c] = (int16_t)p.gv_col_run[c];
         pl->gv_fused_ok = ok;
+        pl->gv_mult_bytes = 1;
+        for (int32_t v : p.gv_run_mult)
+            if (v > 255) pl->gv_mult_bytes = 2;
         HIP_TRY(up(pk.data(), pk.size() * 4, (void**)&pl->d_gv_pk));
         HIP_TRY(up(p.gv_run_mult.data(), p.gv_run_mult.size() * 4, (void**)&pl->d_gv_mult));
         HIP_TRY(up(c16.data(), c16.size() * 2, (void**)&pl->d_gv_col16));
@@ -980,9 +984,11 @@ int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double
                            lt_b.as<uint16_t>(), L.n_lines, esz_shift_q, L.grid, bounds_b.as<uint32_t>());
         typedef void (*kq_t)(const T*, const int64_t*, const int32_t*, int64_t, const int32_t*, int64_t, int, int, int,
                              const uint16_t*, T, int, T*);
-        // lanes per row (= entry slots / 4) from the entries a row has in ONE tile: mean of the widest tile -- from the
-        // caller's row-length hint (icv_matrix._pad: the length most rows stay under) where there is one -- plus three
-        // sigma of a Poisson count.  Rows beyond the slots take the guarded loads: any choice gives the same bits.
+        // lanes per row (= entry slots / 4) from the mean number of entries a row has in the WIDEST tile (from the
+        // caller's row-length hint, icv_matrix._pad: the length most rows stay under, where there is one).  Measured on
+        // 500 000 x 20 000 (profiles/r06_csr_means_density.txt): 16 slots up to ~8 entries per row and tile (beyond, too
+        // many rounds hold a row past the slots, whose guarded loads wait behind the loads in flight), 32 slots to ~28.
+        // Rows beyond the slots take the guarded loads: any choice gives the same bits.
         int pieces = 4;
         {
             const double rows_all = m->n_rows > 0 ? (double)m->n_rows : 1.0;
@@ -990,8 +996,7 @@ int colchain_csr(const icv_matrix* m, const int32_t* rows, int64_t n_sel, double
             if (m->_pad > 0 && (double)m->_pad > per_row) per_row = (double)m->_pad;
             const int tile_lines = (L.n_lines + L.grid - 1) / L.grid;
             const double mu = per_row * (double)(tile_lines * (128 / (int)sizeof(T))) / (double)(m->n_cols > 0 ? m->n_cols : 1);
-            const double need = mu + 3.0 * std::sqrt(mu);
-            pieces = need <= 8.0 ? 2 : need <= 16.0 ? 4 : need <= 32.0 ? 8 : 16;
+            pieces = mu <= 2.0 ? 2 : mu <= 8.5 ? 4 : mu <= 28.0 ? 8 : 16;
             const int forced = knobs().chain_pieces;
             if (forced == 2 || forced == 4 || forced == 8 || forced == 16) pieces = forced;
         }
@@ -1451,7 +1456,7 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
     const icv::Plan& p = pl->p;
     if (n < 1) return ICV_OK;
     const int W = p.W, n_cov = (int)p.cov_col.size(), R = (int)p.gv_run_j0.size();
-    const size_t lds = icv::gv_lds_bytes(W, R);
+    const size_t lds = icv::gv_lds_bytes(W, R, pl->gv_mult_bytes);
     if (lds <= (size_t)icv::kLdsLimit && pl->gv_fused_ok && !knobs().no_gene_fused) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_gene_fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1461,7 +1466,7 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
         if (grid > n) grid = n;
         hipLaunchKernelGGL(icv::k_gene_fused, dim3((unsigned)grid), dim3(icv::kGvThreads), lds, st, win, ldw, n, W,
                            pl->d_gv_pk, pl->d_gv_mult, R, n_cov, pl->d_gv_col16, p.n_cols_all, thr,
-                           chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg);
+                           chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg, pl->gv_mult_bytes);
         HIP_TRY(hipGetLastError());
         return ICV_OK;
     }

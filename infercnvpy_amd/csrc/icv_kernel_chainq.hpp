@@ -306,51 +306,74 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                 a_rp = indptr[row];
             }
         };
-        const auto fetch_b = [&]() {
-            b_base = a_rp + (int64_t)a_lo;
-            b_cnt = (int)(a_hi - a_lo);
+        // stage B of the NEXT round, split so that its loads fly behind the current round's work (round 6; the wavefront
+        // used to issue them after the round's publication and to need them at once: every round paid one exposed
+        // memory latency -- 3 us per wavefront and round whatever the density, 1.6 of the 3.15 ms at config 4):
+        //   next_addr  (after step 1 of the current round: its index registers are dead) addresses + INDEX loads,
+        //   next_vals  (after step 5: its value registers are dead) VALUE loads, and the next round becomes current.
+        constexpr bool EARLY = sizeof(T) == 4 || PIECES == 2;
+        int64_t n_base = 0;
+        int n_cnt = 0, n_from = 0;
+        bool n_more = false, n_slow = false;
+        int n_nv[NVEC];
+        unsigned n_off[NVEC];
+        __amdgpu_buffer_rsrc_t n_vrs = make_rsrc(vals, 0u);
+        const auto next_addr = [&]() {
+            n_base = a_rp + (int64_t)a_lo;
+            n_cnt = (int)(a_hi - a_lo);
             // range-checked 16-byte loads relative to the round's first entry (rows ascend, so it is the first row
             // with entries): lanes without entries and reads past the end of the arrays return zeros
-            const unsigned long long has = __builtin_amdgcn_ballot_w64(b_cnt > 0);
+            const unsigned long long has = __builtin_amdgcn_ballot_w64(n_cnt > 0);
             const int first = has ? (int)__builtin_ctzll(has) : 0;
-            int64_t e_first = ((int64_t)__builtin_amdgcn_readlane((int)(b_base >> 32), first) << 32) |
-                              (unsigned)__builtin_amdgcn_readlane((int)b_base, first);
+            int64_t e_first = ((int64_t)__builtin_amdgcn_readlane((int)(n_base >> 32), first) << 32) |
+                              (unsigned)__builtin_amdgcn_readlane((int)n_base, first);
             if (!has) e_first = e_end;
             const int64_t left = e_end - e_first;
             const unsigned rec = (unsigned)(left < (int64_t)far_limit + SLOTS ? left : (int64_t)far_limit + SLOTS);
             const __amdgpu_buffer_rsrc_t i_rs = make_rsrc(indices + e_first, rec * 4u);
-            const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(vals + e_first, rec * (unsigned)sizeof(T));
-            const int64_t rel64 = b_base - e_first;
-            const bool far = b_cnt > 0 && rel64 >= (int64_t)far_limit;
-            b_slow = far || b_cnt > SLOTS;
-            b_from = far ? 0 : SLOTS;
-            b_more = __builtin_amdgcn_ballot_w64(b_slow) != 0ull;
-            const int rel = far || b_cnt <= 0 ? -1 : (int)rel64;
+            n_vrs = make_rsrc(vals + e_first, rec * (unsigned)sizeof(T));
+            const int64_t rel64 = n_base - e_first;
+            const bool far = n_cnt > 0 && rel64 >= (int64_t)far_limit;
+            n_slow = far || n_cnt > SLOTS;
+            n_from = far ? 0 : SLOTS;
+            n_more = __builtin_amdgcn_ballot_w64(n_slow) != 0ull;
+            const int rel = far || n_cnt <= 0 ? -1 : (int)rel64;
 #pragma unroll
             for (int v = 0; v < NVEC; ++v) {
                 const int src = RPV * v + sub;
-                const int cnt_v = __shfl(b_cnt, src);
+                const int cnt_v = __shfl(n_cnt, src);
                 const int rel_v = __shfl(rel, src);
                 int nv = cnt_v - 4 * piece;
                 nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);
                 if (rel_v < 0) nv = 0;
-                b_nv[v] = nv;
-                const unsigned off = nv > 0 ? (unsigned)(rel_v + 4 * piece) : 0x3fffffffu;  // (no entries: out of range)
-                b_idx[v] = __builtin_amdgcn_raw_buffer_load_b128(i_rs, off * 4u, 0, 0);
+                n_nv[v] = nv;
+                n_off[v] = nv > 0 ? (unsigned)(rel_v + 4 * piece) : 0x3fffffffu;  // (no entries: out of range)
+                b_idx[v] = __builtin_amdgcn_raw_buffer_load_b128(i_rs, n_off[v] * 4u, 0, 0);
+            }
+        };
+        const auto next_vals = [&]() {
+#pragma unroll
+            for (int v = 0; v < NVEC; ++v) {
                 if constexpr (sizeof(T) == 4) {
-                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(v_rs, off * 4u, 0, 0);
+                    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(n_vrs, n_off[v] * 4u, 0, 0);
                     b_val[v][0] = __uint_as_float(w.x), b_val[v][1] = __uint_as_float(w.y);
                     b_val[v][2] = __uint_as_float(w.z), b_val[v][3] = __uint_as_float(w.w);
                 } else {
-                    const unsigned offb = nv > 0 ? off * 8u : 0xfffffff0u;
-                    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(v_rs, offb, 0, 0);
-                    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(v_rs, offb, 16, 0);
+                    const unsigned offb = n_nv[v] > 0 ? n_off[v] * 8u : 0xfffffff0u;
+                    const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(n_vrs, offb, 0, 0);
+                    const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(n_vrs, offb, 16, 0);
                     b_val[v][0] = __hiloint2double((int)w0.y, (int)w0.x);
                     b_val[v][1] = __hiloint2double((int)w0.w, (int)w0.z);
                     b_val[v][2] = __hiloint2double((int)w1.y, (int)w1.x);
                     b_val[v][3] = __hiloint2double((int)w1.w, (int)w1.z);
                 }
+                b_nv[v] = n_nv[v];
             }
+            b_base = n_base;
+            b_cnt = n_cnt;
+            b_from = n_from;
+            b_slow = n_slow;
+            b_more = n_more;
         };
         // round k: row masks -> LDS rows needed -> allocation in round order -> zero + scatter -> publication in round
         // order.  The per-entry code has NO branches: a lane without an entry ORs into the trash word behind the masks
@@ -378,6 +401,11 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                     for (int j = b_from; j < b_cnt; ++j)
                         __hip_atomic_fetch_or(cm + (indices[b_base + j] - c0), 1ull << lane, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            // (the index registers are dead: the next round's addresses and index loads, the table words of the round after it)
+            if constexpr (EARLY) {
+                next_addr();
+                fetch_a(k + 2 * kChLoaders);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // 2. LDS rows of the round = the longest column queue
@@ -437,6 +465,8 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                     }
                 }
             }
+            // (the value registers are dead: the next round's value loads; it becomes the current round)
+            if constexpr (EARLY) next_vals();
             // 6. masks back to zero for this wavefront's next round
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(cm) + lane * 16) = make_uint4(0, 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows are complete)
@@ -446,16 +476,18 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
                 ctl[4] = start + (unsigned)(pad + n);
                 q_store(ctl + 3, k + 1u);
             }
+            if constexpr (!EARLY) {  // (float64 at 16+ slots per row: the early loads' extra registers would spill)
+                next_addr();
+                next_vals();
+                fetch_a(k + 2 * kChLoaders);
+            }
         };
         unsigned mine = (unsigned)wave;  // this wavefront's next round
         fetch_a(mine);
-        fetch_b();
+        next_addr();
+        next_vals();
         fetch_a(mine + kChLoaders);
-        for (; mine < n_rounds; mine += kChLoaders) {
-            write_round(mine);
-            fetch_b();
-            fetch_a(mine + 2 * kChLoaders);
-        }
+        for (; mine < n_rounds; mine += kChLoaders) write_round(mine);
     } else {
         const int col = lane * 8 < row_bytes ? c0 + lane * CPL : n_cols;
         lane_t a;

@@ -41,11 +41,12 @@ struct GvScratch {
 
 // (the tables need W <= 65 535 windows, run lengths and window counts that fit 16 bits, fewer than 32 768 runs)
 // dynamic LDS: win[W] (float64; dead after the run values: the scratch aliases it) | val[R] | mult[R] (16-bit)
-__host__ __device__ inline size_t gv_lds_bytes(int W, int R) {
+// (run lengths as bytes where no run is longer than 255 genes: 4 KB less at 4 000 runs -- three workgroups per CU instead of two)
+__host__ __device__ inline size_t gv_lds_bytes(int W, int R, int mult_bytes = 2) {
     size_t w = (size_t)W * 8;
     if (w < sizeof(GvScratch)) w = sizeof(GvScratch);
     w = (w + 15) / 16 * 16;
-    return w + (size_t)R * 8 + ((size_t)R * 2 + 15) / 16 * 16;
+    return w + (size_t)R * 8 + ((size_t)R * mult_bytes + 15) / 16 * 16;
 }
 
 // numpy's float64 add.reduce of a[0..n) in LDS, n <= 128 inlined (the recursion of numpy_sum above that)
@@ -76,7 +77,8 @@ __device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
 __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     const double* __restrict__ win, int64_t ldw, int64_t n_rows, int W, const uint32_t* __restrict__ run_pk,
     const int32_t* __restrict__ run_mult, int R, int n_cov, const int16_t* __restrict__ col_run16, int n_cols,
-    const double* __restrict__ thr, int64_t chunksize, int64_t row_phase, double* __restrict__ out, int64_t ldg) {
+    const double* __restrict__ thr, int64_t chunksize, int64_t row_phase, double* __restrict__ out, int64_t ldg,
+    int mult_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     size_t woff = (size_t)W * 8;
     if (woff < sizeof(GvScratch)) woff = sizeof(GvScratch);
@@ -84,17 +86,23 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     double* lwin = reinterpret_cast<double*>(gsm);
     GvScratch* sc = reinterpret_cast<GvScratch*>(gsm);  // aliases the windows (used after they are dead)
     double* val = reinterpret_cast<double*>(gsm + woff);
-    unsigned short* mult = reinterpret_cast<unsigned short*>(gsm + woff + (size_t)R * 8);
+    unsigned short* mult16 = reinterpret_cast<unsigned short*>(gsm + woff + (size_t)R * 8);
+    unsigned char* mult8 = reinterpret_cast<unsigned char*>(mult16);
+    const bool m8 = mult_bytes == 1;
+    const auto mult_of = [&](int r) { return m8 ? (int)mult8[r] : (int)mult16[r]; };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int k1 = (n_cov - 1) / 2, k2 = n_cov / 2;
-    for (int i = t; i < R; i += kGvThreads) mult[i] = (unsigned short)run_mult[i];
+    for (int i = t; i < R; i += kGvThreads) {
+        if (m8) mult8[i] = (unsigned char)run_mult[i];
+        else mult16[i] = (unsigned short)run_mult[i];
+    }
     const bool vec2 = (ldg % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const bool win16 = (ldw % 2 == 0) && ((reinterpret_cast<uintptr_t>(win) & 15) == 0);
     const double nan = __builtin_nan("");
     constexpr int UW = 4;  // window loads (16 bytes) in flight per thread
     constexpr int UR = 4;  // run-table loads in flight per thread
     constexpr int UC = 8;  // column-table loads (2 columns each) in flight per thread
-
+    // (keeping the thread's 20 table words in registers for all cells of the workgroup made the compiler take 252 VGPRs)
     for (int64_t cell = blockIdx.x; cell < n_rows; cell += gridDim.x) {
         __syncthreads();  // the previous cell's output phase has read val[]; its scratch use is over
         // ---- 1. the cell's windows
@@ -167,7 +175,7 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
                     v1 = lo;
                     // weight of the elements equal to lo
                     int w = 0;
-                    for (int r = t; r < R; r += kGvThreads) w += (val[r] == lo) ? (int)mult[r] : 0;
+                    for (int r = t; r < R; r += kGvThreads) w += (val[r] == lo) ? mult_of(r) : 0;
                     w = wave_sum_i(w);
                     if (lane == 0) sc->wsum[wave] = w;
                     __syncthreads();
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
                     if (v >= lo && v <= hi) {
                         int b = (int)((v - lo) * scale);
                         b = b > kGvBins - 1 ? kGvBins - 1 : b;
-                        atomicAdd(&sc->hist[b], (unsigned)mult[r]);
+                        atomicAdd(&sc->hist[b], (unsigned)mult_of(r));
                     }
                 }
                 __syncthreads();
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
                             const int idx = atomicAdd(&sc->ncand, 1);
                             if (idx < kGvCand) {
                                 sc->cand_v[idx] = v;
-                                sc->cand_w[idx] = (int)mult[r];
+                                sc->cand_w[idx] = mult_of(r);
                             }
                             bmn = v < bmn ? v : bmn;
                             bmx = v > bmx ? v : bmx;
