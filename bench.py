@@ -731,6 +731,30 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
 
     leg("scores_and_gene_values", scores_and_gene_values)
 
+    # ---- the same step with adata.var in GENOME order ("benchmarks should report both orders"; BASELINE's
+    # configs are specified with a random var permutation = the worst case, real annotations are usually GTF-ordered):
+    # the plan detects consecutive input columns per block and k_smooth_x16<ORD> forms the block sums from the row
+    v_pos, _ = cases.position_ordered(v)
+    import pandas as _pd
+
+    var_pos = _pd.DataFrame({"chromosome": v_pos["chromosome"], "start": v_pos["start"], "end": v_pos["end"]},
+                            index=v_pos["names"])
+
+    def ordered_leg(X, cells, steps, label):
+        ad = SimpleAnnData(X, var=var_pos)
+        dt, roof, nnz = api_step(torch, _engine, ad, steps, 2, "dense", 100, 10, traffic_key=None)
+        plan = T._cached_plan(var_pos["chromosome"].to_numpy(), var_pos["start"].to_numpy(), 100, 10, ("chrX", "chrY"),
+                              torch.cuda.current_device())
+        roof["kernel"] = "k_smooth_x16<10,10,chunk moments,ORD> (dense fp32, window 100 / step 10, position-ordered columns)"
+        return {"workload": label, "var_order": "position", "kernel_id": int(plan.last_kernel()),
+                "ms_per_step": dt / steps * 1e3, "cells_per_s": cells / (dt / steps), "steps": steps, "x_cnv_nnz": nnz,
+                "roofline": roof}
+
+    leg("config2_position_ordered_var", lambda: ordered_leg(
+        synth_rows(torch, 0, CONFIG2_CELLS, G), CONFIG2_CELLS, 100,
+        "BASELINE config 2's matrix with adata.var in genome order (chromosomes one after the other, positions "
+        "ascending): one cnv.tl.infercnv(adata) call per step, HBM resident, reference = all-cell mean"))
+
     def one_million():
         X = synth_rows(torch, 0, CONFIG3_CELLS, G)
         leg_ = api_leg(SimpleAnnData(X, var=var), CONFIG3_CELLS, "dense", 100,
@@ -750,6 +774,10 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
                            "smooth_kernel_ms": roof["kernel_ms"], "roofline_frac": roof["frac"]}
         plan.close()
         leg_["scale_n1"] = scale
+        try:  # the same 1 M cells with position-ordered columns (sustained clocks)
+            leg_["position_ordered_var"] = ordered_leg(X, CONFIG3_CELLS, 3, "the same matrix, adata.var in genome order")
+        except Exception as e:
+            leg_["position_ordered_var"] = {"error": repr(e)}
         return leg_
 
     leg("config3_cells_on_one_gpu", one_million)
@@ -806,6 +834,14 @@ def _summary(result):
         out["ithcna_ms"] = r(g(sg, "ithcna", "ms_per_call"))
     elif "error" in sg:
         out["scores_and_gene_values_error"] = sg["error"][:200]
+    po = ex.get("config2_position_ordered_var") or {}
+    if "ms_per_step" in po:
+        out["position_ordered_ms_per_step"] = r(po["ms_per_step"])
+        out["position_ordered_kernel_ms"] = r(g(po, "roofline", "kernel_ms"))
+        out["position_ordered_roofline_frac"] = r(g(po, "roofline", "frac"))
+    po1 = c3.get("position_ordered_var") or {}
+    if "ms_per_step" in po1:
+        out["one_million_position_ordered_roofline_frac"] = r(g(po1, "roofline", "frac"))
     c5 = ex.get("config5") or {}
     if "roofline" in c5:
         out["config5_pdist_s"] = r(c5.get("pdist_stream_s"))
@@ -1025,6 +1061,7 @@ def main():
                            + ("applied while X_cnv is packed to device CSR (dist.run_shard(pack=True))" if not args.engine_step
                               else "applied in place (dist.run_shard)")),
             "io_dtype": "f32 matrix in, f32 x_res out",
+            "var_order": "random (BASELINE's worst case; extra.config2_position_ordered_var has the genome order)",
             "cells_total": n_total,
             "cells_per_gpu": [b - a for a, b in bounds],
             "n_windows": W,

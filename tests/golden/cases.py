@@ -40,6 +40,24 @@ def synthetic_var(genes_per_chrom, names=None, seed_start=0, seed_perm=1, permut
     return dict(chromosome=chrom, start=start, end=start + 1000, names=gene_names)
 
 
+def position_ordered(v, chrom_order=None):
+    """The same annotation with ``var`` in GENOME order (what a GTF-derived ``adata.var`` looks like): chromosomes one
+    after the other (``chrom_order``: list of names, default first appearance in natural order; genes without a
+    chromosome last), positions ascending inside each.  Returns (v_sorted, perm) with ``v_sorted[k] = v[k][perm]``."""
+    chrom, start = np.asarray(v["chromosome"], dtype=object), np.asarray(v["start"])
+    names = [c for c in dict.fromkeys(chrom.tolist()) if c is not None]
+    if chrom_order is None:
+        import re
+
+        chrom_order = sorted(names, key=lambda k: [int(x) if x.isdigit() else x.lower() for x in re.split("([0-9]+)", k)])
+    rank = {c: i for i, c in enumerate(chrom_order)}
+    key = np.array([rank.get(c, len(rank)) for c in chrom.tolist()])
+    perm = np.lexsort((start, key))
+    out = {k: (np.asarray(x, dtype=object)[perm] if k == "chromosome" else
+               ([x[i] for i in perm] if isinstance(x, list) else np.asarray(x)[perm])) for k, x in v.items()}
+    return out, perm
+
+
 def synthetic_expr(n_cells, n_genes, seed=2, dtype=np.float32, density_cut=0.5):
     """log1p-like expression: gamma(0.3, 1), entries < cut set to 0 (~19 % nnz).  SURVEY §8(d)."""
     rng = np.random.RandomState(seed)
