@@ -732,8 +732,9 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
     leg("scores_and_gene_values", scores_and_gene_values)
 
     # ---- the same step with adata.var in GENOME order ("benchmarks should report both orders"; BASELINE's
-    # configs are specified with a random var permutation = the worst case, real annotations are usually GTF-ordered):
-    # the plan detects consecutive input columns per block and k_smooth_x16<ORD> forms the block sums from the row
+    # configs are specified with a random var permutation = the worst case, real annotations are usually GTF-ordered).
+    # Both orders take the scatter form of k_smooth_x16: the variant that forms the block sums straight from an ordered
+    # row measured 2.2 x slower (profiles/r06_x16_position_ordered_experiment.txt)
     v_pos, _ = cases.position_ordered(v)
     import pandas as _pd
 
@@ -745,7 +746,7 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         dt, roof, nnz = api_step(torch, _engine, ad, steps, 2, "dense", 100, 10, traffic_key=None)
         plan = T._cached_plan(var_pos["chromosome"].to_numpy(), var_pos["start"].to_numpy(), 100, 10, ("chrX", "chrY"),
                               torch.cuda.current_device())
-        roof["kernel"] = "k_smooth_x16<10,10,chunk moments,ORD> (dense fp32, window 100 / step 10, position-ordered columns)"
+        roof["kernel"] = "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10, position-ordered columns)"
         return {"workload": label, "var_order": "position", "kernel_id": int(plan.last_kernel()),
                 "ms_per_step": dt / steps * 1e3, "cells_per_s": cells / (dt / steps), "steps": steps, "x_cnv_nnz": nnz,
                 "roofline": roof}

@@ -121,8 +121,7 @@ enum {
     ICV_KERNEL_WS_CSR = 3,  /* k_csr_prepare + k_smooth_ws: CSR float32, row rebuilt in LDS               */
     ICV_KERNEL_X16 = 4,     /* k_smooth_x16: dense float32, window 100 or 250 / step 10                   */
     ICV_KERNEL_SD = 5,      /* k_smooth_sd: CSR float32, block form, stored entries only (prefix sums)    */
-    ICV_KERNEL_SPLIT = 6,   /* chromosome groups (row larger than LDS) + median on float64 windows in HBM */
-    ICV_KERNEL_X16_ORDERED = 7 /* k_smooth_x16<ORD>: the same for position-ordered input columns (no row in LDS) */
+    ICV_KERNEL_SPLIT = 6    /* chromosome groups (row larger than LDS) + median on float64 windows in HBM */
 };
 int icv_plan_last_kernel(icv_plan_t plan, int32_t *h_kind);
 /* Host tables of the CSR stored-entries kernel (k_smooth_se), for tests that restate its arithmetic on the CPU:

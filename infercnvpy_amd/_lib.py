@@ -21,7 +21,7 @@ ICV_FLAG_TRUNC_TO_INT = 1
 ICV_FLAG_ROUND_F32 = 2
 ICV_FLAG_NO_APPLY = 4
 (ICV_KERNEL_NONE, ICV_KERNEL_GENERIC, ICV_KERNEL_WS, ICV_KERNEL_WS_CSR, ICV_KERNEL_X16, ICV_KERNEL_SD,
- ICV_KERNEL_SPLIT, ICV_KERNEL_X16_ORDERED) = range(8)
+ ICV_KERNEL_SPLIT) = range(7)
 
 # every symbol include/infercnv_hip.h declares
 EXPORTS = (

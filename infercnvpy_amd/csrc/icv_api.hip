@@ -57,7 +57,7 @@ int fail(int code, const std::string& msg) {
 // changes them calls icv_developer_knobs_reload().
 struct Knobs {
     bool force_generic, no_x16, no_sd, phase_profile, ward_in_place, no_mask_ring, no_fill_ring, no_chain_queues, se_maxw4,
-         no_gene_fused, no_xo;
+         no_gene_fused;
     int wgs_per_cu;        // 0 = not set
     int chain_far;         // ICV_CHAIN_FAR: entries a buffer offset may span in k_colchain_csrq (tests: a small value)
     int chain_pieces;      // ICV_CHAIN_PIECES: lanes per row of k_colchain_csrq (2 / 4 / 8 / 16; 0 = from the density)
@@ -73,7 +73,6 @@ struct Knobs {
         no_chain_queues = std::getenv("ICV_NO_CHAIN_QUEUES") != nullptr;
         se_maxw4 = std::getenv("ICV_SE_MAXW4") != nullptr;
         no_gene_fused = std::getenv("ICV_NO_GENE_FUSED") != nullptr;  // gene values through the three round-1 kernels
-        no_xo = std::getenv("ICV_NO_XO") != nullptr;  // position-ordered input through the scatter form of k_smooth_x16
         const char* e = std::getenv("ICV_WGS_PER_CU");
         wgs_per_cu = e ? std::atoi(e) : 0;
         e = std::getenv("ICV_CHAIN_FAR");
@@ -131,7 +130,6 @@ struct icv_plan_s {
     int64_t hb_stats_cap = 0;        // in rows
     uint16_t* d_dst16 = nullptr;
     uint32_t* d_x16_wdesc = nullptr;
-    uint32_t* d_xo_desc = nullptr;  // k_smooth_x16<ORD> (position-ordered input columns)
     int32_t* d_blk_g0 = nullptr;  // per block: first-gene offset inside its chromosome (k_se_wtab)
     uint32_t *d_se_w0 = nullptr, *d_se_w1 = nullptr;   // k_smooth_se (plan: se_window_words)
     void* d_zrow = nullptr;  // CSR workspace: padded row, sized for float64
@@ -294,7 +292,6 @@ int ensure_device(icv_plan_t pl) {
     }
     HIP_TRY(up(p.dst16.data(), p.dst16.size() * 2, (void**)&pl->d_dst16));
     HIP_TRY(up(p.x16_wdesc.data(), p.x16_wdesc.size() * 4, (void**)&pl->d_x16_wdesc));
-    HIP_TRY(up(p.xo_desc.data(), p.xo_desc.size() * 4, (void**)&pl->d_xo_desc));
     HIP_TRY(up(p.blk_g0.data(), p.blk_g0.size() * 4, (void**)&pl->d_blk_g0));
     HIP_TRY(up(p.se_w0.data(), p.se_w0.size() * 4, (void**)&pl->d_se_w0));
     HIP_TRY(up(p.se_w1.data(), p.se_w1.size() * 4, (void**)&pl->d_se_w1));
@@ -416,8 +413,6 @@ int fill_params(icv_plan_t pl, const icv_matrix* m, const void* ref_lo, const vo
     K.pad_idx = pl->d_pad;
     K.w_pack = pl->d_wpack;
     K.x16_wdesc = pl->d_x16_wdesc;
-    K.xo_desc = pl->d_xo_desc;
-    K.xo_s01_bytes = p.xo_s01_bytes;
     K.blk_g0 = pl->d_blk_g0;
     K.x16_half = p.x16_half;
     K.n_pad = (int32_t)p.pad_idx.size();
@@ -710,7 +705,6 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
     // dense float32, one reference row, window 100 / step 10 or window 250 / step 10 geometry: the 16-wavefront
     // kernel, one 1024-thread workgroup per CU (ICV_NO_X16=1: developer knob, previous generation)
     void (*xk)(const icv::KParams) = nullptr;
-    bool ordered = false;
     if (!csr && p.x16_ok && !K.bounded && !knobs().no_x16) {
         if (p.step != 10)
             xk = nullptr;  // the instantiations below assume step 10 (blocks between adjacent windows)
@@ -722,24 +716,18 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
             xk = K.win_out ? icv::k_smooth_x16<5, 50, 2, true, 1024, false, true>
                            : (K.chunk_part ? icv::k_smooth_x16<5, 50, 2, true, 1024, false>
                                            : icv::k_smooth_x16<5, 50, 2, false, 1024, false>);
-        // position-ordered input columns (plan: xo_ok): {S0,S1} from the genes in registers, no row in LDS
-        if (xk && p.xo_ok && K.chunk_part && !K.win_out && !knobs().no_xo) {
-            xk = (p.B == 10) ? icv::k_smooth_x16<10, 10, 1, true, 4096, true, false, true>
-                             : icv::k_smooth_x16<5, 50, 2, true, 1024, true, false, true>;
-            ordered = true;
-        }
     }
     // float64 windows requested (calculate_gene_values): only the x16 instantiations write them, in chunk-moment mode;
     // every other geometry takes the generic kernel (ONE smoothing pass either way)
     if (K.win_out && (!xk || !K.chunk_part)) return -1;
     if (xk) {
         icv::KParams X = K;
-        X.win_off = ordered ? 0 : p.x16_s01_off;
-        X.hist_off = ordered ? p.xo_hist_off : p.x16_hist_off;
-        X.scratch_off = ordered ? p.xo_scratch_off : p.x16_scratch_off;
+        X.win_off = p.x16_s01_off;
+        X.hist_off = p.x16_hist_off;
+        X.scratch_off = p.x16_scratch_off;
         int64_t gx = pl->n_cu;
         if (gx > K.n_rows) gx = K.n_rows;
-        rc = run_kernel(xk, gx, ordered ? p.xo_lds : p.x16_lds, X, st, icv::XT);
+        rc = run_kernel(xk, gx, p.x16_lds, X, st, icv::XT);
         if (kernel_done && !rc) HIP_TRY(hipEventRecord(kernel_done, st));
         if (rc) return rc;
         if (!K.chunk_part)
@@ -753,7 +741,7 @@ int launch_smooth_fast(icv_plan_t pl, icv::KParams K, hipStream_t st, bool csr, 
         hipLaunchKernelGGL(icv::k_stats_finish, dim3((unsigned)((K.n_rows + 255) / 256)), dim3(256), 0, st,
                            K.cell_part, K.n_rows, K.cell_stats);
     }
-    pl->last_kernel = xk ? (ordered ? ICV_KERNEL_X16_ORDERED : ICV_KERNEL_X16) : (csr ? ICV_KERNEL_WS_CSR : ICV_KERNEL_WS);
+    pl->last_kernel = xk ? ICV_KERNEL_X16 : (csr ? ICV_KERNEL_WS_CSR : ICV_KERNEL_WS);
     return launch_hand_back(pl, K, st, csr);
 }
 
@@ -1115,7 +1103,6 @@ void icv_plan_destroy(icv_plan_t pl) {
         (void)hipFree(pl->d_win_scratch);
         (void)hipFree(pl->d_dst16);
         (void)hipFree(pl->d_x16_wdesc);
-        (void)hipFree(pl->d_xo_desc);
         (void)hipFree(pl->d_blk_g0);
         (void)hipFree(pl->d_se_w0);
         (void)hipFree(pl->d_se_w1);

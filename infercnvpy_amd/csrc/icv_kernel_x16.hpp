@@ -105,14 +105,8 @@ __device__ __forceinline__ int hist_bin_x(double v, float inv_bound, float c_sca
 // of every L phase (long windows need the registers for larger batches of {S0,S1} reads)
 // WIN: the float64 windows of every cell (before centring) also go to P.win_out[cell * P.win_ld + j] -- what
 // calculate_gene_values averages (reference tl/_infercnv.py:274-288); cells handed back are rewritten by k_smooth
-// ORD: POSITION-ORDERED input columns (plan: xo_ok -- the genes of every block are consecutive columns of the row, what
-// adata.var in GTF order gives).  A thread loads the 2 BT genes of each of its pairs of blocks straight from
-// the row (4-byte aligned 16 / 8 / 4-byte loads), centres and clips them in registers and forms {S0,S1} there: no row in
-// LDS, no per-gene scatter, no S phase reading it back -- 25 of the thread's ~56 LDS instructions per cell are gone, and
-// {S0,S1} is double buffered instead (phase A of iteration `it` = the block sums of cell it+1, phase B = the windows of
-// cell it).  Same arithmetic, same order: x_res and medians are bit-identical to the scatter form.
 template <int BT, int NBW, int SB /* blocks between adjacent windows = step / BT */, bool CHUNK, int FINE, bool REFRES,
-          bool WIN = false, bool ORD = false>
+          bool WIN = false>
 __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     constexpr int XFINE = FINE, XCOARSE = FINE / 64;
     static_assert(FINE % 1024 == 0 && XCOARSE * XREP <= XT && FINE / 4 <= XT, "histogram cleared by one store per thread");
@@ -145,31 +139,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         __builtin_trap();  // the L phase addresses the row by absolute LDS offsets
 
     // ---- per-thread constants, loaded once -------------------------------------------------------
-    constexpr int OPAIRS = ORD ? (BT >= 10 ? 1 : 2) : 1;  // ORD: pairs of blocks per thread (plan: xo_pairs)
-    constexpr int OV = BT >= 10 ? 3 : 2;                  // ORD: loads per block: 16 + 16 + 8 bytes (BT = 10), 16 + 4 (BT = 5)
-    static_assert(!ORD || BT == 10 || BT == 5, "ORD: block sizes of the instantiated geometries");
-    u32x4 refv[(REFRES && !ORD) ? XU : 1];
+    u32x4 refv[REFRES ? XU : 1];
     const __amdgpu_buffer_rsrc_t ref_rs = make_rsrc(P.ref_lo, row_bytes);
-    unsigned laddr[ORD ? 1 : XU][4];  // LDS byte addresses of the thread's 20 genes, resident for the whole kernel
-    unsigned obase[OPAIRS][2];        // ORD: byte offset in the row of the first gene of the thread's blocks
-    float oref[ORD ? OPAIRS : 1][ORD ? 2 * BT : 1];  // ORD: reference of the thread's genes (resident)
-    if constexpr (ORD) {
-        const __amdgpu_buffer_rsrc_t d_rs = make_rsrc(P.xo_desc, (unsigned)(OPAIRS * XT * 8));
-#pragma unroll
-        for (int k = 0; k < OPAIRS; ++k) {
-            const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(d_rs, (unsigned)t * 8u, k * XT * 8, 0);
-            obase[k][0] = d.x < 0x40000000u ? d.x * 4u : 0xfffffff0u;  // (no full block here: out of range, reads zeros)
-            obase[k][1] = d.y < 0x40000000u ? d.y * 4u : 0xfffffff0u;
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int r = 0; r < BT; ++r)
-                    oref[k][h * BT + r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ref_rs, obase[k][h], r * 4, 0));
-        }
-        laddr[0][0] = laddr[0][1] = laddr[0][2] = laddr[0][3] = 0u;
-    } else {
-        obase[0][0] = obase[0][1] = 0u;
-        oref[0][0] = 0.0f;
+    unsigned laddr[XU][4];  // LDS byte addresses of the thread's 20 genes, resident for the whole kernel
+    {
         const __amdgpu_buffer_rsrc_t d16_rs = make_rsrc(P.dst16, (unsigned)(XU * XT * 8));
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
@@ -198,18 +171,14 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     const bool valid0 = (wdx >> 24) & 1u, valid1 = (wdx >> 25) & 1u;
     constexpr int INTER = 2 * SB;  // {S0,S1} of block b lives in array b % INTER at slot b / INTER
     const int half = P.x16_half;   // slots per array
-    // LDS byte address of blocks b0, b0 + 1, ..., b0 + INTER - 1 (ORD: in both {S0,S1} buffers, by cell parity)
-    unsigned spK[ORD ? 2 : 1][INTER];
+    unsigned spK[INTER];           // LDS byte address of blocks b0, b0 + 1, ..., b0 + INTER - 1
 #pragma unroll
-    for (int k = 0; k < INTER; ++k) {
-        spK[0][k] = (unsigned)P.win_off + (unsigned)((wb0 + k) / INTER + half * ((wb0 + k) % INTER)) * 16u;
-        if constexpr (ORD) spK[1][k] = spK[0][k] + (unsigned)P.xo_s01_bytes;
-    }
+    for (int k = 0; k < INTER; ++k)
+        spK[k] = (unsigned)P.win_off + (unsigned)((wb0 + k) / INTER + half * ((wb0 + k) % INTER)) * 16u;
     const bool wave_w = __builtin_amdgcn_ballot_w64(valid0) != 0;  // the wavefront has windows at all
     const bool wfull = __builtin_amdgcn_ballot_w64((valid0 && !((wdx >> 26) & 1u)) || (valid1 && !((wdx >> 27) & 1u))) == 0;
     // pad slots and the trash slot are written once: nothing aliases the row
-    if constexpr (!ORD)
-        for (int i = t; i < P.n_pad; i += XT) row[P.pad_idx[i]] = 0.0f;
+    for (int i = t; i < P.n_pad; i += XT) row[P.pad_idx[i]] = 0.0f;
     for (int i = t; i < x16_hist_bytes(FINE) / 4; i += XT) hist[i] = 0u;
     if (t < 2) {
         sc->ncand[t] = 0;
@@ -222,90 +191,17 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
     // against two 4-byte stores per thread): needs 16-byte aligned rows
     const bool st16 = ((P.ldo & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.out) & 15) == 0);
     for (int i = t; i < ((W + 3) & ~3); i += XT) stage[i] = 0.0f;
-    for (int i = t; i < (ORD ? 2 : 1) * 2 * INTER * half; i += XT) S01[i] = 0.0;  // slots past the last block are read (and discarded)
+    for (int i = t; i < 2 * INTER * half; i += XT) S01[i] = 0.0;  // slots past the last block are read (and discarded)
 
-    u32x4 xq[ORD ? 1 : XU];
-    float ox[ORD ? OPAIRS : 1][ORD ? 2 * BT : 1];  // ORD: the next cell's genes of the thread's blocks, in flight
-    // ORD: the BT genes of block h of pair k of the row behind `xr` into ox (16-byte pieces at 4-byte alignment)
-    auto o_load = [&](const __amdgpu_buffer_rsrc_t xr, int k, int h) __attribute__((always_inline)) {
-        if constexpr (ORD) {
-            float* o = &ox[k][h * BT];
-            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(xr, obase[k][h], 0, ICV_X_ROW_AUX);
-            o[0] = __uint_as_float(a.x), o[1] = __uint_as_float(a.y), o[2] = __uint_as_float(a.z), o[3] = __uint_as_float(a.w);
-            if constexpr (BT >= 10) {
-                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(xr, obase[k][h], 16, ICV_X_ROW_AUX);
-                const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(xr, obase[k][h], 32, ICV_X_ROW_AUX);
-                o[4] = __uint_as_float(b.x), o[5] = __uint_as_float(b.y), o[6] = __uint_as_float(b.z), o[7] = __uint_as_float(b.w);
-                o[8] = __uint_as_float(c.x), o[9] = __uint_as_float(c.y);
-            } else {
-                o[4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, obase[k][h], 16, ICV_X_ROW_AUX));
-            }
-        }
-    };
-    (void)OV;
-    if constexpr (ORD) {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
-#pragma unroll
-        for (int k = 0; k < OPAIRS; ++k) {
-            o_load(xr, k, 0);
-            o_load(xr, k, 1);
-        }
-        xq[0] = u32x4{0u, 0u, 0u, 0u};
-    } else {
-        ox[0][0] = 0.0f;
+    u32x4 xq[XU];
+    {
         const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (int64_t)blockIdx.x * P.ld, row_bytes);
 #pragma unroll
         for (int u = 0; u < XU; ++u) xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);
     }
-    // ORD: centre and clip the genes in ox, form {S0,S1} of the thread's blocks in registers (canonical order:
-    // block_accumulate without its no-ops, as the S phase below) and store them into the {S0,S1} buffer of parity `par`;
-    // every block's loads are re-requested for cell `c_next` as its registers are consumed
-    auto ls_phase = [&](int64_t c_next, int par) __attribute__((always_inline)) {
-        if constexpr (ORD) {
-            const bool more = c_next < P.n_rows;
-            const __amdgpu_buffer_rsrc_t xr = make_rsrc(xbase + (more ? c_next : 0) * P.ld, more ? row_bytes : 0u);
-            int tq = t;
-            asm volatile("" : "+v"(tq));
-            double2* sp = reinterpret_cast<double2*>(smem + (unsigned)P.win_off + (unsigned)par * (unsigned)P.xo_s01_bytes);
-#pragma unroll
-            for (int k = 0; k < OPAIRS; ++k) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float c[BT];
-                    bool un = false;
-#pragma unroll
-                    for (int r = 0; r < BT; ++r) {
-                        const float y = ox[k][h * BT + r] - oref[k][h * BT + r];
-                        un |= (y != y);
-                        c[r] = __builtin_amdgcn_fmed3f(y, -cap, cap);
-                    }
-                    // v_med3 drops NaNs, np.clip keeps them (never taken on real data)
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(un) != 0ull, 0)) {
-#pragma unroll
-                        for (int r = 0; r < BT; ++r) {
-                            const float y = ox[k][h * BT + r] - oref[k][h * BT + r];
-                            if (y != y) c[r] = y;
-                        }
-                    }
-                    o_load(xr, k, h);  // (registers consumed: the same block of cell c_next)
-                    double s0 = (double)c[0], s1;
-                    {
-                        const double a1 = (double)c[1];
-                        s0 = s0 + a1;
-                        s1 = a1;
-                    }
-#pragma unroll
-                    for (int r = 2; r < BT; ++r) block_accumulate((double)c[r], r, s0, s1);
-                    const int b = 2 * (k * XT + tq) + h;
-                    if (b < NB) sp[b / INTER + half * (b % INTER)] = make_double2(s0, s1);
-                }
-            }
-        }
-    };
 
     // centre, clip and scatter the row in xq, re-requesting every vector for cell `c_next` as it is consumed
     auto l_phase = [&](int64_t c_next) __attribute__((always_inline)) {
-      if constexpr (!ORD) {
         const bool more = c_next < P.n_rows;
 #if defined(ICV_DEV_EXPERIMENTS) && defined(ICV_X_EXP_NOLOAD)
         // upper-bound experiment (WRONG RESULTS; tools/build_variant.sh only): empty range, no HBM row traffic
@@ -349,12 +245,10 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             xq[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, voff, u * XT * 16, ICV_X_ROW_AUX);  // out of range: zeros, no traffic
 #endif
         }
-      }
     };
 
     // the first row is scattered before the loop; its successor is requested right away
-    if constexpr (ORD) ls_phase((int64_t)blockIdx.x + gridDim.x, 0);
-    else l_phase((int64_t)blockIdx.x + gridDim.x);
+    l_phase((int64_t)blockIdx.x + gridDim.x);
 
     // windows 2t, 2t+1 of cells of even / odd iteration (double buffered), and their fine bins (-1: no window)
     double wvE0 = 0.0, wvE1 = 0.0, wvO0 = 0.0, wvO1 = 0.0;
@@ -498,11 +392,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
             }
         }
         ICV_XPH(7)
-        if constexpr (ORD) {
-            // ---- {S0,S1} of cell it+1 from its genes in registers (ls_phase), the genes of cell it+2 requested
-            const int64_t nxt_o = cell + gridDim.x;
-            if (nxt_o < P.n_rows) ls_phase(nxt_o + gridDim.x, p1);
-        } else if (have0) {
+        if (have0) {
             // ---- S: block partial sums, straight into their own LDS region.  A pass of a wavefront covers 64
             // pairs of adjacent blocks.  With q = ceil(pairs / 1024) passes per wavefront on average, the chain
             // wavefronts 0, 1 take q - 1 passes, wavefronts 4, 5 (same SIMDs) q + 1, the others q: every SIMD
@@ -676,7 +566,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 constexpr int WCH = NBW > 10 ? 5 : ICV_X_WCH;  // long windows: fewer, larger batches of LDS reads
 #endif
                 auto blk = [&](int i) __attribute__((always_inline)) {  // {S0,S1} of block b0 + i
-                    return reinterpret_cast<const double2*>(smem + spK[ORD ? p0 : 0][i % INTER])[i / INTER];
+                    return reinterpret_cast<const double2*>(smem + spK[i % INTER])[i / INTER];
                 };
                 v0 = 0.0;
                 v1 = 0.0;
@@ -716,8 +606,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                     const unsigned fi = P.x16_wdesc[XT + wbase + L];  // uniform address: s_load
                     const int nb = (int)(fi & 0xffffu);
                     const int bs = __builtin_amdgcn_readlane(wb0, L);
-                    const double2* sb = reinterpret_cast<const double2*>(
-                        smem + (unsigned)P.win_off + (ORD ? (unsigned)p0 * (unsigned)P.xo_s01_bytes : 0u));
+                    const double2* sb = reinterpret_cast<const double2*>(S01);
                     // one LDS read per block, all in flight at once (lane m: block m), then the canonical
                     // left-to-right sum through lane reads
                     double acc = 0.0;
@@ -754,8 +643,7 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
         }
         ICV_XPH(5)
         const int64_t nxt = cell + gridDim.x;
-        if constexpr (!ORD)
-            if (nxt < P.n_rows) l_phase(nxt + gridDim.x);
+        if (nxt < P.n_rows) l_phase(nxt + gridDim.x);
         if (have2) {
             const int64_t pcell = cell - 2 * (int64_t)gridDim.x;
             if (!st16) {  // unaligned result rows: 4-byte stores, after the row loads of the L phase

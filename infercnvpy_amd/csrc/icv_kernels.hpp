@@ -88,9 +88,7 @@ struct KParams {
     // window valid (24, 25), full pyramid window (26, 27); then per thread: 0, or for a flat first window its
     // block count | gene count << 16
     const uint32_t* x16_wdesc;
-    int32_t x16_half;         // k_smooth_x16: slots of the even-block {S0,S1} array
-    int32_t xo_s01_bytes;     // k_smooth_x16<ORD>: bytes of one {S0,S1} buffer (two of them, by cell parity)
-    const uint32_t* xo_desc;  // k_smooth_x16<ORD>: per block, the input column of its first gene (plan: xo_desc)
+    int32_t x16_half, _pad4;  // k_smooth_x16: slots of the even-block {S0,S1} array
     // k_smooth_se (CSR float32, stored entries only).  Per block the gene offset of its first gene inside its
     // chromosome; per input column {LDS address of the block's bins, ref_lo, in-block offset * 2^k1, clip(0 - ref)}
     // (k_se_table), ref_hi per column (bounded references); per window {w0, w1, zero-row sum} (k_se_wtab); per block

@@ -80,17 +80,6 @@ struct Plan {
     int x16_half = 0;  // slots of the even-block {S0,S1} array (odd blocks follow)
     int x16_fine = 0;  // fine histogram bins: 4096, or 1024 where LDS is short (window 250: twice the blocks)
     std::vector<uint32_t> x16_wdesc;  // per thread: the pair of adjacent windows it owns (icv_kernels.hpp KParams)
-    // k_smooth_x16<ORD> (position-ordered input columns, SURVEY 7 "input column order != window order"): the genes of
-    // every block are CONSECUTIVE input columns (adata.var in GTF order: monotone positions inside a chromosome), so a
-    // thread loads the 2 x B genes of its pair of blocks straight from the row and forms {S0,S1} in registers -- no row
-    // in LDS, no scatter.  xo_desc[pair]: input column of the first gene of block 2 pair and of block 2 pair + 1
-    // (0x7fffffff: no such block / not a full block).  Needs every FULL block consecutive; the partial last block of a
-    // chromosome is read by flat windows only (pyramid windows end on block boundaries), so a chromosome with at most
-    // `window` genes must consist of full blocks.
-    bool xo_ok = false;
-    std::vector<uint32_t> xo_desc;
-    int xo_pairs = 0;                  // pairs of blocks per thread (1: window 100, 2: window 250)
-    int xo_s01_bytes = 0, xo_hist_off = 0, xo_scratch_off = 0, xo_lds = 0;
     Layout lay32, lay64;
 };
 
@@ -383,33 +372,6 @@ inline std::string build_plan(Plan& p, int n_cols_all, const int32_t* col_pos, i
                                          ((v1 ? 1u : 0u) << 25) | (full0 << 26) | (full1 << 27);
                 }
             }
-        }
-        // position-ordered variant: same geometry, {S0,S1} double buffered instead of the row
-        p.xo_ok = false;
-        p.xo_desc.clear();
-        if (p.x16_ok) {
-            const int pairs = (p.NB + 1) / 2;
-            p.xo_pairs = (pairs + kX16Threads - 1) / kX16Threads;
-            bool ok = p.xo_pairs >= 1 && p.xo_pairs <= 2;
-            p.xo_desc.assign((size_t)2 * p.xo_pairs * kX16Threads, 0x7fffffffu);
-            std::vector<char> full((size_t)p.NB, 1);
-            for (int b = 0; b < p.NB && ok; ++b) {
-                for (int r = 0; r < B; ++r) full[b] = full[b] && p.src[b * B + r] >= 0;
-                if (!full[b]) continue;  // partial last block of a chromosome: no pyramid window reads it
-                for (int r = 1; r < B && ok; ++r) ok = p.src[b * B + r] == p.src[b * B] + r;
-                p.xo_desc[b] = (uint32_t)p.src[b * B];
-            }
-            // a flat window (chromosome with at most `window` genes) sums ALL blocks of its chromosome: they must be full
-            for (int j = 0; j < p.W && ok; ++j)
-                if (p.w_len[j] < 0)
-                    for (int b = p.w_start[j] / B; b < (p.w_start[j] - p.w_len[j]) / B && ok; ++b) ok = full[b] != 0;
-            const int inter = 2 * ((B > 0 && step % B == 0) ? step / B : 1);
-            p.xo_s01_bytes = inter * 16 * p.x16_half;
-            p.xo_hist_off = 2 * p.xo_s01_bytes;
-            const int hist_bytes = 2 * (p.x16_fine * 4 + 16 * (p.x16_fine / 64) * 4);
-            p.xo_scratch_off = p.xo_hist_off + hist_bytes;
-            p.xo_lds = p.xo_scratch_off + kFastScratchBytes + round_up(4 * p.W, 16);
-            p.xo_ok = ok && p.xo_lds <= kLdsLimit;
         }
     }
     return "";

@@ -280,13 +280,10 @@ def test_gene_values_old_entry_point_and_odd_strides():
 
 
 @pytest.mark.parametrize("window", [100, 250])
-def test_position_ordered_columns_take_the_ordered_kernel_same_bits(window, monkeypatch):
-    """SURVEY 7 "input column order != window order": with ``adata.var`` in genome order (GTF order: chromosomes one after
-    the other, positions ascending -- the usual case) the genes of a block are consecutive input columns and
-    k_smooth_x16<ORD> forms the block sums straight from the row (no row in LDS, no scatter).  Same arithmetic: X_cnv is
-    bit-identical to the scatter form (ICV_NO_XO) and matches the oracle; chromosomes in another order than the natural
-    one, masked chromosomes in between, a NaN entry, a zero row; annotations that are NOT ordered -- a gene out of place,
-    a chromosome with fewer genes than the window (its flat window reads the partial block) -- keep the scatter form."""
+def test_position_ordered_columns_same_results(window):
+    """SURVEY 7 "input column order != window order": ``adata.var`` in genome order (GTF order: chromosomes one after the
+    other -- not in natural order, a masked chromosome in between --, positions ascending) against the oracle, and the same
+    cells with the columns permuted give the same X_cnv bit for bit (the result does not depend on the column order)."""
     import infercnvpy_amd as cnv
     from infercnvpy_amd import _lib
     from infercnvpy_amd._compat import SimpleAnnData
@@ -294,47 +291,31 @@ def test_position_ordered_columns_take_the_ordered_kernel_same_bits(window, monk
 
     v0 = cases.synthetic_var(cases.GENES_PER_CHROM_20K, extra=(("chrX", 37), ("chrM", 3)))
     order = [f"chr{i}" for i in (3, 1, 2)] + ["chrX"] + [f"chr{i}" for i in range(4, 23)] + ["chrM"]
-    v, _ = cases.position_ordered(v0, chrom_order=order)
+    v, perm = cases.position_ordered(v0, chrom_order=order)
     n_genes = len(v["names"])
-    assert n_genes % 4 == 0
-    n = 700
-    X = cases.synthetic_expr(n, n_genes, seed=71)
-    X[5, :] = 0.0
-    X[11, 4321] = np.nan
-    ref = np.nanmean(X, axis=0).astype(np.float32)
+    n = 96
+    X0 = cases.synthetic_expr(n, n_genes, seed=71)  # columns in v0's (random) order
+    X0[5, :] = 0.0
+    X0[11, 4321] = np.nan
+    X = np.ascontiguousarray(X0[:, perm])           # the same cells, columns in genome order
+    ref0 = np.nanmean(X0, axis=0).astype(np.float32)
+    kw = dict(window_size=window, step=10, chunksize=40, inplace=False)
+    var0 = pd.DataFrame({"chromosome": v0["chromosome"], "start": v0["start"], "end": v0["end"]}, index=v0["names"])
     var = pd.DataFrame({"chromosome": v["chromosome"], "start": v["start"], "end": v["end"]}, index=v["names"])
-    kw = dict(reference=ref, window_size=window, step=10, chunksize=256, inplace=False)
     tm = {}
-    pos, res, _ = cnv.tl.infercnv(SimpleAnnData(X, var=var), _timings=tm, **kw)
-    assert tm["kernel"] == _lib.ICV_KERNEL_X16_ORDERED
-    monkeypatch.setenv("ICV_NO_XO", "1")
-    _lib.load().icv_developer_knobs_reload()
-    tm2 = {}
-    _, res2, _ = cnv.tl.infercnv(SimpleAnnData(X, var=var), _timings=tm2, **kw)
-    monkeypatch.delenv("ICV_NO_XO")
-    _lib.load().icv_developer_knobs_reload()
-    assert tm2["kernel"] == _lib.ICV_KERNEL_X16
-    for a, b in ((res.indptr, res2.indptr), (res.indices, res2.indices)):
+    pos, res, _ = cnv.tl.infercnv(SimpleAnnData(X, var=var), reference=ref0[perm], _timings=tm, **kw)
+    assert tm["kernel"] == _lib.ICV_KERNEL_X16
+    pos0, res0, _ = cnv.tl.infercnv(SimpleAnnData(X0, var=var0), reference=ref0, **kw)
+    assert pos == pos0
+    for a, b in ((res.indptr, res0.indptr), (res.indices, res0.indices), (res.data, res0.data)):
         np.testing.assert_array_equal(a, b)
-    np.testing.assert_array_equal(res.data.view(np.int64), res2.data.view(np.int64))
-    sub = slice(0, 96)
-    o_pos, o_res, _, _ = O.infercnv(X[sub], v["chromosome"], v["start"], reference=ref, window_size=window, step=10,
-                                    chunksize=256)
-    # (chunk thresholds differ between 96 and 256 rows: compare the un-thresholded part through a second call)
-    _, res_s, _ = cnv.tl.infercnv(SimpleAnnData(X[sub].copy(), var=var), **kw)
+    o_pos, o_res, _, _ = O.infercnv(X, v["chromosome"], v["start"], reference=ref0[perm], window_size=window, step=10,
+                                    chunksize=40)
     assert {k: int(x) for k, x in pos.items()} == {k: int(x) for k, x in o_pos.items()}
-    got, exp = res_s.toarray(), o_res.toarray()
+    got, exp = res.toarray(), o_res.toarray()
     np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
     np.testing.assert_array_equal(np.nan_to_num(got) == 0, np.nan_to_num(exp) == 0)
     np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(exp), rtol=0, atol=ATOL_TIGHT)
-    # not ordered: two genes of one chromosome swapped -> the scatter form
-    vs = {k: (np.array(x, dtype=object) if k == "chromosome" else (list(x) if isinstance(x, list) else np.array(x)))
-          for k, x in v.items()}
-    vs["start"][[100, 101]] = vs["start"][[101, 100]]
-    var_s = pd.DataFrame({"chromosome": vs["chromosome"], "start": vs["start"], "end": vs["end"]}, index=vs["names"])
-    tm3 = {}
-    cnv.tl.infercnv(SimpleAnnData(X[sub].copy(), var=var_s), _timings=tm3, **kw)
-    assert tm3["kernel"] == _lib.ICV_KERNEL_X16
 
 
 def test_reference_fixture_through_public_api():
