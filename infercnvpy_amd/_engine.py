@@ -359,10 +359,12 @@ def _default_pack_threads():
 
 
 # Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as
-# the packing itself): at most _PACK_POOL_MAX buffer pairs, handed out largest first.
+# the packing itself): at most _PACK_POOL_MAX buffer pairs and _PACK_POOL_BYTES of host memory (six 1 GB pairs
+# stayed allocated after the call), handed out largest first; release_pinned_buffers() empties it.
 _PACK_POOL = []
 _PACK_POOL_LOCK = None
 _PACK_POOL_MAX = 6
+_PACK_POOL_BYTES = 3 << 30
 
 
 def _pack_pool_take(np_dtype):
@@ -385,18 +387,31 @@ def _pack_pool_give(bufs):
     if _PACK_POOL_LOCK is None or bufs[0].shape[0] == 0:
         return
     with _PACK_POOL_LOCK:
-        if len(_PACK_POOL) < _PACK_POOL_MAX:
+        held = sum(b[0].nbytes + b[1].nbytes for b in _PACK_POOL)
+        if len(_PACK_POOL) < _PACK_POOL_MAX and held + bufs[0].nbytes + bufs[1].nbytes <= _PACK_POOL_BYTES:
             _PACK_POOL.append(bufs)
 
 
 def _probe_density(X, np_dtype, row0, row1, probe_rows=256):
-    """Stored entries per element in the first ``probe_rows`` rows of X[row0:row1] (a C-ordered float matrix)."""
-    n = min(probe_rows, row1 - row0)
-    xs = X[row0:row0 + n]
-    cnt = np.zeros(n, dtype=np.int64)
-    _lib.check(_lib.load().icv_host_dense_row_nnz(xs.ctypes.data, _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64,
-                                                  n, X.shape[1], X.strides[0] // X.itemsize, cnt.ctypes.data, 1))
-    return float(cnt.sum()) / float(max(1, n * X.shape[1]))
+    """Stored entries per element in ``probe_rows`` rows of X[row0:row1] (a C-ordered float matrix) taken in 16 runs
+    spread evenly over the range (a matrix sorted by library size -- empty droplets first -- is not what its
+    first rows look like)."""
+    n_all = row1 - row0
+    n = min(probe_rows, n_all)
+    runs = 16 if n_all >= 16 * 16 else 1
+    per = max(1, n // runs)
+    lib = _lib.load()
+    code = _lib.ICV_F32 if np_dtype == np.float32 else _lib.ICV_F64
+    total = rows = 0
+    for k in range(runs):
+        a = row0 + (k * (n_all - per)) // max(runs - 1, 1) if runs > 1 else row0
+        xs = X[a:a + per]
+        cnt = np.zeros(xs.shape[0], dtype=np.int64)
+        _lib.check(lib.icv_host_dense_row_nnz(xs.ctypes.data, code, xs.shape[0], X.shape[1], X.strides[0] // X.itemsize,
+                                              cnt.ctypes.data, 1))
+        total += int(cnt.sum())
+        rows += xs.shape[0]
+    return float(total) / float(max(1, rows * X.shape[1]))
 
 
 def _wants_sparse_upload(X, np_dtype, row0, row1, max_density=0.3):
@@ -547,7 +562,18 @@ class SlabStream:
                             self._err = e
 
                 def copy_piece(r0, r1):  # noqa: F811 -- the sparse form replaces the dense copy
-                    item = packed_q.get()
+                    # (polled: a packer that was cancelled before it started this piece enqueues nothing -- ADVICE r5)
+                    item = None
+                    while item is None:
+                        try:
+                            item = packed_q.get(timeout=0.1)
+                        except queue.Empty:
+                            if self._err is not None:
+                                raise self._err
+                            if self._cancel.is_set():
+                                raise RuntimeError("sparse upload cancelled")
+                            if not self._packer.is_alive() and packed_q.empty():
+                                raise RuntimeError("sparse upload: the packer stopped without delivering the piece")
                     if isinstance(item, BaseException):
                         raise item
                     ip, nnz, bufs = item
@@ -929,7 +955,11 @@ def release_pinned_buffers():
     """Free the pinned staging rings of the device -> host copies (128 MB per GPU used so far, kept between calls) and the
     host buffers of the sparse upload."""
     _PinnedRing.release_all()
-    del _PACK_POOL[:]
+    if _PACK_POOL_LOCK is not None:
+        with _PACK_POOL_LOCK:
+            del _PACK_POOL[:]
+    else:
+        del _PACK_POOL[:]
 
 
 class CsrDrain:

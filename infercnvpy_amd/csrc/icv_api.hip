@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -1863,7 +1864,7 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     } guard{z, c, d_cnt};
     HIP_TRY(hipMalloc((void**)&z, (size_t)n * kz * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c, (size_t)n * n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&d_cnt, 5 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&d_cnt, (4 * 2048 + 1) * sizeof(unsigned long long)));
     hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
     GramWork gw;
     if (int rc = launch_gram<false, true>(st, gw, z, kz, nullptr, gram_supers_sym(n, n), n, n, c, n, c, n)) return rc;
@@ -1875,32 +1876,57 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
         target[2 * q] = (unsigned long long)std::floor(pos[q]);
         target[2 * q + 1] = target[2 * q] + 1 < (unsigned long long)(m1 + 1.0) ? target[2 * q] + 1 : target[2 * q];
     }
-    // smallest key K with #{key <= K} > target, by bisection on the ordered 32-bit keys (exact)
-    unsigned lo[4] = {0, 0, 0, 0}, hi[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    // the keys of ranks target[0..3] by radix selection on the ordered 32-bit keys (exact): 11 + 11 + 10 bits, one pass
+    // over the matrix each (k_key_hist; targets that share their higher bits share a histogram).  Round 5 bisected with
+    // k_count_le4: 33 passes, half of ithcna's time at 25 000 cells per group.
+    unsigned lo[4] = {0, 0, 0, 0};
     const int64_t m = n * n;
     int64_t grid = (m + 255) / 256;
     if (grid > 4096) grid = 4096;
     bool any_nan = false;
-    for (int it = 0; it < 33; ++it) {
-        bool active = false;
-        unsigned mid[4];
-        for (int q = 0; q < 4; ++q) {
-            mid[q] = lo[q] + (hi[q] - lo[q]) / 2;
-            active |= lo[q] < hi[q];
+    {
+        std::vector<unsigned long long> h(4 * 2048 + 1);
+        unsigned long long below[4] = {0, 0, 0, 0};  // elements whose key is below the target's current prefix range
+        unsigned prefix[4] = {0, 0, 0, 0};
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3 && !any_nan; ++pass) {
+            const unsigned himask = pass == 0 ? 0u : ~((1u << (shifts[pass] + bits[pass])) - 1u);
+            // distinct prefixes -> histograms
+            unsigned pq[4] = {0, 0, 0, 0};
+            int which[4], nq = 0;
+            for (int q = 0; q < 4; ++q) {
+                int f = -1;
+                for (int k = 0; k < nq; ++k)
+                    if (pq[k] == (prefix[q] & himask)) f = k;
+                if (f < 0) {
+                    pq[nq] = prefix[q] & himask;
+                    f = nq++;
+                }
+                which[q] = f;
+            }
+            HIP_TRY(hipMemsetAsync(d_cnt, 0, (4 * 2048 + 1) * sizeof(unsigned long long), st));
+            hipLaunchKernelGGL(icv::k_key_hist, dim3((unsigned)grid), dim3(256), 0, st, c, m, shifts[pass], bits[pass], himask,
+                               pq[0], pq[1], pq[2], pq[3], nq, d_cnt);
+            HIP_TRY(hipMemcpyAsync(h.data(), d_cnt, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (h[4 * 2048]) {
+                any_nan = true;
+                break;
+            }
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long* hq = h.data() + (size_t)which[q] * 2048;
+                unsigned long long run = below[q];
+                unsigned d = 0;
+                const unsigned nd = 1u << bits[pass];
+                for (; d + 1 < nd; ++d) {
+                    if (run + hq[d] > target[q]) break;
+                    run += hq[d];
+                }
+                below[q] = run;
+                prefix[q] |= d << shifts[pass];
+            }
         }
-        if (!active) break;
-        HIP_TRY(hipMemsetAsync(d_cnt, 0, 5 * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(icv::k_count_le4, dim3((unsigned)grid), dim3(256), 0, st, c, m, mid[0], mid[1], mid[2],
-                           mid[3], d_cnt);
-        unsigned long long h[5];
-        HIP_TRY(hipMemcpyAsync(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (h[4]) { any_nan = true; break; }
-        for (int q = 0; q < 4; ++q) {
-            if (lo[q] >= hi[q]) continue;
-            if (h[q] > target[q]) hi[q] = mid[q];
-            else lo[q] = mid[q] + 1;
-        }
+        for (int q = 0; q < 4; ++q) lo[q] = prefix[q];
     }
     if (any_nan) {
         *h_iqr = std::nan("");
@@ -2795,9 +2821,19 @@ int host_pack_fused(const T* x, int64_t n_rows, int64_t n_cols, int64_t ld, int6
     if (n_threads == 1) {
         worker();
     } else {
+        // (a thread that cannot be created -- ulimit, exhaustion -- must not leave joinable threads behind: the blocks are
+        // claimed by whoever runs, so the threads that did start, and this one, finish the piece: ADVICE r5)
         std::vector<std::thread> pool;
         pool.reserve(n_threads);
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+        bool short_of_threads = false;
+        for (int t = 0; t < n_threads && !short_of_threads; ++t) {
+            try {
+                pool.emplace_back(worker);
+            } catch (const std::system_error&) {
+                short_of_threads = true;
+            }
+        }
+        if (short_of_threads) worker();
         for (auto& th : pool) th.join();
     }
     *total_out = total;
@@ -2817,7 +2853,11 @@ void host_parallel_rows(int64_t n_rows, int n_threads, F&& fn) {
     pool.reserve(n_threads);
     for (int t = 0; t < n_threads; ++t) {
         const int64_t a = n_rows * t / n_threads, b = n_rows * (t + 1) / n_threads;
-        pool.emplace_back([&fn, a, b] { fn(a, b); });
+        try {
+            pool.emplace_back([&fn, a, b] { fn(a, b); });
+        } catch (const std::system_error&) {
+            fn(a, b);  // no thread to be had: this range on the calling thread
+        }
     }
     for (auto& th : pool) th.join();
 }

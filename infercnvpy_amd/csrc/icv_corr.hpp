@@ -314,6 +314,36 @@ __host__ __device__ inline float from_ordered_key32(unsigned k) {
 #endif
 }
 
+// Radix selection of order statistics over the ordered 32-bit keys: one pass histograms the `nbits` key bits at `shift` of
+// the elements whose higher bits equal one of up to four prefixes (himask = the bits above the digit; nq histograms of
+// 2048 64-bit counters in `hist`, per-workgroup counts collected in LDS first); hist[nq * 2048] counts the NaNs.  Three
+// passes (11 + 11 + 10 bits) locate four ranks exactly where the bisection on k_count_le4 needed 33 passes over the matrix.
+__global__ void __launch_bounds__(256) k_key_hist(const float* __restrict__ v, int64_t m, int shift, int nbits,
+                                                  unsigned himask, unsigned p0, unsigned p1, unsigned p2, unsigned p3,
+                                                  int nq, unsigned long long* __restrict__ hist) {
+    __shared__ unsigned lh[4 * 2048 + 1];
+    for (int i = threadIdx.x; i < 4 * 2048 + 1; i += 256) lh[i] = 0u;
+    __syncthreads();
+    const unsigned dmask = (1u << nbits) - 1u;
+    const unsigned pq[4] = {p0, p1, p2, p3};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+        const float x = v[i];
+        if (x != x) {
+            atomicAdd(&lh[4 * 2048], 1u);
+            continue;
+        }
+        const unsigned k = ordered_key32(x);
+        const unsigned d = (k >> shift) & dmask;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nq && ((k ^ pq[q]) & himask) == 0u) atomicAdd(&lh[q * 2048 + d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq * 2048; i += 256)
+        if (lh[i]) atomicAdd(hist + i, (unsigned long long)lh[i]);
+    if (threadIdx.x == 0 && lh[4 * 2048]) atomicAdd(hist + 4 * 2048, (unsigned long long)lh[4 * 2048]);
+}
+
 // counts[p] += #{ key(v) <= pivot[p] }, p < 4; counts[4] += #NaN
 __global__ void __launch_bounds__(256) k_count_le4(const float* v, int64_t m, unsigned p0, unsigned p1, unsigned p2,
                                                    unsigned p3, unsigned long long* counts) {

@@ -512,8 +512,8 @@ __global__ void __launch_bounds__(XT) k_smooth_x16(const KParams P) {
                 }
                 if constexpr (WIN) {
                     double* wrow = P.win_out + pcell * P.win_ld;
-                    if (v0) wrow[wj0] = wvA0;
-                    if (v1) wrow[wj0 + 1] = wvA1;
+                    if (v0) __builtin_nontemporal_store(wvA0, wrow + wj0);  // (written once, read by another kernel)
+                    if (v1) __builtin_nontemporal_store(wvA1, wrow + wj0 + 1);
                 }
             }
         }

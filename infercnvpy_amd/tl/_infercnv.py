@@ -466,7 +466,9 @@ def infercnv(
     values travel through the host); the uploads of all shards still overlap.  A dense matrix stored column-major
     (``np.asfortranarray``, a transposed genes x cells array) gets numpy's order for THAT layout (pairwise per column
     over 8 192-element pieces), formed on the first GPU before the shards start.  Not reproduced: scipy's order for
-    sparse formats other than CSR / CSC (converted to CSR; a warning says so).
+    sparse formats other than CSR / CSC (converted to CSR; a warning says so), and the per-category means of a dense
+    matrix with ONE column (``X[rows, :]`` is then a contiguous vector that numpy reduces pairwise; the all-cell mean of
+    such a matrix does take that route).
     ``_timings`` (not part of the reference API): a dict that receives the wall-clock seconds of the stages (plan,
     host -> HBM copy, kernels, CSR pack + copy back; per shard under ``"shards"`` when there are several).
 
