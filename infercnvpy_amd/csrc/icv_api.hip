@@ -215,8 +215,9 @@ struct AsyncBuf {
     }
     // The device's default memory pool gives everything back to the driver whenever the stream is synchronised (release
     // threshold 0), and the next temporary is a real allocation again: milliseconds of an idle GPU in front of a
-    // 0.2 ms kernel for every caller that synchronises between calls.  Keep up to 2 GB of temporaries pooled (once
-    // per device and process).
+    // 0.2 ms kernel for every caller that synchronises between calls.  Keep up to 6 GB of temporaries pooled (once
+    // per device and process; the largest single temporary is the n x n correlation matrix of tl.ithcna: 2.5 GB at
+    // 25 000 cells per group).
     static void keep_pool() {
         static std::atomic<unsigned long long> done{0};
         int dev = 0;
@@ -225,7 +226,7 @@ struct AsyncBuf {
         if (done.fetch_or(bit) & bit) return;
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-            uint64_t keep = 2ull << 30;
+            uint64_t keep = 6ull << 30;
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
         }
     }
@@ -1851,20 +1852,14 @@ int icv_corr_iqr(const float* x, int64_t n, int32_t k, int64_t ld, double* h_iqr
     if (!x || !h_iqr || n < 2 || k < 1 || ld < k) return fail(ICV_ERR_INVALID, "bad corr_iqr arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int kz = icv::round_up(k, icv::GK);
-    float *z = nullptr, *c = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    struct Guard {  // frees the temporaries on every exit path
-        float *&z, *&c;
-        unsigned long long*& n;
-        ~Guard() {
-            (void)hipFree(z);
-            (void)hipFree(c);
-            (void)hipFree(n);
-        }
-    } guard{z, c, d_cnt};
-    HIP_TRY(hipMalloc((void**)&z, (size_t)n * kz * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&c, (size_t)n * n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&d_cnt, (4 * 2048 + 1) * sizeof(unsigned long long)));
+    // stream-ordered temporaries from the device's pool (kept between calls up to AsyncBuf's threshold: a fresh
+    // hipMalloc of the n x n matrix costs tens of milliseconds on a box whose VRAM has not been touched yet)
+    AsyncBuf z_b, c_b, cnt_b;
+    HIP_TRY(z_b.alloc((size_t)n * kz * sizeof(float), st));
+    HIP_TRY(c_b.alloc((size_t)n * n * sizeof(float), st));
+    HIP_TRY(cnt_b.alloc((4 * 2048 + 1) * sizeof(unsigned long long), st));
+    float *z = z_b.as<float>(), *c = c_b.as<float>();
+    unsigned long long* d_cnt = cnt_b.as<unsigned long long>();
     hipLaunchKernelGGL(icv::k_row_normalize, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, k, ld, z, kz);
     GramWork gw;
     if (int rc = launch_gram<false, true>(st, gw, z, kz, nullptr, gram_supers_sym(n, n), n, n, c, n, c, n)) return rc;
