@@ -1463,7 +1463,7 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_gene_fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = (int)((size_t)icv::kLdsLimit / lds);
-        if (per_cu > 4) per_cu = 4;  // 512-thread workgroups: 32 wavefronts per CU
+        if (per_cu > 2048 / icv::kGvThreads) per_cu = 2048 / icv::kGvThreads;  // 32 wavefronts per CU
         int64_t grid = (int64_t)pl->n_cu * per_cu;
         if (grid > n) grid = n;
         hipLaunchKernelGGL(icv::k_gene_fused, dim3((unsigned)grid), dim3(icv::kGvThreads), lds, st, win, ldw, n, W,
