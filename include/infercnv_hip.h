@@ -232,6 +232,26 @@ int icv_infercnv_run(icv_plan_t plan, const icv_matrix *m, const void *ref_lo, c
 int icv_profile_begin(icv_plan_t plan);
 int icv_profile_collect(icv_plan_t plan, icv_profile *out, int32_t max_records, int32_t *n_records);
 
+/* ---- the reference-order float32 chain by BLOCKS of rows (csrc/icv_kernel_blocks.hpp) ---------------------------
+ * icv_colchain evaluates np.mean's sequential float32 chain (reference :385) at HBM stream rate on ONE GPU, but row
+ * shards on several GPUs must take turns.  Inside one binade the chain is integer arithmetic (fl(s + x) = s + q ulp(s)
+ * with q = round(x / ulp(s)) independent of s except at exact ties), so a block of 64 rows whose chain stays inside its
+ * binade and holds no tie is ONE integer: the ranks compute them CONCURRENTLY from a float64 estimate of their start,
+ * and only a scan over the records (plus the rare replays) runs in row order.  Dense float32 matrices, all rows;
+ * everything else: ICV_ERR_UNSUPPORTED (use icv_colchain).  Bit-equal to icv_colchain for any estimate.
+ *   workspace: device buffer of icv_colchain_blocks_workspace(n_rows, n_cols) bytes, the same for the three calls
+ *   1. icv_colchain_blocks_sums:    float64 column totals of the matrix -> total[n_cols] (device); all-gather them
+ *   2. icv_colchain_blocks_records: est_start[n_cols] (device float64, NULL = 0) = the estimate of the chain value
+ *                                   before row 0 (sum of the earlier ranks' totals) -> the block records
+ *   3. icv_colchain_blocks_scan:    acc[n_cols] (device float32, in / out) = the EXACT chain values before row 0 (from
+ *                                   the previous rank) -> after the last row; columns [col0, col1) only (ranks pipeline
+ *                                   over column groups); d_replayed (device, optional) += blocks replayed row by row. */
+int icv_colchain_blocks_workspace(int64_t n_rows, int32_t n_cols, int64_t *bytes);
+int icv_colchain_blocks_sums(const icv_matrix *m, void *workspace, double *total, void *stream);
+int icv_colchain_blocks_records(const icv_matrix *m, void *workspace, const double *est_start, void *stream);
+int icv_colchain_blocks_scan(const icv_matrix *m, void *workspace, float *acc, int32_t col0, int32_t col1,
+                             uint64_t *d_replayed, void *stream);
+
 /* ---- calculate_gene_values=True (reference :247-298, :443-453) -------------------------------
  * Per-gene CNV values: mean of the kept windows that contain the gene (:274-288), minus the per-cell median
  * over the covered genes (:443-444), zeroed below the chunk's noise threshold (:452-453; `thr` from

@@ -217,6 +217,53 @@ def column_chain(dm: DeviceMatrix, acc=None, rows=None, count=None, row0=0, row1
     return acc
 
 
+class ChainBlocks:
+    """The reference-order float32 chain of a dense float32 matrix BY BLOCKS of rows (``icv_colchain_blocks_*``,
+    csrc/icv_kernel_blocks.hpp): what row-sharded ranks run so that they do not take turns on the chain.
+
+        cb = ChainBlocks(dm)                 # workspace on the device
+        total = cb.sums()                    # float64 column totals of these rows (concurrent; all-gather them)
+        cb.records(est_start)                # block records from the float64 estimate of the chain before row 0
+        cb.scan(acc)                         # acc: EXACT float32 chain values before row 0 -> after the last row
+
+    ``scan`` equals ``column_chain(dm, acc)`` bit for bit whatever ``est_start`` was (a wrong estimate costs replays)."""
+
+    def __init__(self, dm: "DeviceMatrix", row0=0, row1=None):
+        torch = _torch()
+        lib = _lib.load()
+        self.dm = dm
+        self.m = dm.c_struct(row0, row1)
+        nbytes = C.c_int64(0)
+        _lib.check(lib.icv_colchain_blocks_workspace(self.m.n_rows, self.m.n_cols, C.byref(nbytes)))
+        self.ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device="cuda")
+        self.replayed = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def sums(self):
+        torch = _torch()
+        total = torch.empty(self.m.n_cols, dtype=torch.float64, device="cuda")
+        _lib.check(_lib.load().icv_colchain_blocks_sums(C.byref(self.m), _ptr(self.ws), _ptr(total), _stream_ptr(torch)))
+        return total
+
+    def records(self, est_start=None):
+        torch = _torch()
+        if est_start is not None:
+            assert est_start.dtype == torch.float64 and est_start.is_cuda and est_start.numel() == self.m.n_cols
+            est_start = est_start.contiguous()
+        _lib.check(_lib.load().icv_colchain_blocks_records(C.byref(self.m), _ptr(self.ws), _ptr(est_start),
+                                                           _stream_ptr(torch)))
+
+    def scan(self, acc, cols=None):
+        torch = _torch()
+        assert acc.dtype == torch.float32 and acc.is_cuda and acc.numel() == self.m.n_cols and acc.is_contiguous()
+        c0, c1 = (0, self.m.n_cols) if cols is None else (int(cols[0]), int(cols[1]))
+        _lib.check(_lib.load().icv_colchain_blocks_scan(C.byref(self.m), _ptr(self.ws), _ptr(acc), c0, c1,
+                                                        _ptr(self.replayed), _stream_ptr(torch)))
+        return acc
+
+    def n_blocks(self):
+        return (-(-int(self.m.n_rows) // 64)) * int(self.m.n_cols)
+
+
 def chain_mean(acc, count, is_csr):
     """Means from the accumulators of :func:`column_chain`: ``acc / count`` in the matrix dtype for dense input
     (numpy's ``true_divide(sum, n)``); CSR accumulators already are the means (scipy scales the entries)."""

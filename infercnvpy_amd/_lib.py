@@ -29,6 +29,7 @@ EXPORTS = (
     "icv_plan_last_kernel", "icv_plan_se_tables",
     "icv_colsum", "icv_colchain", "icv_colsum_pairwise", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_infercnv_run_windows", "icv_gene_values_from_windows",
+    "icv_colchain_blocks_workspace", "icv_colchain_blocks_sums", "icv_colchain_blocks_records", "icv_colchain_blocks_scan",
     "icv_profile_begin", "icv_profile_collect",
     "icv_gene_values", "icv_csr_count", "icv_csr_fill", "icv_threshold_mask", "icv_csr_fill_masked", "icv_row_offsets", "icv_pack_geometry", "icv_threshold_pack", "icv_corr_iqr",
     "icv_pairwise_sqeuclidean", "icv_ward_linkage", "icv_pairwise_sqeuclidean_tiles",
@@ -110,6 +111,10 @@ def load():
     lib.icv_infercnv_run_windows.argtypes = [vp, P(Matrix), vp, vp, dbl, dbl, i64, i64, i32, vp, i64, vp, vp, vp,
                                              P(Profile), vp, i64, vp]
     lib.icv_gene_values_from_windows.argtypes = [vp, vp, i64, i64, vp, i64, i64, vp, i64, vp]
+    lib.icv_colchain_blocks_workspace.argtypes = [i64, i32, P(i64)]
+    lib.icv_colchain_blocks_sums.argtypes = [P(Matrix), vp, vp, vp]
+    lib.icv_colchain_blocks_records.argtypes = [P(Matrix), vp, vp, vp]
+    lib.icv_colchain_blocks_scan.argtypes = [P(Matrix), vp, vp, i32, i32, vp, vp]
     lib.icv_profile_begin.argtypes = [vp]
     lib.icv_profile_collect.argtypes = [vp, P(Profile), i32, P(i32)]
     lib.icv_gene_values.argtypes = [vp, P(Matrix), vp, vp, dbl, i32, vp, i64, i64, vp, i64, vp]

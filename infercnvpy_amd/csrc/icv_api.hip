@@ -30,6 +30,7 @@
 #include "icv_kernel_pack.hpp"
 #include "icv_kernel_util.hpp"
 #include "icv_kernel_gene.hpp"
+#include "icv_kernel_blocks.hpp"
 #include "icv_corr.hpp"
 #include "icv_ward.hpp"
 #include "icv_ward_strip.hpp"
@@ -1230,6 +1231,104 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
         hipLaunchKernelGGL(icv::k_colsum_finish, dim3((nc + 63) / 64), dim3(1024), 0, st, partial, (int)n_slabs, nc,
                            sums + (int64_t)g * nc);
     }
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+// ---- the reference-order float32 chain by blocks (csrc/icv_kernel_blocks.hpp): row shards that do not take turns -----
+namespace {
+struct BlocksLayout {  // one workspace, laid out here (the caller allocates icv_colchain_blocks_workspace() bytes)
+    int64_t n_slabs, n_blocks;
+    size_t partial_off, slab_rec_off, rec_off, count_off, stash_off, bytes;
+    unsigned stash_cap;
+    BlocksLayout(int64_t n_rows, int32_t n_cols) {
+        n_slabs = (n_rows + icv::kBkSlab - 1) / icv::kBkSlab;
+        if (n_slabs < 1) n_slabs = 1;
+        n_blocks = n_slabs * icv::kBkPerSlab;
+        const size_t nc = (size_t)(n_cols > 0 ? n_cols : 1);
+        auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+        partial_off = 0;
+        slab_rec_off = up(partial_off + (size_t)n_slabs * nc * 8);
+        rec_off = up(slab_rec_off + (size_t)n_slabs * nc * 4);
+        count_off = up(rec_off + (size_t)n_blocks * nc * 4);
+        stash_off = up(count_off + 256);
+        // stash: the blocks that cannot be summarised -- 0.1-1 % of the (block, column) pairs of a shard that starts
+        // inside the chains, ~1 % + the first few thousand rows of a shard that starts them; 3 % here, the rest is
+        // replayed from the matrix
+        const size_t want = (size_t)n_blocks * nc / 32 + 4096;
+        stash_cap = (unsigned)(want < 0x7ffffff0u ? want : 0x7ffffff0u);
+        bytes = up(stash_off + (size_t)stash_cap * icv::kBkRows * 4);
+    }
+};
+int blocks_check(const icv_matrix* m, const void* ws) {
+    if (!m || !ws) return fail(ICV_ERR_INVALID, "null matrix or workspace");
+    if (m->format != ICV_DENSE || m->dtype != ICV_F32)
+        return fail(ICV_ERR_UNSUPPORTED, "the block form of the chain takes dense float32 matrices (others: icv_colchain)");
+    if (m->n_rows < 0 || m->n_cols < 1 || m->ld < m->n_cols) return fail(ICV_ERR_INVALID, "bad matrix");
+    return ICV_OK;
+}
+}  // namespace
+
+int icv_colchain_blocks_workspace(int64_t n_rows, int32_t n_cols, int64_t* bytes) {
+    if (!bytes || n_rows < 0 || n_cols < 1) return fail(ICV_ERR_INVALID, "bad colchain_blocks_workspace arguments");
+    *bytes = (int64_t)BlocksLayout(n_rows, n_cols).bytes;
+    return ICV_OK;
+}
+
+int icv_colchain_blocks_sums(const icv_matrix* m, void* workspace, double* total, void* stream) {
+    int rc = blocks_check(m, workspace);
+    if (rc) return rc;
+    if (!total) return fail(ICV_ERR_INVALID, "total is required");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BlocksLayout L(m->n_rows, m->n_cols);
+    double* partial = reinterpret_cast<double*>(static_cast<char*>(workspace) + L.partial_off);
+    HIP_TRY(hipMemsetAsync(total, 0, (size_t)m->n_cols * sizeof(double), st));
+    if (m->n_rows == 0) return ICV_OK;
+    dim3 grid((m->n_cols + 255) / 256, (unsigned)L.n_slabs);
+    hipLaunchKernelGGL(icv::k_colsum_dense<float>, grid, dim3(256), 0, st, (const float*)m->values, m->n_rows, m->ld,
+                       m->n_cols, (const int32_t*)nullptr, 0, icv::kBkSlab, partial);
+    hipLaunchKernelGGL(icv::k_colsum_finish, dim3((m->n_cols + 63) / 64), dim3(1024), 0, st, partial, (int)L.n_slabs,
+                       m->n_cols, total);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_colchain_blocks_records(const icv_matrix* m, void* workspace, const double* est_start, void* stream) {
+    int rc = blocks_check(m, workspace);
+    if (rc) return rc;
+    if (m->n_rows == 0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BlocksLayout L(m->n_rows, m->n_cols);
+    char* w = static_cast<char*>(workspace);
+    double* partial = reinterpret_cast<double*>(w + L.partial_off);
+    HIP_TRY(hipMemsetAsync(w + L.count_off, 0, 256, st));
+    hipLaunchKernelGGL(icv::k_blocks_prefix, dim3((m->n_cols + 255) / 256), dim3(256), 0, st, partial, (int)L.n_slabs,
+                       m->n_cols, est_start, (double*)nullptr);
+    dim3 grid((m->n_cols + 255) / 256, (unsigned)L.n_slabs);
+    hipLaunchKernelGGL(icv::k_chain_records, grid, dim3(256), 0, st, (const float*)m->values, m->n_rows, m->ld, m->n_cols,
+                       partial, reinterpret_cast<uint32_t*>(w + L.rec_off), reinterpret_cast<uint32_t*>(w + L.slab_rec_off),
+                       reinterpret_cast<float*>(w + L.stash_off), reinterpret_cast<unsigned*>(w + L.count_off), L.stash_cap);
+    HIP_TRY(hipGetLastError());
+    return ICV_OK;
+}
+
+int icv_colchain_blocks_scan(const icv_matrix* m, void* workspace, float* acc, int32_t col0, int32_t col1,
+                             uint64_t* d_replayed, void* stream) {
+    int rc = blocks_check(m, workspace);
+    if (rc) return rc;
+    if (!acc || col0 < 0 || col1 > m->n_cols || col0 > col1) return fail(ICV_ERR_INVALID, "bad colchain_blocks_scan arguments");
+    if (m->n_rows == 0 || col1 == col0) return ICV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BlocksLayout L(m->n_rows, m->n_cols);
+    char* w = static_cast<char*>(workspace);
+    // (the column range: ranks pipeline the scan over column groups, as the chained form does)
+    const int nc = col1 - col0;
+    hipLaunchKernelGGL(icv::k_chain_scan, dim3((nc + 255) / 256), dim3(256), 0, st,
+                       (const float*)m->values + col0, m->n_rows, m->ld, nc, (int64_t)m->n_cols,
+                       reinterpret_cast<const uint32_t*>(w + L.rec_off) + col0,
+                       reinterpret_cast<const uint32_t*>(w + L.slab_rec_off) + col0,
+                       reinterpret_cast<const float*>(w + L.stash_off), acc + col0,
+                       reinterpret_cast<unsigned long long*>(d_replayed));
     HIP_TRY(hipGetLastError());
     return ICV_OK;
 }

@@ -196,6 +196,75 @@ def reference_means_chained(dm_local, counts_global, local_rows=None, group=None
     return means
 
 
+def reference_means_blocks(dm_local, n_total, group=None, n_col_groups=4, stats=None):
+    """The all-cell reference profile of a row-sharded DENSE float32 matrix in the reference's own evaluation order
+    (bit-equal to ``np.mean(X, axis=0)`` of the whole matrix, reference :385, and to :func:`reference_means_chained`)
+    WITHOUT the ranks taking turns on their rows (``csrc/icv_kernel_blocks.hpp``; proofs: ``tests/exact_chain_proto.py``).
+
+    Inside one binade a float32 chain is integer arithmetic, so a block of rows whose chain stays in its binade is one
+    integer ``Q`` that can be formed at any time -- it only needs the binade of its start, from a float64 estimate:
+
+    1. every rank adds the float64 column totals of its rows                       (one pass, concurrent)
+    2. ONE all-gather of ``[G]`` float64 per rank: rank k's start estimate = the totals of ranks < k
+    3. every rank forms its block records                                          (one pass, concurrent)
+    4. the exact float32 chain values travel rank to rank; a rank only SCANS its records (one word per 1024 rows and
+       column) and replays the few blocks that cannot be summarised (0.04-0.5 % on ranks > 0) -- pipelined over
+       ``n_col_groups`` column groups like the chained form -- and the last rank broadcasts the means.
+
+    Two passes over the shard instead of one, but both concurrent on all ranks: at 8 ranks the means cost ~2 passes of one
+    rank's rows + a scan, where the chained form costs (T + R - 1) / T = 4.5 passes.  Other inputs (CSR,
+    float64, categories) keep :func:`reference_means_chained`."""
+    import torch
+
+    from . import _engine, _lib
+
+    dist = _dist()
+    rank, size, peers = _group_ranks(group)
+    if dm_local.format != _lib.ICV_DENSE or dm_local.dtype != torch.float32:
+        raise ValueError("reference_means_blocks: dense float32 shards (use reference_means_chained)")
+    n_cols = dm_local.shape[1]
+    device = getattr(dm_local, "device", "cuda")
+    have_rows = dm_local.shape[0] > 0
+    cb = _engine.ChainBlocks(dm_local) if have_rows else None
+    total = cb.sums() if have_rows else torch.zeros(n_cols, dtype=torch.float64, device=device)
+    if size > 1:
+        on_host = total.is_cuda and dist.get_backend(group) != "nccl"
+        t = total.cpu() if on_host else total
+        gathered = [torch.empty_like(t) for _ in range(size)]
+        dist.all_gather(gathered, t, group=group)
+        est = torch.zeros_like(t)
+        for k in range(rank):  # (in rank order: every rank derives the same estimates)
+            est = est + gathered[k]
+        est = est.to(device) if on_host else est
+    else:
+        est = None
+    if have_rows:
+        cb.records(est)
+    acc = torch.zeros(n_cols, dtype=torch.float32, device=device)
+    col_groups = [(0, n_cols)] if size == 1 else chain_column_groups(n_cols, 4, n_col_groups)
+    for c0, c1 in col_groups:
+        if size > 1 and rank > 0:
+            buf = torch.empty(c1 - c0, dtype=torch.float32, device=device)
+            _p2p(buf, peers[rank - 1], send=False, group=group)
+            acc[c0:c1] = buf
+        if have_rows:
+            cb.scan(acc, cols=(c0, c1))
+        if size > 1 and rank < size - 1:
+            _p2p(acc[c0:c1].contiguous(), peers[rank + 1], send=True, group=group)
+    means = _engine.chain_mean(acc, int(n_total), False)[None, :]
+    if size > 1:
+        if means.is_cuda and dist.get_backend(group) != "nccl":
+            h = means.cpu()
+            dist.broadcast(h, peers[size - 1], group=group)
+            means = h.to(device)
+        else:
+            dist.broadcast(means, peers[size - 1], group=group)
+    if stats is not None and have_rows:
+        stats["blocks"] = cb.n_blocks()
+        stats["replayed"] = int(cb.replayed.item())
+    return means
+
+
 def chunk_moments(cell_stats, global_row0: int, chunksize: int, n_chunks_global: int):
     """Per global chunk (rows, sum x, sum x^2) contributed by this rank's rows.
 

@@ -233,3 +233,84 @@ def test_public_call_on_column_major_input_matches_numpy_order():
     _, got, _ = cnv.tl.infercnv(cnv.SimpleAnnData(X, obs=obs, var=var), inplace=False, chunksize=3000,
                                 reference_key="group", reference_cat=["n"])
     np.testing.assert_array_equal(got.toarray() == 0, exp.toarray() == 0)
+
+
+@pytest.mark.parametrize("shape,kind", [((5000, 20000), "gamma"), ((3001, 1337), "gamma"), ((64, 96), "gamma"),
+                                        ((1, 5), "gamma"), ((2500, 4099), "counts"), ((1500, 3000), "ties"),
+                                        ((4000, 999), "scaled"), ((900, 2000), "negative"), ((700, 513), "nan")])
+def test_chain_by_blocks_is_the_chain_bit_for_bit(shape, kind):
+    """icv_colchain_blocks_* (integer block records + scan, csrc/icv_kernel_blocks.hpp) against the chain kernel and
+    numpy: equal bits whatever the data -- integer counts (exact sums), values that tie in the upper binades, columns
+    scaled over 60 decades, a negative entry, a NaN -- and whatever the estimate of the start (right, wrong binade, NaN)."""
+    from infercnvpy_amd import _engine
+
+    torch = _engine._torch()
+    n, g = shape
+    rs = np.random.RandomState(n + g)
+    X = _expr(n, g, seed=n + g)
+    if kind == "counts":
+        X = np.floor(X * 4).astype(np.float32)
+    elif kind == "ties":
+        X = (np.round(X * 8) / 8 + (X > 0) * 1024).astype(np.float32)
+    elif kind == "scaled":
+        X = (X * np.float32(10.0) ** rs.randint(-30, 30, size=g).astype(np.float32)).astype(np.float32)
+    elif kind == "negative":
+        X[rs.randint(n), rs.randint(g)] = -1.5
+    elif kind == "nan":
+        X[n // 2, 7] = np.nan
+    dm = _engine.to_device_matrix(X)
+    want = _engine.column_chain(dm, None, None, n).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        ref = np.add.reduce(X, axis=0) if g > 1 and n >= 2 else want
+    np.testing.assert_array_equal(want, ref)
+    cb = _engine.ChainBlocks(dm)
+    total = cb.sums()
+    np.testing.assert_allclose(total.cpu().numpy(), X.sum(axis=0, dtype=np.float64), rtol=1e-12, atol=0)
+    cb.records(None)
+    got = cb.scan(torch.zeros(g, dtype=torch.float32, device="cuda")).cpu().numpy()
+    np.testing.assert_array_equal(got.view(np.int32), want.view(np.int32))
+    # continued from another matrix's exact values, with estimates of every quality
+    A = _expr(777, g, seed=3)
+    sA = _engine.column_chain(_engine.to_device_matrix(A), None, None, 777)
+    whole = _engine.column_chain(dm, sA.clone(), None, n).cpu().numpy()
+    estA = torch.from_numpy(A.sum(axis=0, dtype=np.float64)).cuda()
+    for est in (estA, estA * 2.1, estA * 0.3, torch.zeros_like(estA), torch.full_like(estA, float("nan"))):
+        cb.records(est)
+        got = cb.scan(sA.clone()).cpu().numpy()
+        np.testing.assert_array_equal(got.view(np.int32), whole.view(np.int32))
+    # column ranges (the ranks' pipeline) cover the columns
+    cb.records(estA)
+    acc = sA.clone()
+    for c0, c1 in ((0, g // 3), (g // 3, g // 3), (g // 3, g)):
+        cb.scan(acc, cols=(c0, c1))
+    np.testing.assert_array_equal(acc.cpu().numpy().view(np.int32), whole.view(np.int32))
+
+
+def test_chain_by_blocks_replays_little_at_config3_geometry():
+    """125 000 x 20 000 (one rank's rows of config 3 at 8 ranks) continued from a running chain: the scan replays well
+    under 1 % of the (block, column) pairs, and the result is the chain kernel's."""
+    from infercnvpy_amd import _engine
+
+    torch = _engine._torch()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    g = 20000
+
+    def rows(n):
+        x = torch._standard_gamma(torch.full((n, g), 0.3, device="cuda"), generator=gen)
+        return torch.where(x < 0.5, torch.zeros_like(x), x)
+
+    A, B = rows(125_000), rows(125_000)
+    dmA, dmB = _engine.DeviceMatrix(dense=A), _engine.DeviceMatrix(dense=B)
+    sA = _engine.column_chain(dmA, None, None, 250_000)
+    want = _engine.column_chain(dmB, sA.clone(), None, 250_000)
+    cbA, cbB = _engine.ChainBlocks(dmA), _engine.ChainBlocks(dmB)
+    tA = cbA.sums()
+    cbA.records(None)
+    gotA = cbA.scan(torch.zeros(g, dtype=torch.float32, device="cuda"))
+    assert torch.equal(gotA.view(torch.int32), sA.view(torch.int32))
+    cbB.sums()
+    cbB.records(tA)
+    gotB = cbB.scan(gotA.clone())
+    assert torch.equal(gotB.view(torch.int32), want.view(torch.int32))
+    assert int(cbB.replayed.item()) < 0.005 * cbB.n_blocks(), (int(cbB.replayed.item()), cbB.n_blocks())
+    assert int(cbA.replayed.item()) < 0.03 * cbA.n_blocks(), (int(cbA.replayed.item()), cbA.n_blocks())
