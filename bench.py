@@ -432,7 +432,9 @@ def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksiz
              bounds=None, row0=0, n_total=None, no_refmean=False, nnz_row=G, traffic_key=None, pack=False,
              means="allreduce"):
     """Time `steps` passes of the per-rank hot path (dist.run_shard) over the resident rows of `dm`; returns (seconds,
-    roofline dict).  means = "chained": the reference's own bits -- icv_colchain accumulators handed from rank to rank,
+    roofline dict).  means = "blocks": the reference's own bits with the ranks' passes CONCURRENT -- the float32 chain by
+    integer blocks (dist.reference_means_blocks: float64 totals, one all-gather, block records, a scan that travels);
+    "chained": the reference's own bits -- icv_colchain accumulators handed from rank to rank,
     pipelined over column groups (dist.reference_means_chained), the same computation as the N = 1 public call;
     "allreduce": float64 column sums + ONE all-reduce (correctly rounded means, concurrent)."""
     n_total = n_local if n_total is None else n_total
@@ -444,6 +446,8 @@ def hbm_step(torch, icd, _engine, plan, dm, n_local, fmt, window, step, chunksiz
     def one_step():
         if fixed_ref is not None:
             ref = fixed_ref
+        elif means == "blocks":
+            ref = icd.reference_means_blocks(dm, n_total)[0]
         elif means == "chained":
             ref = icd.reference_means_chained(dm, [n_total])[0]
         else:
@@ -771,8 +775,10 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         plan = GenePlan(v["chromosome"], v["start"], window_size=100, step=10)
         scale = {"workload": "BASELINE config 3's 1 000 000 cells on ONE rank through the per-rank code path of "
                              "bench.py --gpus N (means -> dist.run_shard(pack=True)); cells/s comparable with the N > 1 "
-                             "lines' value / value_allreduce_means", "n_gpus": 1, "cells": CONFIG3_CELLS, "steps": 3}
-        for form in ("chained", "allreduce"):
+                             "lines' value (blocks) / value_chained_means / value_allreduce_means.  On ONE rank the block "
+                             "form is two passes over the rows where the chain kernel needs one: it pays from 2 ranks on",
+                 "n_gpus": 1, "cells": CONFIG3_CELLS, "steps": 3}
+        for form in ("blocks", "chained", "allreduce"):
             dt, roof = hbm_step(torch, icd, _engine, plan, dm, CONFIG3_CELLS, "dense", 100, 10, CHUNK, steps=3,
                                 warmup=1, traffic_key="dense_w100", pack=True, means=form)
             scale[form] = {"ms_per_step": dt / 3 * 1e3, "value": CONFIG3_CELLS / (dt / 3), "unit": "cells/s",
@@ -820,6 +826,7 @@ def _summary(result):
            "roofline_frac": r(g(result, "roofline", "frac")), "kernel_ms": r(g(result, "roofline", "kernel_ms"))}
     if "value_allreduce_means" in result:
         out["value_allreduce_means"] = r(result["value_allreduce_means"], 0)
+        out["value_chained_means"] = r(result.get("value_chained_means"), 0)
     ex = result.get("extra") or {}
     c4 = ex.get("config4_csr_w250") or {}
     if "ms_per_step" in c4:
@@ -1003,14 +1010,19 @@ def main():
         # and reported beside it.
         common = dict(dist=dist, bounds=bounds, row0=row0, n_total=n_total, no_refmean=args.no_refmean, nnz_row=nnz_row,
                       traffic_key=traffic_key, pack=not args.engine_step)
+        # `value`: the reference's bits.  Dense float32 shards: the chain by integer blocks (the ranks' passes run
+        # concurrently); CSR shards: the chained accumulators (the only exact form there)
+        first = "blocks" if args.format == "dense" else "chained"
         dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
-                            args.steps, args.warmup, means="chained", **common)
+                            args.steps, args.warmup, means=first, **common)
+        dt_ch, roof_ch = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
+                                  args.chunksize, args.steps, args.warmup, means="chained", **common)
         dt_ar, roof_ar = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
                                   args.chunksize, args.steps, args.warmup, means="allreduce", **common)
     if dist is not None:
-        t = torch.tensor([dt, dt_ar], dtype=torch.float64, device="cpu" if dry else "cuda")
+        t = torch.tensor([dt, dt_ar, dt_ch], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt_ar = float(t[0].item()), float(t[1].item())
+        dt, dt_ar, dt_ch = float(t[0].item()), float(t[1].item()), float(t[2].item())
 
     def host_barrier(tag):
         """Ranks meet through the rendezvous store (CPU only): no collective kernel spins on the idle GPUs while rank
@@ -1037,7 +1049,8 @@ def main():
     result = {
         "metric": (f"cells/sec through tl.infercnv (window={args.window}), input resident in HBM" if not rank_path else
                    f"cells/sec through the tl.infercnv hot path (window={args.window}) as dist.run_shard on every rank "
-                   f"(reference-order means chained over the ranks), input resident in HBM"),
+                   f"(reference-order means: the float32 chain by integer blocks, concurrent over the ranks), input "
+                   f"resident in HBM"),
         "value": value,
         "unit": "cells/s",
         "n_gpus": n_gpus,
@@ -1060,9 +1073,9 @@ def main():
                         + ("; step = one cnv.tl.infercnv(adata) call, adata.X a CUDA tensor, X_cnv returned as device "
                            "CSR float64 (reference-order means, smoothing, noise threshold + CSR pack)"
                            if stages is not None else
-                           "; step = reference-order column means (icv_colchain accumulators handed from rank to "
-                           "rank, pipelined over 2 column groups: numpy's own bits, the computation of the N = 1 "
-                           "public call) + smoothing + thresholds "
+                           "; step = reference-order column means (numpy's own bits: the float32 chain by integer "
+                           "blocks, dist.reference_means_blocks -- float64 totals + one all-gather + block records on "
+                           "every rank at once, then a scan over the records from rank to rank) + smoothing + thresholds "
                            + ("applied while X_cnv is packed to device CSR (dist.run_shard(pack=True))" if not args.engine_step
                               else "applied in place (dist.run_shard)")),
             "io_dtype": "f32 matrix in, f32 x_res out",
@@ -1075,8 +1088,10 @@ def main():
             "parallelism": f"{n_gpus} rank(s) (torch.distributed world size "
                            f"{dist.get_world_size() if dist is not None else 1}, backend "
                            f"{('gloo, ALL RANKS ON cuda:0 (dry run)' if dry else 'nccl/RCCL') if dist is not None else 'none'}), "
-                           + ("row shards aligned to the chunks; value: the [G] float32 chain accumulators travel rank to "
-                              "rank point to point in 2 column groups + one broadcast of the means; value_allreduce_means: "
+                           + ("row shards aligned to the chunks; value: one all-gather of [G] float64 totals, the [G] float32 "
+                              "chain values travel rank to rank point to point in 4 column groups behind a scan of the "
+                              "block records, one broadcast of the means; value_chained_means: the accumulators of the "
+                              "chain kernel travel instead (the ranks' passes take turns); value_allreduce_means: "
                               "one all-reduce of the [G+1] float64 reference sums per step; no other collective"
                               if n_gpus > 1 else "one GPU, no collective"),
         },
@@ -1085,9 +1100,17 @@ def main():
     if rank_path:
         result["value_allreduce_means"] = n_total / (dt_ar / args.steps)
         result["ms_per_step_allreduce_means"] = dt_ar / args.steps * 1e3
+        result["value_chained_means"] = n_total / (dt_ch / args.steps)
+        result["ms_per_step_chained_means"] = dt_ch / args.steps * 1e3
         result["forms"] = {
-            "value": "reference means in the reference's own evaluation order (dist.reference_means_chained): X_cnv "
-                     "bit-identical to the one-GPU public call for any number of ranks",
+            "value": ("reference means in the reference's own evaluation order WITHOUT the ranks taking turns: the float32 "
+                      "chain by integer blocks (dist.reference_means_blocks: every rank adds float64 totals and forms "
+                      "its block records concurrently, one all-gather, a scan over the records travels rank to rank): "
+                      "X_cnv bit-identical to the one-GPU public call for any number of ranks"
+                      if args.format == "dense" else
+                      "CSR shards: the chained accumulators (value = value_chained_means)"),
+            "value_chained_means": "the same bits with the icv_colchain accumulators handed from rank to rank, pipelined "
+                                   "over 2 column groups (dist.reference_means_chained; rounds 4-5: the ranks take turns)",
             "value_allreduce_means": "float64 column sums + one all-reduce (dist.reference_means): correctly rounded "
                                      "means, concurrent over the ranks, ~1e-3 of the X_cnv entries next to the noise "
                                      "threshold may differ from the reference (tl.infercnv(mean_order='float64'))",

@@ -295,9 +295,12 @@ def test_chain_by_blocks_replays_little_at_config3_geometry():
     gen = torch.Generator(device="cuda").manual_seed(5)
     g = 20000
 
-    def rows(n):
-        x = torch._standard_gamma(torch.full((n, g), 0.3, device="cuda"), generator=gen)
-        return torch.where(x < 0.5, torch.zeros_like(x), x)
+    def rows(n):  # (in 5000-row pieces, as bench.py: one 125 000 x 20 000 draw leaves the first ~16 000 rows zero)
+        out = torch.empty((n, g), dtype=torch.float32, device="cuda")
+        for r in range(0, n, 5000):
+            x = torch._standard_gamma(torch.full((min(5000, n - r), g), 0.3, device="cuda"), generator=gen)
+            out[r:r + 5000] = torch.where(x < 0.5, torch.zeros_like(x), x)
+        return out
 
     A, B = rows(125_000), rows(125_000)
     dmA, dmB = _engine.DeviceMatrix(dense=A), _engine.DeviceMatrix(dense=B)
