@@ -1239,7 +1239,7 @@ int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, 
 namespace {
 struct BlocksLayout {  // one workspace, laid out here (the caller allocates icv_colchain_blocks_workspace() bytes)
     int64_t n_slabs, n_blocks;
-    size_t partial_off, slab_rec_off, rec_off, count_off, stash_off, bytes;
+    size_t partial_off, start_off, slab_rec_off, rec_off, count_off, stash_off, bytes;
     unsigned stash_cap;
     BlocksLayout(int64_t n_rows, int32_t n_cols) {
         n_slabs = (n_rows + icv::kBkSlab - 1) / icv::kBkSlab;
@@ -1248,7 +1248,8 @@ struct BlocksLayout {  // one workspace, laid out here (the caller allocates icv
         const size_t nc = (size_t)(n_cols > 0 ? n_cols : 1);
         auto up = [](size_t v) { return (v + 255) / 256 * 256; };
         partial_off = 0;
-        slab_rec_off = up(partial_off + (size_t)n_slabs * nc * 8);
+        start_off = up(partial_off + (size_t)n_slabs * nc * 8);
+        slab_rec_off = up(start_off + (size_t)n_slabs * nc * 8);
         rec_off = up(slab_rec_off + (size_t)n_slabs * nc * 4);
         count_off = up(rec_off + (size_t)n_blocks * nc * 4);
         stash_off = up(count_off + 256);
@@ -1300,13 +1301,14 @@ int icv_colchain_blocks_records(const icv_matrix* m, void* workspace, const doub
     hipStream_t st = static_cast<hipStream_t>(stream);
     const BlocksLayout L(m->n_rows, m->n_cols);
     char* w = static_cast<char*>(workspace);
-    double* partial = reinterpret_cast<double*>(w + L.partial_off);
+    const double* partial = reinterpret_cast<const double*>(w + L.partial_off);
+    double* slab_start = reinterpret_cast<double*>(w + L.start_off);
     HIP_TRY(hipMemsetAsync(w + L.count_off, 0, 256, st));
     hipLaunchKernelGGL(icv::k_blocks_prefix, dim3((m->n_cols + 255) / 256), dim3(256), 0, st, partial, (int)L.n_slabs,
-                       m->n_cols, est_start, (double*)nullptr);
+                       m->n_cols, est_start, slab_start);
     dim3 grid((m->n_cols + 255) / 256, (unsigned)L.n_slabs);
     hipLaunchKernelGGL(icv::k_chain_records, grid, dim3(256), 0, st, (const float*)m->values, m->n_rows, m->ld, m->n_cols,
-                       partial, reinterpret_cast<uint32_t*>(w + L.rec_off), reinterpret_cast<uint32_t*>(w + L.slab_rec_off),
+                       slab_start, reinterpret_cast<uint32_t*>(w + L.rec_off), reinterpret_cast<uint32_t*>(w + L.slab_rec_off),
                        reinterpret_cast<float*>(w + L.stash_off), reinterpret_cast<unsigned*>(w + L.count_off), L.stash_cap);
     HIP_TRY(hipGetLastError());
     return ICV_OK;
@@ -1323,7 +1325,11 @@ int icv_colchain_blocks_scan(const icv_matrix* m, void* workspace, float* acc, i
     char* w = static_cast<char*>(workspace);
     // (the column range: ranks pipeline the scan over column groups, as the chained form does)
     const int nc = col1 - col0;
-    hipLaunchKernelGGL(icv::k_chain_scan, dim3((nc + 255) / 256), dim3(256), 0, st,
+    // one wavefront per column, four per workgroup, up to eight workgroups per CU at a time
+    int64_t grid = ((int64_t)nc + 3) / 4;
+    const int64_t cap = (int64_t)current_cu_count() * 8;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(icv::k_chain_scan, dim3((unsigned)grid), dim3(256), 0, st,
                        (const float*)m->values + col0, m->n_rows, m->ld, nc, (int64_t)m->n_cols,
                        reinterpret_cast<const uint32_t*>(w + L.rec_off) + col0,
                        reinterpret_cast<const uint32_t*>(w + L.slab_rec_off) + col0,

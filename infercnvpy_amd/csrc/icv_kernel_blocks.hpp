@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "icv_kernels.hpp"
+
 namespace icv {
 
 constexpr int kBkRows = 64;                       // rows per block
@@ -35,19 +37,16 @@ constexpr unsigned kBkMargin = 1u << 13;          // ulps: the float64 estimate 
 constexpr unsigned kBkReplay = 0x80000000u;       // record: replay; low 31 bits = stash slot, kBkNoSlot = from the matrix
 constexpr unsigned kBkNoSlot = 0x7fffffffu;
 
-// slab_start[s][c] = est_start[c] + sum of partial[s'][c], s' < s (in place over `partial`); total[c] = the sum of all
-__global__ void __launch_bounds__(256) k_blocks_prefix(double* __restrict__ partial, int n_slabs, int n_cols,
-                                                       const double* __restrict__ est_start, double* __restrict__ total) {
+// slab_start[s][c] = est_start[c] + sum of partial[s'][c], s' < s
+__global__ void __launch_bounds__(256) k_blocks_prefix(const double* __restrict__ partial, int n_slabs, int n_cols,
+                                                       const double* __restrict__ est_start, double* __restrict__ slab_start) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= n_cols) return;
-    double run = est_start ? est_start[col] : 0.0, tot = 0.0;
+    double run = est_start ? est_start[col] : 0.0;
     for (int s = 0; s < n_slabs; ++s) {
-        const double p = partial[(int64_t)s * n_cols + col];
-        partial[(int64_t)s * n_cols + col] = run;
-        run += p;
-        tot += p;
+        slab_start[(int64_t)s * n_cols + col] = run;
+        run += partial[(int64_t)s * n_cols + col];
     }
-    if (total) total[col] = tot;
 }
 
 // one workgroup = 256 columns x one slab of 1024 rows; a thread walks its column block by block
@@ -78,7 +77,7 @@ __global__ void __launch_bounds__(256) k_chain_records(const float* __restrict__
         if (nr == kBkRows) {
 #pragma unroll 2
             for (int r = 0; r < kBkRows; r += 8) {
-                float v[8];
+                float v[8];  // (16 loads in flight measured the same: 2.0 ms per 125 000 x 20 000)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(xp + (int64_t)(r + u) * ld);
 #pragma unroll
@@ -133,73 +132,73 @@ __global__ void __launch_bounds__(256) k_chain_records(const float* __restrict__
     slab_rec[slab * n_cols + col] = (slab_ok && q_slab < 0x800000u) ? ((eb0 << 23) | q_slab) : (kBkReplay | kBkNoSlot);
 }
 
-// acc[c] (the exact float32 chain values before row 0 of this matrix, in / out): one thread per column walks the slab
-// records, the block records of slabs without one, and replays what has to be replayed
+// acc[c] (the exact float32 chain values before row 0 of this matrix, in / out).  ONE WAVEFRONT PER COLUMN: the lanes
+// hold 64 consecutive slab records, a DPP prefix sum applies every run of valid ones at once (valid for the TRUE start:
+// exponent equal, mantissa + prefix below 2^24 -- an integer add on the bit pattern), the first invalid slab is opened
+// (its 16 block records, the same way) and a block that has to be replayed arrives as ONE 256-byte load of its 64
+// stashed values (or 64 strided matrix loads) that the wavefront adds in order through lane reads.  (First version: one
+// THREAD per column -- the ~5 replays per column and rank, each a dependent load + 64 adds, ran one after the other
+// for the 64 columns of a wavefront: 0.28 ms per rank, serial over the ranks; this form: the latency of a replay is
+// paid per column, 8 192 wavefronts at a time.)
 __global__ void __launch_bounds__(256) k_chain_scan(const float* __restrict__ x, int64_t n_rows, int64_t ld, int n_cols,
                                                     int64_t rec_ld /* columns of the record tables (n_cols of a column range may be fewer) */,
                                                     const uint32_t* __restrict__ rec, const uint32_t* __restrict__ slab_rec,
                                                     const float* __restrict__ stash, float* __restrict__ acc,
                                                     unsigned long long* __restrict__ n_replayed) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= n_cols) return;
+    const int lane = threadIdx.x & 63;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const int64_t n_slabs = (n_rows + kBkSlab - 1) / kBkSlab;
-    unsigned sb = __float_as_uint(acc[col]);
     unsigned replays = 0;
-    const auto apply = [&](unsigned r) -> bool {  // a summarising record: valid for the true start?
-        const unsigned eb = (r >> 23) & 0xffu, q = r & 0x7fffffu;
-        if (!(r & kBkReplay) && (sb >> 23) == eb && (sb & 0x7fffffu) + q < 0x800000u) {
-            sb += q;  // the mantissa grows by Q ulps: an integer add on the bit pattern
-            return true;
-        }
-        return false;
-    };
-    constexpr int PFS = 8;  // slab records in flight
-    for (int64_t s0 = 0; s0 < n_slabs; s0 += PFS) {
-        uint32_t sr[PFS];
-#pragma unroll
-        for (int u = 0; u < PFS; ++u) sr[u] = s0 + u < n_slabs ? slab_rec[(s0 + u) * rec_ld + col] : 0u;
-#pragma unroll 1
-        for (int u = 0; u < PFS && s0 + u < n_slabs; ++u) {
-            if (apply(sr[u])) continue;
-            const int64_t s = s0 + u;
-            uint32_t br[kBkPerSlab];
-#pragma unroll
-            for (int b = 0; b < kBkPerSlab; ++b) {
-                const int64_t r0 = (s * kBkPerSlab + b) * kBkRows;
-                br[b] = r0 < n_rows ? rec[(s * kBkPerSlab + b) * rec_ld + col] : 0u;  // (0: adds nothing)
+    for (int col = wave_id; col < n_cols; col += n_waves) {
+        unsigned sb = __float_as_uint(acc[col]);  // (uniform)
+        // records r[0 .. cnt) in the lanes: apply every valid run, call `open(i)` for the first record that is not
+        const auto walk = [&](unsigned r, int cnt, auto&& open) {
+            int pos = 0;
+            while (pos < cnt) {
+                const bool live = lane >= pos && lane < cnt;
+                const bool plain = live && !(r & kBkReplay);
+                const int q = plain ? (int)(r & 0x7fffffu) : 0;
+                const int incl = wave_scan_dpp(q);
+                const bool ok = lane < pos || (plain && ((r >> 23) & 0xffu) == (sb >> 23) &&
+                                               (sb & 0x7fffffu) + (unsigned)incl < 0x800000u);
+                const unsigned long long bad = ~__builtin_amdgcn_ballot_w64(ok);
+                int first = bad ? (int)__builtin_ctzll(bad) : 64;
+                first = first < cnt ? first : cnt;
+                if (first > pos) sb += (unsigned)__builtin_amdgcn_readlane(incl, first - 1);
+                if (first >= cnt) break;
+                open(first);
+                pos = first + 1;
             }
-#pragma unroll 1
-            for (int b = 0; b < kBkPerSlab; ++b) {
-                const int64_t r0 = (s * kBkPerSlab + b) * kBkRows;
-                if (r0 >= n_rows) break;
-                if (apply(br[b])) continue;
-                // replay: the block's rows one after the other, in float32 (what the chain kernels do for every row)
-                ++replays;
-                float sv = __uint_as_float(sb);
-                const unsigned slot = br[b] & 0x7fffffffu;
-                if ((br[b] & kBkReplay) && slot != kBkNoSlot && stash) {
-                    const float4* sp = reinterpret_cast<const float4*>(stash + (size_t)slot * kBkRows);
-                    float4 v[kBkRows / 4];
-#pragma unroll
-                    for (int i = 0; i < kBkRows / 4; ++i) v[i] = sp[i];
-#pragma unroll
-                    for (int i = 0; i < kBkRows / 4; ++i) {
-                        sv = sv + v[i].x;
-                        sv = sv + v[i].y;
-                        sv = sv + v[i].z;
-                        sv = sv + v[i].w;
-                    }
-                } else {
+        };
+        for (int64_t s0 = 0; s0 < n_slabs; s0 += 64) {
+            const int cnt = (int)(n_slabs - s0 < 64 ? n_slabs - s0 : 64);
+            const unsigned sr = lane < cnt ? slab_rec[(s0 + lane) * rec_ld + col] : 0u;
+            walk(sr, cnt, [&](int si) {
+                const int64_t s = s0 + si;
+                const int64_t rows_left = n_rows - s * kBkSlab;
+                const int nb = (int)(rows_left >= kBkSlab ? kBkPerSlab : (rows_left + kBkRows - 1) / kBkRows);
+                const unsigned br = lane < nb ? rec[(s * kBkPerSlab + lane) * rec_ld + col] : 0u;
+                walk(br, nb, [&](int bi) {
+                    // replay: the block's rows one after the other, in float32 (what the chain kernels do for every row)
+                    ++replays;
+                    const unsigned rb = (unsigned)__builtin_amdgcn_readlane((int)br, bi);
+                    const int64_t r0 = (s * kBkPerSlab + bi) * (int64_t)kBkRows;
                     const int nr = (int)(n_rows - r0 < kBkRows ? n_rows - r0 : kBkRows);
-                    const float* xp = x + r0 * ld + col;
-                    for (int r = 0; r < nr; ++r) sv = sv + xp[(int64_t)r * ld];
-                }
-                sb = __float_as_uint(sv);
-            }
+                    const unsigned slot = rb & 0x7fffffffu;
+                    float v;
+                    if ((rb & kBkReplay) && slot != kBkNoSlot && stash) v = stash[(size_t)slot * kBkRows + lane];
+                    else v = lane < nr ? x[(r0 + lane) * ld + col] : 0.0f;
+                    float sv = __uint_as_float(sb);
+#pragma unroll 8
+                    for (int i = 0; i < kBkRows; ++i)
+                        sv = sv + __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), i));
+                    sb = __float_as_uint(sv);
+                });
+            });
         }
+        if (lane == 0) acc[col] = __uint_as_float(sb);
     }
-    acc[col] = __uint_as_float(sb);
-    if (n_replayed && replays) atomicAdd(n_replayed, (unsigned long long)replays);
+    if (n_replayed && replays && lane == 0) atomicAdd(n_replayed, (unsigned long long)replays);
 }
 
 }  // namespace icv
