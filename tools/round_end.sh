@@ -2,10 +2,10 @@
 # Evidence run on the GPU box (one gpurun call): tests, smoke, the default bench line (stages, e2e, extra legs), rocprofv3
 # kernel statistics of the bench step / config 4 / CSR window 100 / config 5, PMC passes (FETCH_SIZE and WRITE_SIZE in
 # separate runs, --kernel-trace only; instruction mix), the N-rank dry run on one GPU.
-#   ROUND=r05 tools/round_end.sh [quick]      -> gpurun_out/${ROUND}final/   (copy what is to be judged into profiles/)
+#   ROUND=r06 tools/round_end.sh [quick]      -> gpurun_out/${ROUND}final/   (copy what is to be judged into profiles/)
 set -u
 REPO=$PWD
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 O=$REPO/gpurun_out/${ROUND}final; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import torch; print(torch.cuda.get_device_name(0), torch.cuda.device_count())" > $O/box.txt 2>&1
@@ -28,6 +28,7 @@ stats dense_w100 --steps 20 --warmup 3 $BASE
 stats csr_w250 --format csr --cells 500000 --window 250 --steps 5 --warmup 2 $BASE
 stats csr_w100 --format csr --cells 200000 --window 100 --steps 5 --warmup 2 $BASE
 stats config5 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --extra config5
+stats gene_values_scores --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --extra scores_and_gene_values
 pmc() {  # label, bench.py arguments...
   label=$1; shift
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
@@ -41,6 +42,26 @@ pmc() {  # label, bench.py arguments...
 pmc dense_w100_100000_cells --steps 2 --warmup 1 $BASE
 pmc csr_w250_500000_cells --format csr --cells 500000 --window 250 --steps 2 --warmup 1 $BASE
 pmc csr_w100_200000_cells --format csr --cells 200000 --window 100 --steps 2 --warmup 1 $BASE
+pmc_hbm() {  # label, bench.py arguments...: HBM traffic only (two passes)
+  label=$1; shift
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    (cd /tmp && timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/_p -o pmc -- python $REPO/bench.py "$@" > $O/pmc_${label}_$grp.log 2>&1)
+    f=$(find $O/_p -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && (echo "== $label --pmc $grp"; python $REPO/tools/summarize_pmc.py "$f") | tee -a $O/pmc_summary.txt | head -30
+    rm -rf $O/_p
+  done
+}
+pmc_hbm gene_values_100000_cells --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --extra scores_and_gene_values
+# round 6: the CSR means over the density, the chain by integer blocks (one rank's share), the HBM write ceiling, clocks and
+# power over the sustained 1 M-cell leg
+timeout 400 python tools/time_csr_means.py 2>/dev/null | tee $O/csr_means_density.txt
+timeout 300 python tools/time_chain_blocks.py 2>/dev/null | tee $O/chain_blocks_times.txt
+timeout 120 python tools/time_hbm_write.py 2>/dev/null | tee $O/hbm_write.txt
+( while true; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power \(W\)|Average Graphics" | tr -s " " | tr "\n" ";"; echo; sleep 0.25; done > $O/clocks_1m_leg.txt ) &
+CLK=$!
+timeout 600 python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-e2e --extra config3_cells_on_one_gpu > $O/bench_1m_leg.json 2> $O/bench_1m_leg.err
+kill $CLK 2>/dev/null
+tail -1 $O/bench_1m_leg.err | cut -c1-600
 # round 5: k_smooth_se at three densities, the host-side packing of the sparse upload, fuzzers and the soak on the final tree
 for d in 0.02 0.07 0.14; do
   timeout 300 python bench.py --format csr --cells 500000 --window 250 --density $d --steps 10 --warmup 2 $BASE 2>/dev/null | python -c "

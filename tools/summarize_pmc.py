@@ -10,7 +10,7 @@ for r in rows:
     k = r.get("Kernel_Name", "?")[:60]
     acc[k][r.get("Counter_Name", "?")].append(float(r.get("Counter_Value", 0)))
 for k, cs in acc.items():
-    if not any(w in k for w in ("smooth", "apply", "colsum", "colchain", "thr_", "csr_", "row_offsets", "gram", "ward")):
+    if not any(w in k for w in ("smooth", "apply", "colsum", "colchain", "thr_", "csr_", "row_offsets", "gram", "ward", "gene", "chain_", "key_hist")):
         continue
     print(k)
     for c, vals in sorted(cs.items()):
