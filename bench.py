@@ -17,13 +17,15 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           (k_thr_mask_ring, k_row_offsets, k_csr_fill_ring; reference _infercnv.py:449-455 is inside the chunk kernel)
           -> X_cnv as device CSR float64.
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
-  N > 1   one process per GPU over the rows of config 3 (dist.run_shard per rank).  TWO forms of the reference means
-          are timed back to back, K steps each: `value` = the reference's own evaluation order (icv_colchain
-          accumulators handed from rank to rank, pipelined over 2 column groups, means broadcast:
-          dist.reference_means_chained -- the same computation as the N = 1 public call, X_cnv bit-identical for any
-          N); `value_allreduce_means` = float64 column sums + ONE RCCL all-reduce of [G + 1] float64 (concurrent,
-          correctly rounded means: tl.infercnv(mean_order="float64")).  Both -> the same smoothing kernel -> per-chunk
-          std -> noise threshold + CSR pack (dist.run_shard(pack=True)).
+  N > 1   one process per GPU over the rows of config 3 (dist.run_shard per rank).  THREE forms of the reference means
+          are timed back to back, K steps each: `value` = the reference's own evaluation order with the ranks' passes
+          CONCURRENT -- the float32 chain by integer blocks (dist.reference_means_blocks: float64 totals, ONE all-gather of
+          [G] float64, block records on every rank at once, a scan over the records from rank to rank, means broadcast:
+          X_cnv bit-identical to the N = 1 public call for any N); `value_chained_means` = the same bits with the
+          icv_colchain accumulators handed from rank to rank (dist.reference_means_chained: the ranks take turns);
+          `value_allreduce_means` = float64 column sums + ONE RCCL all-reduce of [G + 1] float64 (concurrent, correctly
+          rounded means -- not the reference's bits: tl.infercnv(mean_order="float64")).  All -> the same smoothing kernel ->
+          per-chunk std -> noise threshold + CSR pack (dist.run_shard(pack=True)).
           The N = 1 line carries `scale_n1`: config 3's 1 M cells on ONE rank through this same per-rank code path,
           both forms -- the N = 1 point a scaling curve over the N > 1 lines starts from.
   N > 1   BASELINE config 3: 1 000 000 cells x 20 000 genes in total, row shards aligned to the 5000-cell chunks
