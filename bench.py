@@ -718,6 +718,24 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
                 "note": "whole call (means + smoothing + threshold / CSR pack + gene values) against the algorithmic bytes "
                         "4 G in + 4 W x_res out + 8 G gene values out per cell (the float64 cells x genes layer is the "
                         "reference's output type, tl/_infercnv.py:147-149)"})}
+        # the same flag on 10x-style CSR input (k_smooth_se also stores its windows): 100 000 cells, density 0.07, window 100
+        ip, ix, dv = synth_csr_on_device(torch, cells, G, 0.07, seed=3)
+        adc = SimpleAnnData(_engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(cells, G)), var=var)
+        ms_plain_c = timed(lambda: cnv.tl.infercnv(adc), 5, 2)
+
+        def gv_call_csr():
+            adc.layers.clear()
+            cnv.tl.infercnv(adc, calculate_gene_values=True)
+
+        ms_gv_c = timed(gv_call_csr, 3, 2)
+        nnz_row = dv.numel() / cells
+        out["gene_values_csr_w100"] = {
+            "ms_per_call": ms_gv_c, "plain_call_ms": ms_plain_c, "ratio_to_plain_call": ms_gv_c / ms_plain_c,
+            "nnz_per_cell": nnz_row,
+            "roofline": _roof((8 * nnz_row + 8 + 4 * W + 8 * G) * cells, ms_gv_c, {
+                "note": "whole call on CSR fp32 input (density 0.07, window 100): 8 B per stored entry in + 4 W x_res out + "
+                        "8 G gene values out per cell"})}
+        del adc, ip, ix, dv
         x_cnv = ad.obsm["X_cnv"]
         nnz = x_cnv.nnz()
         ms_score = timed(lambda: cnv.tl.cnv_score(ad, "group"), 20, 2)
@@ -753,7 +771,9 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
 
     def ordered_leg(X, cells, steps, label):
         ad = SimpleAnnData(X, var=var_pos)
-        dt, roof, nnz = api_step(torch, _engine, ad, steps, 2, "dense", 100, 10, traffic_key=None)
+        # (five untimed calls: the result buffers of both generations exist before the clock starts -- a first 2 GB
+        # allocation on a box whose VRAM has not been touched costs ~0.15 s)
+        dt, roof, nnz = api_step(torch, _engine, ad, steps, 5, "dense", 100, 10, traffic_key=None)
         plan = T._cached_plan(var_pos["chromosome"].to_numpy(), var_pos["start"].to_numpy(), 100, 10, ("chrX", "chrY"),
                               torch.cuda.current_device())
         roof["kernel"] = "k_smooth_x16<10,10,chunk moments> (dense fp32, window 100 / step 10, position-ordered columns)"
@@ -762,7 +782,7 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
                 "roofline": roof}
 
     leg("config2_position_ordered_var", lambda: ordered_leg(
-        synth_rows(torch, 0, CONFIG2_CELLS, G), CONFIG2_CELLS, 100,
+        synth_rows(torch, 0, CONFIG2_CELLS, G), CONFIG2_CELLS, 200,
         "BASELINE config 2's matrix with adata.var in genome order (chromosomes one after the other, positions "
         "ascending): one cnv.tl.infercnv(adata) call per step, HBM resident, reference = all-cell mean"))
 
@@ -844,6 +864,7 @@ def _summary(result):
         out["gene_values_ms"] = r(g(sg, "gene_values", "ms_per_call"))
         out["gene_values_ratio_to_plain"] = r(g(sg, "gene_values", "ratio_to_plain_call"))
         out["gene_values_roofline_frac"] = r(g(sg, "gene_values", "roofline", "frac"))
+        out["gene_values_csr_w100_ms"] = r(g(sg, "gene_values_csr_w100", "ms_per_call"))
         out["cnv_score_ms"] = r(g(sg, "cnv_score", "ms_per_call"))
         out["ithcna_ms"] = r(g(sg, "ithcna", "ms_per_call"))
     elif "error" in sg:

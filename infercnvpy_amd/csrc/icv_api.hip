@@ -280,7 +280,7 @@ int ensure_device(icv_plan_t pl) {
         bool ok = p.W <= 65535 && R < 32768;
         std::vector<uint32_t> pk(R);
         for (size_t r = 0; r < R && ok; ++r) {
-            ok = p.gv_run_cnt[r] <= 65535 && p.gv_run_mult[r] <= 65535;
+            ok = p.gv_run_cnt[r] <= 128 && p.gv_run_mult[r] <= 65535;  // (<= 128 windows per gene: gv_numpy_sum)
             pk[r] = (uint32_t)p.gv_run_j0[r] | ((uint32_t)p.gv_run_cnt[r] << 16);
         }
         std::vector<int16_t> c16(((size_t)p.n_cols_all + 7) / 8 * 8, (int16_t)-1);

@@ -49,7 +49,9 @@ __host__ __device__ inline size_t gv_lds_bytes(int W, int R, int mult_bytes = 2)
     return w + (size_t)R * 8 + ((size_t)R * mult_bytes + 15) / 16 * 16;
 }
 
-// numpy's float64 add.reduce of a[0..n) in LDS, n <= 128 inlined (the recursion of numpy_sum above that)
+// numpy's float64 add.reduce of a[0..n) in LDS for n <= 128 (the launcher sends plans with longer runs -- a gene covered
+// by more than 128 kept windows: step 1 with a window beyond 128 -- to the round-1 kernels, whose numpy_sum recurses: the
+// call alone cost this kernel a 192-byte stack frame)
 __device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
     if (n < 8) {
         double r = 0.0;
@@ -69,7 +71,7 @@ __device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
         for (; i < n; ++i) res += a[i];
         return res;
     }
-    return numpy_sum(a, n);
+    return __builtin_nan("");  // (never reached: gv_fused_ok)
 }
 
 // run_pk[r] = first window | #windows << 16 of run r; col_run16[c] = run of input column c or -1 (padded to a multiple of
