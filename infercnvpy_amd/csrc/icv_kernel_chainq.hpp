@@ -161,6 +161,15 @@ __device__ __forceinline__ int wave_max_nonneg_dpp(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// what a producer does between two looks at a hand-over word (ICV_Q_SLEEP: developer knob of tools/build_variant.sh)
+#ifndef ICV_Q_SLEEP
+#define ICV_Q_SLEEP 1
+#endif
+#if ICV_Q_SLEEP > 0
+#define ICV_Q_WAIT() __builtin_amdgcn_s_sleep(ICV_Q_SLEEP)
+#else
+#define ICV_Q_WAIT() ((void)0)
+#endif
 __device__ __forceinline__ unsigned q_load(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -417,7 +426,7 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
             n = wave_max_nonneg_dpp(n);
             // 3. rows of the stream, in round order.  A round never wraps around the ring: if its rows do not fit
             // before the end, the rest of the ring becomes zero rows (adding zeros is exact) and the round starts at 0.
-            while (q_load(ctl + 0) != k) __builtin_amdgcn_s_sleep(1);
+            while (q_load(ctl + 0) != k) ICV_Q_WAIT();
             const unsigned start = __builtin_amdgcn_readfirstlane(ctl[1]);
             const int pos0 = __builtin_amdgcn_readfirstlane((int)ctl[2]);
             const int pad = pos0 + n > n_ring ? n_ring - pos0 : 0;
@@ -431,7 +440,7 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
             }
             // the chain must be done with what these ring rows held a lap ago
             const unsigned need = start + (unsigned)(pad + n) - (unsigned)n_ring;
-            while ((int)(q_load(ctl + 5) - need) < 0) __builtin_amdgcn_s_sleep(1);
+            while ((int)(q_load(ctl + 5) - need) < 0) ICV_Q_WAIT();
             // 4. zeros: the padding rows up to the end of the ring, the round's rows
             unsigned char* z1 = smem + (size_t)pos0 * row_bytes;
             for (int o = lane * 16; o < pad * row_bytes; o += 64 * 16) *reinterpret_cast<uint4*>(z1 + o) = make_uint4(0, 0, 0, 0);
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(kChThreads) k_colchain_csrq(const T* __restric
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(cm) + lane * 16) = make_uint4(0, 0, 0, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows are complete)
             // 7. publish, in round order
-            while (q_load(ctl + 3) != k) __builtin_amdgcn_s_sleep(1);
+            while (q_load(ctl + 3) != k) ICV_Q_WAIT();
             if (lane == 0) {
                 ctl[4] = start + (unsigned)(pad + n);
                 q_store(ctl + 3, k + 1u);

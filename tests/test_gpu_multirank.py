@@ -181,14 +181,15 @@ def test_sharded_ward_two_processes_one_gpu(world, n, d, in_place):
 _HP_GENES = [700, 320, 150, 100, 60]
 # geometry -> (genes per chromosome, cells, chunksize); "cfg3" = BASELINE config 3's own geometry (20 000 genes on
 # chr1..22, 5000-cell chunks: k_smooth_x16's chunk-moment partials cross a shard cut when the shards are unaligned)
-_HP_GEOM = {"small": (_HP_GENES, 2300, 500), "cfg3": (cases.GENES_PER_CHROM_20K, 12_500, 5000)}
+_HP_GEOM = {"small": (_HP_GENES, 2300, 500), "cfg3": (cases.GENES_PER_CHROM_20K, 12_500, 5000),
+            "tiny": (_HP_GENES, 1000, 500)}  # (two chunks: with three ranks one of them owns no rows)
 
 
 def _hp_inputs(fmt, geom="small"):
     import scipy.sparse as sp
 
     genes, n, _ = _HP_GEOM[geom]
-    v = cases.synthetic_var(genes, extra=(("chrX", 40), (None, 6)) if geom == "small" else ())
+    v = cases.synthetic_var(genes, extra=(("chrX", 40), (None, 6)) if geom != "cfg3" else ())
     n_genes = len(v["names"]) - len(v["names"]) % 4
     for key in ("chromosome", "start"):
         v[key] = v[key][:n_genes]
@@ -285,7 +286,7 @@ def _hp_worker(rank, world, port, fmt, window, geom, means, q):
     (2, "dense", 100, "small", "allreduce"), (3, "dense", 100, "small", "allreduce"), (2, "csr", 100, "small", "allreduce"),
     (3, "csr", 250, "small", "allreduce"), (3, "dense", 100, "small", "chain"), (2, "csr", 250, "small", "chain"),
     (3, "dense", 100, "cfg3", "allreduce"), (3, "dense", 100, "cfg3", "chain"), (2, "csr", 100, "cfg3", "chain"),
-    (2, "dense", 100, "small", "blocks"), (3, "dense", 100, "cfg3", "blocks")])
+    (2, "dense", 100, "small", "blocks"), (3, "dense", 100, "cfg3", "blocks"), (3, "dense", 100, "tiny", "blocks")])
 def test_hot_path_ranks_on_one_gpu(world, fmt, window, geom, means):
     """BASELINE config 3's code path (row shards, ONE all-reduce of the reference sums -- or the reference-order chains
     handed from rank to rank --, chunk-aligned and unaligned thresholds) with 2-3 ranks sharing cuda:0, at a small
