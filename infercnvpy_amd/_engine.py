@@ -825,6 +825,9 @@ def threshold_csr(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi, res, *, lfc_
     lib = _lib.load()
     rows = res.out.shape[0]
     W = plan.n_windows
+    if (dm.shape[0] if row1 is None else row1) - row0 == 0:  # an empty shard packs to an empty matrix
+        return PackedCsr(torch.zeros(1, dtype=torch.int64, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"),
+                         torch.empty(1, dtype=torch.float64, device="cuda"), W, res.thr)
     if single_pass and W <= 20480:
         return threshold_pack(plan, dm, ref_lo, ref_hi, res, lfc_clip=lfc_clip, chunksize=chunksize,
                               row_phase=row_phase, flags=flags, row0=row0, row1=row1, capacity=capacity)
@@ -1206,6 +1209,11 @@ def run_hot_path(plan: GenePlan, dm: DeviceMatrix, ref_lo, ref_hi=None, *, lfc_c
     assert out.dtype == torch.float32 and out.shape[0] >= rows and out.shape[1] >= W and out.stride(1) == 1
     med = torch.empty(rows, dtype=torch.float64, device="cuda")
     stats = torch.empty((rows, 2), dtype=torch.float64, device="cuda") if cell_stats else None
+    if rows == 0:  # a rank that owns no rows (more ranks than chunks): nothing to launch, no chunk, no threshold
+        res = SmoothResult(out, med, stats,
+                           None if dynamic_threshold is None else torch.empty(0, dtype=torch.float64, device="cuda"), None)
+        res.windows = torch.empty((0, W), dtype=torch.float64, device="cuda") if windows else None
+        return res
     dyn = float("nan") if dynamic_threshold is None else float(dynamic_threshold)
     thr = None
     if dynamic_threshold is not None:

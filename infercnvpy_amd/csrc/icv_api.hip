@@ -1625,6 +1625,7 @@ int icv_infercnv_run_windows(icv_plan_t pl, const icv_matrix* m, const void* ref
     if (rc) return rc;
     PLAN_BUSY_GUARD(pl);
     const bool do_thr = !std::isnan(dynamic_threshold);
+    if (m->n_rows == 0) return ICV_OK;  // an empty shard: no cell, no chunk, nothing written
     if (!cell_median) return fail(ICV_ERR_INVALID, "cell_median is required");
     if (do_thr && (!thr || chunksize < 1 || row_phase < 0 || row_phase >= chunksize))
         return fail(ICV_ERR_INVALID, "thr buffer / chunksize / row_phase invalid");

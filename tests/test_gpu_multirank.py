@@ -243,7 +243,7 @@ def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window, geo
         torch.cuda.synchronize()
         outs[ab is None] = (res.out.cpu().numpy(), None if res.thr is None else res.thr.cpu().numpy())
     # the same shard with the thresholds applied while X_cnv is packed to device CSR (what bench.py --gpus N times)
-    if r1 > r0:
+    if True:  # (an empty shard packs to an empty matrix)
         import scipy.sparse as sp
 
         _, pk = icd.run_shard(plan, dm, ref_lo, ref_hi, global_row0=r0, n_obs_global=n_all, chunksize=cs, all_bounds=bounds,
