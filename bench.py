@@ -715,6 +715,11 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
             "ms_per_call": ms_gv, "plain_call_ms": ms_plain, "ratio_to_plain_call": ms_gv / ms_plain,
             "cells_per_s": cells / (ms_gv * 1e-3), "nan_entries_in_first_64_rows": n_nan,
             "roofline": _roof(gv_bytes, ms_gv, {
+                "traffic": (lambda t: sum(t) if all(t) else None)(
+                    [pmc_traffic(k, cells) for k in ("colchain_dense", "dense_w100_windows", "thr_mask_ring",
+                                                     "csr_fill_ring", "gene_fused")]),
+                "traffic_note": "PMC bytes of the call's five large kernels (profiles/pmc_traffic.json): the matrix is read "
+                                "twice (means, smoothing), x_res three times written / read, the float64 windows once each way",
                 "note": "whole call (means + smoothing + threshold / CSR pack + gene values) against the algorithmic bytes "
                         "4 G in + 4 W x_res out + 8 G gene values out per cell (the float64 cells x genes layer is the "
                         "reference's output type, tl/_infercnv.py:147-149)"})}
