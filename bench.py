@@ -336,19 +336,22 @@ def e2e_legs(torch, window_dense=100, dense_cells=200_000, csr_cells=500_000):
     import scipy.sparse as sp
 
     legs = {}
-    Xd = synth_rows(torch, 0, dense_cells, G).cpu().numpy()
-    _e2e_run(f"dense fp32 {dense_cells} x 20000, window {window_dense}", Xd, window_dense, legs, devices=[0])
-    _e2e_run(f"dense fp32 {dense_cells} x 20000, window {window_dense}, reference=None (means on the GPU, in numpy's order)",
-             Xd, window_dense, legs, devices=[0], repeats=1, default_reference=True)
-    del Xd
-    ip, ix, dv = synth_csr_on_device(torch, csr_cells, G, 0.07, seed=3)
-    Xs = sp.csr_matrix((dv.cpu().numpy(), ix.cpu().numpy(), ip.cpu().numpy()), shape=(csr_cells, G))
-    del ip, ix, dv
-    torch.cuda.empty_cache()
-    _e2e_run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250 (BASELINE config 4)", Xs, 250, legs, devices=[0])
-    _e2e_run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250, reference=None (means on the GPU, in scipy's order)",
-             Xs, 250, legs, devices=[0], repeats=1, default_reference=True)
-    del Xs
+    only = os.environ.get("BENCH_E2E_LEGS", "dense,csr,1m").split(",")  # (debugging aid: a subset of the legs)
+    if "dense" in only:
+        Xd = synth_rows(torch, 0, dense_cells, G).cpu().numpy()
+        _e2e_run(f"dense fp32 {dense_cells} x 20000, window {window_dense}", Xd, window_dense, legs, devices=[0])
+        _e2e_run(f"dense fp32 {dense_cells} x 20000, window {window_dense}, reference=None (means on the GPU, in numpy's order)",
+                 Xd, window_dense, legs, devices=[0], repeats=1, default_reference=True)
+        del Xd
+    if "csr" in only:
+        ip, ix, dv = synth_csr_on_device(torch, csr_cells, G, 0.07, seed=3)
+        Xs = sp.csr_matrix((dv.cpu().numpy(), ix.cpu().numpy(), ip.cpu().numpy()), shape=(csr_cells, G))
+        del ip, ix, dv
+        torch.cuda.empty_cache()
+        _e2e_run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250 (BASELINE config 4)", Xs, 250, legs, devices=[0])
+        _e2e_run(f"CSR fp32 {csr_cells} x 20000 density 0.07, window 250, reference=None (means on the GPU, in scipy's order)",
+                 Xs, 250, legs, devices=[0], repeats=1, default_reference=True)
+        del Xs
     # north_star's own size from HOST memory (1 000 000 x 20 000 dense fp32 = 80 GB): only where the box has the RAM
     try:
         import psutil
@@ -356,7 +359,7 @@ def e2e_legs(torch, window_dense=100, dense_cells=200_000, csr_cells=500_000):
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 0
-    if avail >= 130e9:
+    if avail >= 130e9 and "1m" in only:
         import numpy as np
 
         n = CONFIG3_CELLS
@@ -511,6 +514,7 @@ def api_step(torch, _engine, ad, steps, warmup, fmt, window, step, nnz_row=G, tr
     t0 = time.perf_counter()
     for _ in range(steps):
         cnv.tl.infercnv(ad, window_size=window, step=step, **kw)
+    t_issued = time.perf_counter() - t0  # host time to ISSUE the steps (the calls are asynchronous); == dt: host bound
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     smooth_ms = [r.smooth_ms for r in _engine.profile_collect(plan)]
@@ -524,7 +528,7 @@ def api_step(torch, _engine, ad, steps, warmup, fmt, window, step, nnz_row=G, tr
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": pmc_traffic(traffic_key, n_local) if traffic_key else None,
         "bytes_per_cell": bytes_per_cell, "kernel_ms": avg, "kernel_ms_min_max": [min(smooth_ms), max(smooth_ms)],
-        "cells_per_launch": n_local,
+        "cells_per_launch": n_local, "host_issue_ms_per_step": t_issued / steps * 1e3,
     }
     return dt, roof, ad.obsm["X_cnv"].nnz()
 
@@ -640,6 +644,9 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
     def leg(name, fn):
         if which and name not in which:
             return
+        import gc
+
+        gc.collect()  # what the previous legs left for the cyclic collector is not this leg's time
         t0 = time.perf_counter()
         try:
             extra[name] = fn()

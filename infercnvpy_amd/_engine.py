@@ -1043,13 +1043,7 @@ class CsrDrain:
         lib = _lib.load()
         ring = None if os.environ.get("ICV_NO_PINNED_D2H") else _PinnedRing.get(torch)  # knob: A/B timing
         self._pending = []  # futures of chunks on their way into indices_h / data_h
-
-        def settle():
-            pending, self._pending = self._pending, []
-            for f in pending:
-                f.result()
-
-        self._settle = settle
+        settle = self._settle
 
         def reserve(extra, rows_after):
             need = self.nnz + extra
@@ -1147,6 +1141,14 @@ class CsrDrain:
 
         self._thread = threading.Thread(target=work, daemon=True)
         self._thread.start()
+
+    def _settle(self):
+        # (a method, not a closure kept in an attribute: that was a reference cycle, and the drain -- with the host arrays
+        # of X_cnv, 3.5 GB at 1 M cells -- stayed alive until the cyclic collector happened to run, inside someone's
+        # timed region: profiles/r06_gc_stall.txt)
+        pending, self._pending = self._pending, []
+        for f in pending:
+            f.result()
 
     def submit(self, part):
         torch = _torch()

@@ -89,3 +89,34 @@ def test_resident_calls_reuse_their_plan_and_do_not_synchronise():
     ad2 = SimpleAnnData(Xd, obs=obs, var=var2)
     cnv.tl.infercnv(ad2)
     _same_csr(ad2.obsm["X_cnv"].to_scipy(), first)
+
+
+def test_host_call_leaves_nothing_for_the_cyclic_collector():
+    """A finished call's helpers (CsrDrain, SlabStream, packers) are freed by reference counting: a reference cycle kept
+    the drain -- and with it the host arrays of X_cnv, gigabytes at scale -- alive until the cyclic collector ran, which
+    then stalled an unrelated later call by 0.15 s (profiles/r06_gc_stall.txt)."""
+    import gc
+
+    import torch
+
+    import infercnvpy_amd as cnv
+    from infercnvpy_amd._compat import SimpleAnnData
+
+    X, obs, var = _inputs(n=3000)
+    ref = X[:100].mean(axis=0)
+    for mat in (X, sp.csr_matrix(np.where(X > np.quantile(X, 0.8), X, 0)), torch.from_numpy(X).cuda()):
+        cnv.tl.infercnv(SimpleAnnData(mat, obs=obs, var=var))  # (first call: one-time objects)
+        gc.collect()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        try:
+            gc.garbage.clear()
+            ad = SimpleAnnData(mat, obs=obs, var=var)
+            cnv.tl.infercnv(ad, chunksize=500)
+            cnv.tl.infercnv(ad, reference=ref, chunksize=500, calculate_gene_values=True)
+            del ad
+            gc.collect()
+            ours = [type(o).__name__ for o in gc.garbage if (type(o).__module__ or "").startswith("infercnvpy_amd")]
+        finally:
+            gc.set_debug(0)
+            gc.garbage.clear()
+        assert not ours, ours
