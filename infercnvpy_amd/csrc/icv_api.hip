@@ -113,7 +113,7 @@ struct icv_plan_s {
     int32_t *d_cov_col = nullptr, *d_cov_j0 = nullptr, *d_cov_cnt = nullptr;
     uint32_t* d_gv_pk = nullptr;  // k_gene_fused: per run, first window | #windows << 16
     int32_t* d_gv_mult = nullptr;   //               genes per run
-    int16_t* d_gv_col16 = nullptr;  //               input column -> run or -1, padded to a multiple of 8 columns
+    uint16_t* d_gv_col16 = nullptr;  //              input column -> run, or R (the kernel's NaN slot) where the gene has no value; padded to a multiple of 8 columns
     bool gv_fused_ok = false;
     int gv_mult_bytes = 2;  // bytes per run length in the kernel's LDS (1 where every run has at most 255 genes)
     int64_t* d_row_list = nullptr;  // cells handed back by k_smooth_ws to the generic kernel
@@ -277,14 +277,14 @@ int ensure_device(icv_plan_t pl) {
     {
         // tables of k_gene_fused (16-bit fields: the fused kernel applies where they fit)
         const size_t R = p.gv_run_j0.size();
-        bool ok = p.W <= 65535 && R < 32768;
+        bool ok = p.W <= 65535 && R < 65535;
         std::vector<uint32_t> pk(R);
         for (size_t r = 0; r < R && ok; ++r) {
             ok = p.gv_run_cnt[r] <= 128 && p.gv_run_mult[r] <= 65535;  // (<= 128 windows per gene: gv_numpy_sum)
             pk[r] = (uint32_t)p.gv_run_j0[r] | ((uint32_t)p.gv_run_cnt[r] << 16);
         }
-        std::vector<int16_t> c16(((size_t)p.n_cols_all + 7) / 8 * 8, (int16_t)-1);
-        for (int c = 0; c < p.n_cols_all && ok; ++c) c16[c] = (int16_t)p.gv_col_run[c];
+        std::vector<uint16_t> c16(((size_t)p.n_cols_all + 7) / 8 * 8, (uint16_t)R);
+        for (int c = 0; c < p.n_cols_all && ok; ++c) c16[c] = p.gv_col_run[c] < 0 ? (uint16_t)R : (uint16_t)p.gv_col_run[c];
         pl->gv_fused_ok = ok;
         pl->gv_mult_bytes = 1;
         for (int32_t v : p.gv_run_mult)
@@ -1563,7 +1563,9 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
     const icv::Plan& p = pl->p;
     if (n < 1) return ICV_OK;
     const int W = p.W, n_cov = (int)p.cov_col.size(), R = (int)p.gv_run_j0.size();
-    const size_t lds = icv::gv_lds_bytes(W, R, pl->gv_mult_bytes);
+    // the run table in LDS too where two workgroups per CU still fit (87 VGPRs allow no more than two anyway)
+    const bool pk_lds = icv::gv_lds_bytes(W, R, pl->gv_mult_bytes, true) * 2 <= (size_t)icv::kLdsLimit;
+    const size_t lds = icv::gv_lds_bytes(W, R, pl->gv_mult_bytes, pk_lds);
     if (lds <= (size_t)icv::kLdsLimit && pl->gv_fused_ok && !knobs().no_gene_fused) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(icv::k_gene_fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1573,7 +1575,7 @@ int gene_from_windows(icv_plan_t pl, const double* win, int64_t ldw, int64_t n, 
         if (grid > n) grid = n;
         hipLaunchKernelGGL(icv::k_gene_fused, dim3((unsigned)grid), dim3(icv::kGvThreads), lds, st, win, ldw, n, W,
                            pl->d_gv_pk, pl->d_gv_mult, R, n_cov, pl->d_gv_col16, p.n_cols_all, thr,
-                           chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg, pl->gv_mult_bytes);
+                           chunksize > 0 ? chunksize : 1, row_phase, gene_out, ldg, pl->gv_mult_bytes, (int)pk_lds);
         HIP_TRY(hipGetLastError());
         return ICV_OK;
     }

@@ -25,7 +25,7 @@ namespace icv {
 
 constexpr int kGvThreads = 512;
 constexpr int kGvWaves = kGvThreads / 64;
-constexpr int kGvBins = 4 * kGvThreads;  // every thread scans four bins (256 threads x 3 workgroups per CU measured slower: 9.7 against 7.5 ms)
+constexpr int kGvBins = 4 * kGvThreads;  // every thread scans four bins (256 / 384 threads x 3 workgroups per CU measured slower: 9.7 / 8.5 against 7.3 ms per call)
 constexpr int kGvCand = 64;
 
 struct GvScratch {
@@ -39,14 +39,17 @@ struct GvScratch {
     int found2, pad_;
 };
 
-// (the tables need W <= 65 535 windows, run lengths and window counts that fit 16 bits, fewer than 32 768 runs)
-// dynamic LDS: win[W] (float64; dead after the run values: the scratch aliases it) | val[R] | mult[R] (16-bit)
+// (the tables need W <= 65 535 windows, run lengths and window counts that fit 16 bits, fewer than 65 535 runs)
+// dynamic LDS: win[W] (float64; dead after the run values: the scratch aliases it) | val[R + 2] (val[R] = NaN: the slot of
+// the columns without a value) | mult[R] (8 / 16-bit) | the run table (32-bit) where it fits
 // (run lengths as bytes where no run is longer than 255 genes: 4 KB less at 4 000 runs -- three workgroups per CU instead of two)
-__host__ __device__ inline size_t gv_lds_bytes(int W, int R, int mult_bytes = 2) {
+// pk_lds: the run table {first window | count << 16} in LDS as well (4 R bytes): no load from memory between a cell's
+// stores and the next cell's run values (see the kernel)
+__host__ __device__ inline size_t gv_lds_bytes(int W, int R, int mult_bytes = 2, bool pk_lds = false) {
     size_t w = (size_t)W * 8;
     if (w < sizeof(GvScratch)) w = sizeof(GvScratch);
     w = (w + 15) / 16 * 16;
-    return w + (size_t)R * 8 + ((size_t)R * mult_bytes + 15) / 16 * 16;
+    return w + ((size_t)R + 2) * 8 + ((size_t)R * mult_bytes + 15) / 16 * 16 + (pk_lds ? (size_t)R * 4 : 0);
 }
 
 // numpy's float64 add.reduce of a[0..n) in LDS for n <= 128 (the launcher sends plans with longer runs -- a gene covered
@@ -78,9 +81,9 @@ __device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
 // 8 columns with -1).  Global loads are issued in batches before the dependent LDS work.
 __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     const double* __restrict__ win, int64_t ldw, int64_t n_rows, int W, const uint32_t* __restrict__ run_pk,
-    const int32_t* __restrict__ run_mult, int R, int n_cov, const int16_t* __restrict__ col_run16, int n_cols,
+    const int32_t* __restrict__ run_mult, int R, int n_cov, const uint16_t* __restrict__ col_run16, int n_cols,
     const double* __restrict__ thr, int64_t chunksize, int64_t row_phase, double* __restrict__ out, int64_t ldg,
-    int mult_bytes) {
+    int mult_bytes, int pk_lds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     size_t woff = (size_t)W * 8;
     if (woff < sizeof(GvScratch)) woff = sizeof(GvScratch);
@@ -88,8 +91,10 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     double* lwin = reinterpret_cast<double*>(gsm);
     GvScratch* sc = reinterpret_cast<GvScratch*>(gsm);  // aliases the windows (used after they are dead)
     double* val = reinterpret_cast<double*>(gsm + woff);
-    unsigned short* mult16 = reinterpret_cast<unsigned short*>(gsm + woff + (size_t)R * 8);
+    const size_t vbytes = ((size_t)R + 2) * 8;
+    unsigned short* mult16 = reinterpret_cast<unsigned short*>(gsm + woff + vbytes);
     unsigned char* mult8 = reinterpret_cast<unsigned char*>(mult16);
+    uint32_t* lpk = reinterpret_cast<uint32_t*>(gsm + woff + vbytes + ((size_t)R * mult_bytes + 15) / 16 * 16);
     const bool m8 = mult_bytes == 1;
     const auto mult_of = [&](int r) { return m8 ? (int)mult8[r] : (int)mult16[r]; };
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -97,22 +102,42 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     for (int i = t; i < R; i += kGvThreads) {
         if (m8) mult8[i] = (unsigned char)run_mult[i];
         else mult16[i] = (unsigned short)run_mult[i];
+        if (pk_lds) lpk[i] = run_pk[i];
     }
+    if (t == 0) val[R] = __builtin_nan("");  // what a column without a run reads (the table says R there)
     const bool vec2 = (ldg % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     const bool win16 = (ldw % 2 == 0) && ((reinterpret_cast<uintptr_t>(win) & 15) == 0);
     const double nan = __builtin_nan("");
     constexpr int UW = 4;  // window loads (16 bytes) in flight per thread
     constexpr int UR = 4;  // run-table loads in flight per thread
-    constexpr int UC = 8;  // column-table loads (2 columns each) in flight per thread
-    // (keeping the thread's 20 table words in registers for all cells of the workgroup made the compiler take 252 VGPRs)
+    constexpr int UC = 20;  // column-table loads (2 columns each) in flight per thread: a 20 480-column row in ONE batch
+    constexpr int PW = 2;  // 16-byte window loads per thread prefetched a cell ahead (W <= 2 048: all of them)
+    // gfx9 counts a wavefront's loads AND stores in one in-order counter: a load issued after the row's stores is only
+    // there when the stores are acknowledged -- the cell's 160 KB drain before the next cell can even start.  So nothing
+    // is loaded after a store: the NEXT cell's windows and all of the thread's column-table words are fetched before the
+    // first store of the output phase, the stores go out back to back, and they drain while the next cell's run values
+    // and median are formed from LDS.  (The table words live in registers for the output phase only; kept across cells
+    // the compiler took 252 VGPRs.)
+    typedef double f64x2_t __attribute__((ext_vector_type(2)));
+    f64x2_t pre[PW];
+    const int n2w = W / 2;
+    const auto prefetch = [&](int64_t cell_) {
+        const double* wr_ = win + cell_ * ldw;
+#pragma unroll
+        for (int u = 0; u < PW; ++u)
+            if (t + u * kGvThreads < n2w) pre[u] = *reinterpret_cast<const f64x2_t*>(wr_ + 2 * (t + u * kGvThreads));
+    };
+    if (win16 && (int64_t)blockIdx.x < n_rows) prefetch(blockIdx.x);
     for (int64_t cell = blockIdx.x; cell < n_rows; cell += gridDim.x) {
         __syncthreads();  // the previous cell's output phase has read val[]; its scratch use is over
         // ---- 1. the cell's windows
         const double* wr = win + cell * ldw;
         if (win16) {
-            typedef double f64x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < PW; ++u)
+                if (t + u * kGvThreads < n2w) *reinterpret_cast<f64x2_t*>(lwin + 2 * (t + u * kGvThreads)) = pre[u];
             const int n2 = W / 2;
-            for (int j0 = t; j0 < n2; j0 += UW * kGvThreads) {
+            for (int j0 = t + PW * kGvThreads; j0 < n2; j0 += UW * kGvThreads) {
                 f64x2_t q[UW];
 #pragma unroll
                 for (int u = 0; u < UW; ++u)
@@ -132,7 +157,8 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
         for (int r0 = t; r0 < R; r0 += UR * kGvThreads) {
             uint32_t pk[UR];
 #pragma unroll
-            for (int u = 0; u < UR; ++u) pk[u] = r0 + u * kGvThreads < R ? run_pk[r0 + u * kGvThreads] : 0u;
+            for (int u = 0; u < UR; ++u)
+                pk[u] = r0 + u * kGvThreads < R ? (pk_lds ? lpk[r0 + u * kGvThreads] : run_pk[r0 + u * kGvThreads]) : 0u;
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const int r = r0 + u * kGvThreads;
@@ -169,7 +195,11 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
         const bool anynan = sc->anynan != 0;
         // ---- 3. weighted median: rank k1 (and k2 = k1 + 1 for an even count) of the multiset {val[r] x mult[r]}
         double v1 = lo, v2 = lo;
+#if defined(ICV_DEV_EXPERIMENTS) && defined(GV_EXP_NOMEDIAN)
+        if (false) {
+#else
         if (!anynan && R > 0) {
+#endif
             int below = 0;  // weight strictly below the current [lo, hi]
             bool need2 = k2 != k1;
             for (int level = 0; level < 64; ++level) {
@@ -307,40 +337,52 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
             }
         }
         const double med = anynan ? nan : ((k1 == k2) ? v1 : (v1 + v2) / 2.0);
-        // ---- 4. the output row, input-column order: value - median, noise filter, NaN where there is no value
+        // ---- 4. the output row, input-column order: value - median, noise filter, NaN where there is no value.
+        // The arithmetic is done once per RUN, in place (4 000 runs, not 20 000 columns: the per-column form spent 40 % of
+        // the kernel's VALU instructions here); a column then is one LDS read at its table index (val[R] = NaN).
         const bool has_thr = thr != nullptr;
         const double th = has_thr ? thr[(cell + row_phase) / chunksize] : 0.0;
         double* orow = out + cell * ldg;
-        const auto value_of = [&](int rx) {
-            double a = rx >= 0 ? val[rx] - med : nan;
+        for (int r = t; r < R; r += kGvThreads) {
+            double a = val[r] - med;
             if (has_thr && fabs(a) < th) a = 0.0;
-            return a;
-        };
+            val[r] = a;
+        }
+        __syncthreads();
+        const auto value_of = [&](unsigned rx) { return val[rx]; };
         if (vec2) {
             // a lane = two adjacent columns, the lanes of a wavefront = 1 KB of the row: every store instruction writes
             // whole lines (eight columns per lane -- 64-byte runs, lane stride 64 B -- measured 2.4 x slower: partial lines)
-            typedef double f64x2_t __attribute__((ext_vector_type(2)));
             const int n2 = (n_cols + 1) / 2;  // pairs (the table is padded with -1)
             const uint32_t* cr2 = reinterpret_cast<const uint32_t*>(col_run16);
             for (int g0 = t; g0 < n2; g0 += UC * kGvThreads) {
                 uint32_t rr[UC];
 #pragma unroll
-                for (int u = 0; u < UC; ++u) rr[u] = g0 + u * kGvThreads < n2 ? cr2[g0 + u * kGvThreads] : 0xffffffffu;
+                for (int u = 0; u < UC; ++u) rr[u] = g0 + u * kGvThreads < n2 ? cr2[g0 + u * kGvThreads] : 0u;
+                // (the last loads before this cell's stores: the next cell's windows)
+                if (g0 + UC * kGvThreads >= n2 && win16 && cell + gridDim.x < n_rows) prefetch(cell + gridDim.x);
 #pragma unroll
                 for (int u = 0; u < UC; ++u) {
                     const int c = 2 * (g0 + u * kGvThreads);
                     if (c >= n_cols) continue;
-                    const double a = value_of((int)(short)(rr[u] & 0xffffu)), b = value_of((int)(short)(rr[u] >> 16));
+                    const double a = value_of(rr[u] & 0xffffu), b = value_of(rr[u] >> 16);
                     if (c + 2 <= n_cols) {
                         const f64x2_t q = {a, b};
+#if defined(ICV_DEV_EXPERIMENTS) && defined(GV_EXP_PLAIN)
+                        *reinterpret_cast<f64x2_t*>(orow + c) = q;
+#elif defined(ICV_DEV_EXPERIMENTS) && defined(GV_EXP_NOSTORE)
+                        if (a == 1.2345e300) *reinterpret_cast<f64x2_t*>(orow + c) = q;
+#else
                         __builtin_nontemporal_store(q, reinterpret_cast<f64x2_t*>(orow + c));
+#endif
                     } else {
                         orow[c] = a;
                     }
                 }
             }
         } else {
-            for (int c = t; c < n_cols; c += kGvThreads) orow[c] = value_of((int)col_run16[c]);
+            if (win16 && cell + gridDim.x < n_rows) prefetch(cell + gridDim.x);
+            for (int c = t; c < n_cols; c += kGvThreads) orow[c] = value_of((unsigned)col_run16[c]);
         }
     }
 }
