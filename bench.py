@@ -707,12 +707,14 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         plan = T._cached_plan(var["chromosome"].to_numpy(), var["start"].to_numpy(), 100, 10, ("chrX", "chrY"),
                               torch.cuda.current_device())
         W = plan.n_windows
-        ms_plain = timed(lambda: cnv.tl.infercnv(ad), 5, 2)
+        # (enough steps that the ~0.7 ms of host work in front of the FIRST call's first kernel -- the GPU is idle then -- is
+        # not a tenth of the figure: the calls are asynchronous, in steady state the host runs ahead)
+        ms_plain = timed(lambda: cnv.tl.infercnv(ad), 30, 2)
         def gv_call():
             ad.layers.clear()  # (the previous call's 16 GB layer goes back to the allocator first: one buffer, reused --
             cnv.tl.infercnv(ad, calculate_gene_values=True)  # a fresh 16 GB hipMalloc costs ~0.4 s on an untouched box)
 
-        ms_gv = timed(gv_call, 3, 2)
+        ms_gv = timed(gv_call, 15, 2)
         gv = ad.layers["gene_values_cnv"]
         n_nan = int(torch.isnan(gv[:64]).sum().item())
         del gv
@@ -733,13 +735,13 @@ def extra_legs(torch, icd, _engine, GenePlan, cases, which):
         # the same flag on 10x-style CSR input (k_smooth_se also stores its windows): 100 000 cells, density 0.07, window 100
         ip, ix, dv = synth_csr_on_device(torch, cells, G, 0.07, seed=3)
         adc = SimpleAnnData(_engine.DeviceMatrix(indptr=ip, indices=ix, data=dv, shape=(cells, G)), var=var)
-        ms_plain_c = timed(lambda: cnv.tl.infercnv(adc), 5, 2)
+        ms_plain_c = timed(lambda: cnv.tl.infercnv(adc), 30, 2)
 
         def gv_call_csr():
             adc.layers.clear()
             cnv.tl.infercnv(adc, calculate_gene_values=True)
 
-        ms_gv_c = timed(gv_call_csr, 3, 2)
+        ms_gv_c = timed(gv_call_csr, 15, 2)
         nnz_row = dv.numel() / cells
         out["gene_values_csr_w100"] = {
             "ms_per_call": ms_gv_c, "plain_call_ms": ms_plain_c, "ratio_to_plain_call": ms_gv_c / ms_plain_c,
@@ -1048,10 +1050,19 @@ def main():
         # `value`: the reference's bits.  Dense float32 shards: the chain by integer blocks (the ranks' passes run
         # concurrently); CSR shards: the chained accumulators (the only exact form there)
         first = "blocks" if args.format == "dense" else "chained"
-        dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step, args.chunksize,
-                            args.steps, args.warmup, means=first, **common)
+        # (the block form has run under process groups on ONE GPU only: if it fails on every rank of a real multi-GPU job
+        # the line still carries the two older forms, and says so)
+        first_error = None
+        try:
+            dt, roof = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
+                                args.chunksize, args.steps, args.warmup, means=first, **common)
+        except Exception as e:  # pragma: no cover
+            first_error = repr(e)[:300]
+            torch.cuda.synchronize()
         dt_ch, roof_ch = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
                                   args.chunksize, args.steps, args.warmup, means="chained", **common)
+        if first_error is not None:
+            dt, roof = dt_ch, roof_ch
         dt_ar, roof_ar = hbm_step(torch, icd, _engine, plan, dm, n_local, args.format, args.window, args.step,
                                   args.chunksize, args.steps, args.warmup, means="allreduce", **common)
     if dist is not None:
@@ -1151,6 +1162,8 @@ def main():
                                      "threshold may differ from the reference (tl.infercnv(mean_order='float64'))",
             "smooth_kernel_ms_allreduce_run": roof_ar["kernel_ms"],
         }
+        if first_error is not None:
+            result["forms"]["value"] = "THE BLOCK FORM FAILED (" + first_error + "): value = value_chained_means"
     if stages is not None:
         result["stages"] = stages
     if dry:

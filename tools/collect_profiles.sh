@@ -20,6 +20,8 @@ cp $O/csr_density_lines.txt $P/${ROUND}_csr_density_lines.txt
 cp $O/csr_means_density.txt $P/${ROUND}_csr_means_density.txt
 cp $O/chain_blocks_times.txt $P/${ROUND}_chain_blocks_times.txt
 cp $O/hbm_write.txt $P/${ROUND}_hbm_write.txt
+[ -f $O/gene_kernel.txt ] && cp $O/gene_kernel.txt $P/${ROUND}_gene_kernel.txt
+[ -f $O/host_issue_after_e2e.txt ] && cp $O/host_issue_after_e2e.txt $P/${ROUND}_host_issue_after_e2e.txt
 cp $O/bench_1m_leg.json $P/${ROUND}_bench_1m_leg.json
 python - $O/clocks_1m_leg.txt > $P/${ROUND}_clocks_1m_leg.txt <<'PY'
 import re, sys

@@ -57,6 +57,8 @@ pmc_hbm gene_values_100000_cells --steps 2 --warmup 1 --no-cpu-baseline --no-e2e
 timeout 400 python tools/time_csr_means.py 2>/dev/null | tee $O/csr_means_density.txt
 timeout 300 python tools/time_chain_blocks.py 2>/dev/null | tee $O/chain_blocks_times.txt
 timeout 120 python tools/time_hbm_write.py 2>/dev/null | tee $O/hbm_write.txt
+timeout 200 python tools/time_gene_kernel.py 2>/dev/null | tail -1 | tee $O/gene_kernel.txt
+BENCH_E2E_LEGS=1m timeout 400 python tools/host_issue_after_e2e.py 2>/dev/null | grep -v "amdgpu.ids" | tail -12 > $O/host_issue_after_e2e.txt; tail -8 $O/host_issue_after_e2e.txt | cut -c1-200
 ( while true; do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power \(W\)|Average Graphics" | tr -s " " | tr "\n" ";"; echo; sleep 0.25; done > $O/clocks_1m_leg.txt ) &
 CLK=$!
 timeout 600 python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-e2e --extra config3_cells_on_one_gpu > $O/bench_1m_leg.json 2> $O/bench_1m_leg.err
