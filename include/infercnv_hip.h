@@ -132,6 +132,14 @@ int icv_plan_last_kernel(icv_plan_t plan, int32_t *h_kind);
 int icv_plan_se_tables(icv_plan_t plan, int32_t *h_applies, int32_t *h_col_block /* n_cols_all */,
                        int32_t *h_col_offset /* n_cols_all */, int32_t *h_block_gene0 /* n_blocks */,
                        uint32_t *h_w0 /* W */, uint32_t *h_w1 /* W */);
+/* Host tables of calculate_gene_values (reference tl/_infercnv.py:247-298: a gene's value is the mean of the kept windows
+ * that contain it), for tests that check them on the CPU against the oracle: the covered genes in chromosome / position
+ * order fall into RUNS that share their windows; run r averages the windows [first, first + count) (global window
+ * indices) and holds `genes` genes; h_col_run[c] = the run of input column c, -1 where the gene has no value (masked
+ * chromosome, or no kept window contains it: NaN in the layer, :147).  *h_n_runs is always written; the arrays (each may
+ * be NULL) hold *h_n_runs / n_cols_all entries: call once with NULL arrays for the size. */
+int icv_plan_gene_runs(icv_plan_t plan, int32_t *h_n_runs, int32_t *h_run_first, int32_t *h_run_count,
+                       int32_t *h_run_genes, int32_t *h_col_run /* n_cols_all */);
 
 /* ---- reference profile (reference :385, :400) --------------------------------------------
  * Per-group column sums in float64.  h/d: `row_group` (device, n_rows int32; -1 = row not in

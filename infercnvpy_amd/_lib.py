@@ -26,7 +26,7 @@ ICV_FLAG_NO_APPLY = 4
 # every symbol include/infercnv_hip.h declares
 EXPORTS = (
     "icv_plan_create", "icv_plan_destroy", "icv_plan_get_info", "icv_plan_chr_pos", "icv_plan_window_table",
-    "icv_plan_last_kernel", "icv_plan_se_tables",
+    "icv_plan_last_kernel", "icv_plan_se_tables", "icv_plan_gene_runs",
     "icv_colsum", "icv_colchain", "icv_colsum_pairwise", "icv_colchain_mean", "icv_colmean_csc", "icv_infercnv_smooth", "icv_chunk_thresholds", "icv_apply_threshold", "icv_infercnv_run",
     "icv_infercnv_run_windows", "icv_gene_values_from_windows",
     "icv_colchain_blocks_workspace", "icv_colchain_blocks_sums", "icv_colchain_blocks_records", "icv_colchain_blocks_scan",
@@ -98,6 +98,7 @@ def load():
     lib.icv_plan_window_table.argtypes = [vp, vp, vp]
     lib.icv_plan_last_kernel.argtypes = [vp, P(i32)]
     lib.icv_plan_se_tables.argtypes = [vp, P(i32), vp, vp, vp, vp, vp]
+    lib.icv_plan_gene_runs.argtypes = [vp, P(i32), vp, vp, vp, vp]
     lib.icv_colsum.argtypes = [P(Matrix), vp, i32, vp, vp]
     lib.icv_colchain.argtypes = [P(Matrix), vp, i64, dbl, vp, vp]
     lib.icv_colsum_pairwise.argtypes = [vp, i32, i64, i32, i64, vp, vp]

@@ -147,6 +147,19 @@ class GenePlan:
                                           w0.ctypes.data, w1.ctypes.data))
         return dict(col_block=cb, col_offset=co, block_gene0=g0, w0=w0, w1=w1)
 
+    def gene_runs(self):
+        """Host tables of ``calculate_gene_values`` (``icv_plan_gene_runs``): dict(first, count, genes, col_run) -- run r
+        averages the windows ``[first[r], first[r] + count[r])`` for ``genes[r]`` genes; ``col_run[c]`` is the run of
+        input column c (-1: the gene has no value)."""
+        lib = _lib.load()
+        n = C.c_int32(0)
+        _lib.check(lib.icv_plan_gene_runs(self._handle, C.byref(n), None, None, None, None))
+        first, count, genes = (np.zeros(n.value, dtype=np.int32) for _ in range(3))
+        col_run = np.zeros(self.n_cols_all, dtype=np.int32)
+        _lib.check(lib.icv_plan_gene_runs(self._handle, C.byref(n), first.ctypes.data, count.ctypes.data,
+                                          genes.ctypes.data, col_run.ctypes.data))
+        return dict(first=first, count=count, genes=genes, col_run=col_run)
+
     def last_kernel(self) -> int:
         """``_lib.ICV_KERNEL_*`` of the smoothing kernel the last compute call on this plan launched."""
         kind = C.c_int32(0)

@@ -1171,6 +1171,19 @@ int icv_plan_se_tables(icv_plan_t pl, int32_t* h_applies, int32_t* h_col_block, 
     return ICV_OK;
 }
 
+int icv_plan_gene_runs(icv_plan_t pl, int32_t* h_n_runs, int32_t* h_run_first, int32_t* h_run_count,
+                       int32_t* h_run_genes, int32_t* h_col_run) {
+    if (!pl || !h_n_runs) return fail(ICV_ERR_INVALID, "null argument");
+    const icv::Plan& p = pl->p;
+    const size_t R = p.gv_run_j0.size();
+    *h_n_runs = (int32_t)R;
+    if (h_run_first) std::memcpy(h_run_first, p.gv_run_j0.data(), R * sizeof(int32_t));
+    if (h_run_count) std::memcpy(h_run_count, p.gv_run_cnt.data(), R * sizeof(int32_t));
+    if (h_run_genes) std::memcpy(h_run_genes, p.gv_run_mult.data(), R * sizeof(int32_t));
+    if (h_col_run) std::memcpy(h_col_run, p.gv_col_run.data(), (size_t)p.n_cols_all * sizeof(int32_t));
+    return ICV_OK;
+}
+
 int icv_colsum(const icv_matrix* m, const int32_t* row_group, int32_t n_groups, double* sums, void* stream) {
     if (!m || !sums || n_groups < 1) return fail(ICV_ERR_INVALID, "bad colsum arguments");
     if (m->n_rows == 0) return ICV_OK;

@@ -226,3 +226,46 @@ def test_product_package_never_imports_the_oracle():
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").split(".")[0] == "oracle" for n in ast.walk(fn))
         assert not uses or fn.name in ("cpu_baseline", "_cpu_worker", "_cpu_chunk_worker"), fn.name
     assert not any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in tree.body)
+
+
+@pytest.mark.parametrize("genes,window,step", [
+    ([57, 23, 9], 10, 3), ([120, 40], 25, 5), ([64, 64, 5], 8, 4), ([33], 11, 1), ([200, 90, 12], 100, 10),
+    ([75, 31], 6, 7),  # step > window: genes between two windows have no value
+])
+def test_gene_run_tables_are_the_oracles_window_coverage(genes, window, step):
+    """``calculate_gene_values`` on the CPU side: the plan's runs (``icv_plan_gene_runs``: which windows a gene's value
+    averages) against the oracle's restatement of ``_calculate_gene_averages`` (reference tl/_infercnv.py:247-298) --
+    a one-hot window row through ``gene_values_from_windows`` shows exactly which genes window j reaches, and with
+    which 1 / count."""
+    v = cases.synthetic_var(genes, extra=(("chrX", 7), (None, 3)))
+    chrom, start = v["chromosome"], v["start"]
+    plan = GenePlan(chrom, start, window_size=window, step=step)
+    runs = plan.gene_runs()
+    n_cols = len(chrom)
+    assert runs["col_run"].shape == (n_cols,) and runs["genes"].sum() == (runs["col_run"] >= 0).sum()
+    assert (np.bincount(runs["col_run"][runs["col_run"] >= 0], minlength=len(runs["genes"])) == runs["genes"]).all()
+    keep = ~plan.var_mask
+    ch, st = chrom[keep], start[keep]
+    kept_idx = np.flatnonzero(keep)
+    covered = np.zeros(n_cols, dtype=bool)
+    for c in O.used_chromosomes(ch):
+        cols = kept_idx[O.chromosome_gene_order(ch, st, c)]  # input columns of the chromosome, position order
+        g = len(cols)
+        w0 = int(plan.chr_pos[c])
+        n_w = O.smooth_segment(np.zeros((1, g)), window, step).shape[1]
+        cover = O.gene_values_from_windows(np.eye(n_w), g, window, step)  # [window j, gene p] = 1 / count or 0 / NaN
+        for p, col in enumerate(cols):
+            js = np.flatnonzero(np.nan_to_num(cover[:, p]) > 0)
+            r = runs["col_run"][col]
+            if js.size == 0:
+                assert r == -1 and np.isnan(cover[:, p]).all()
+                continue
+            covered[col] = True
+            assert r >= 0
+            assert runs["first"][r] == w0 + js[0] and runs["count"][r] == js.size
+            assert (np.diff(js) == 1).all() and np.allclose(cover[js, p], 1.0 / js.size)
+    assert ((runs["col_run"] >= 0) == covered).all()  # masked chromosomes / null positions: no value
+    # runs are maximal: neighbours differ
+    same = (runs["first"][1:] == runs["first"][:-1]) & (runs["count"][1:] == runs["count"][:-1])
+    assert not same.any()
+    plan.close()
