@@ -326,18 +326,40 @@ __global__ void __launch_bounds__(256) k_key_hist(const float* __restrict__ v, i
     __syncthreads();
     const unsigned dmask = (1u << nbits) - 1u;
     const unsigned pq[4] = {p0, p1, p2, p3};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
-        const float x = v[i];
+    const auto one = [&](float x) {
         if (x != x) {
             atomicAdd(&lh[4 * 2048], 1u);
-            continue;
+            return;
         }
         const unsigned k = ordered_key32(x);
         const unsigned d = (k >> shift) & dmask;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (q < nq && ((k ^ pq[q]) & himask) == 0u) atomicAdd(&lh[q * 2048 + d], 1u);
+    };
+    // 16-byte loads, four of them in flight per thread (one 4-byte load per thread and trip left a CU with 4 KB in
+    // flight: 1.46 ms per pass over the 2.5 GB of a 25 000-cell group = 1.7 TB/s)
+    const bool vec = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+    const int64_t m4 = vec ? m / 4 : 0;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t* v4 = reinterpret_cast<const f32x4_t*>(v);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    constexpr int U = 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m4; i += U * stride) {
+        f32x4_t x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < m4) x[u] = __builtin_nontemporal_load(v4 + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u * stride < m4) {
+                one(x[u].x);
+                one(x[u].y);
+                one(x[u].z);
+                one(x[u].w);
+            }
     }
+    for (int64_t i = 4 * m4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) one(v[i]);
     __syncthreads();
     for (int i = threadIdx.x; i < nq * 2048; i += 256)
         if (lh[i]) atomicAdd(hist + i, (unsigned long long)lh[i]);
