@@ -45,8 +45,12 @@ def cnv_score(adata, groupby: str = "cnv_leiden", *, use_rep: str = "cnv", key_a
     import pandas as pd
 
     labels = adata.obs[groupby]
-    codes, uniques = pd.factorize(np.asarray(labels.values if hasattr(labels, "values") else labels),
-                                  use_na_sentinel=True)
+    if isinstance(getattr(labels, "dtype", None), pd.CategoricalDtype):
+        # what tl.leiden leaves: the codes are there already (-1: missing); unused categories are groups without rows
+        codes, uniques = labels.cat.codes.to_numpy(), labels.cat.categories
+    else:
+        codes, uniques = pd.factorize(np.asarray(labels.values if hasattr(labels, "values") else labels),
+                                      use_na_sentinel=True)
     codes = codes.astype(np.int32, copy=False)
     n_groups = len(uniques)
     sums, _ = _engine.group_sums(row_abs, codes, n_groups, want_counts=False)

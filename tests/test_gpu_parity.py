@@ -423,6 +423,17 @@ def test_cnv_score_known_answer_and_oracle():
     exp = O.cnv_score(big.astype(np.float64), labels)
     for k in exp:
         assert got[k] == pytest.approx(exp[k], rel=1e-12)
+    # a categorical groupby (what tl.leiden writes; an unused category, a missing label): the same numbers from its codes
+    lab_c = pd.Series(labels).astype(pd.CategoricalDtype(["unused", "z", "y", "x"]))
+    lab_c.iloc[7] = np.nan
+    ad_c = SimpleAnnData(np.zeros((5000, 2)), obs=pd.DataFrame({"g": lab_c}), obsm={"X_cnv": sp.csr_matrix(big)})
+    ad_s = SimpleAnnData(np.zeros((5000, 2)), obs=pd.DataFrame({"g": lab_c.astype(object)}), obsm={"X_cnv": sp.csr_matrix(big)})
+    got_c, got_s = cnv.tl.cnv_score(ad_c, "g", inplace=False), cnv.tl.cnv_score(ad_s, "g", inplace=False)
+    assert {k: v for k, v in got_c.items() if k == k} == {k: v for k, v in got_s.items() if k == k} and "unused" not in got_c
+    cnv.tl.cnv_score(ad_c, "g")
+    cnv.tl.cnv_score(ad_s, "g")
+    np.testing.assert_array_equal(ad_c.obs["cnv_score"].values, ad_s.obs["cnv_score"].values)
+    assert np.isnan(ad_c.obs["cnv_score"].values[7])
     with pytest.raises(ValueError):
         cnv.tl.cnv_score(ad)
     with pytest.warns(FutureWarning):
