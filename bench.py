@@ -18,11 +18,13 @@ One "step" = one pass of the whole hot path over one batch of synthetic cells th
           -> X_cnv as device CSR float64.
           The calls are issued back to back without host synchronisation (the function does not wait for the GPU).
   N > 1   one process per GPU over the rows of config 3 (dist.run_shard per rank).  THREE forms of the reference means
-          are timed back to back, K steps each: `value` = the reference's own evaluation order with the ranks' passes
-          CONCURRENT -- the float32 chain by integer blocks (dist.reference_means_blocks: float64 totals, ONE all-gather of
-          [G] float64, block records on every rank at once, a scan over the records from rank to rank, means broadcast:
-          X_cnv bit-identical to the N = 1 public call for any N); `value_chained_means` = the same bits with the
-          icv_colchain accumulators handed from rank to rank (dist.reference_means_chained: the ranks take turns);
+          are timed back to back, K steps each.  Two give the reference's own bits (X_cnv bit-identical to the N = 1
+          public call for any N): `value_blocks_means` -- the ranks' passes CONCURRENT, the float32 chain by integer
+          blocks (dist.reference_means_blocks: float64 totals, ONE all-gather of [G] float64, block records on every rank
+          at once, a scan over the records from rank to rank, means broadcast) -- and `value_chained_means` -- the
+          icv_colchain accumulators handed from rank to rank (dist.reference_means_chained: the ranks take turns, pipelined
+          over two column groups).  `value` = the FASTER of those two at this N (the blocks pay two passes over a rank's
+          rows and win from ~4 ranks on; dist.reference_means_exact chooses alike);
           `value_allreduce_means` = float64 column sums + ONE RCCL all-reduce of [G + 1] float64 (concurrent, correctly
           rounded means -- not the reference's bits: tl.infercnv(mean_order="float64")).  All -> the same smoothing kernel ->
           per-chunk std -> noise threshold + CSR pack (dist.run_shard(pack=True)).
@@ -1086,6 +1088,18 @@ def main():
             dist.barrier()
 
 
+    # N > 1, dense shards: two exact forms of the means were timed (same bits): `value` is the faster one at this rank
+    # count -- the blocks pay two concurrent passes + a scan (~2.2 passes of a rank's rows), the chained accumulators
+    # (T + R - 1) / T passes with T = 2: 1.5 at R = 2, 2.5 at R = 4, 4.5 at R = 8 (dist.reference_means_exact picks alike)
+    value_form, dt_blocks = None, None
+    if stages is None and dist is not None and args.format == "dense" and not args.engine_step:
+        if first_error is None:
+            dt_blocks = dt
+            value_form = "blocks"
+            if dt_ch < dt:
+                dt, roof, value_form = dt_ch, roof_ch, "chained"
+        else:
+            value_form = "chained"
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps)
 
@@ -1100,8 +1114,8 @@ def main():
     result = {
         "metric": (f"cells/sec through tl.infercnv (window={args.window}), input resident in HBM" if not rank_path else
                    f"cells/sec through the tl.infercnv hot path (window={args.window}) as dist.run_shard on every rank "
-                   f"(reference-order means: the float32 chain by integer blocks, concurrent over the ranks), input "
-                   f"resident in HBM"),
+                   f"(reference-order means: the faster of the chain by integer blocks and the chained accumulators, "
+                   f"see forms), input resident in HBM"),
         "value": value,
         "unit": "cells/s",
         "n_gpus": n_gpus,
@@ -1153,13 +1167,22 @@ def main():
         result["ms_per_step_allreduce_means"] = dt_ar / args.steps * 1e3
         result["value_chained_means"] = n_total / (dt_ch / args.steps)
         result["ms_per_step_chained_means"] = dt_ch / args.steps * 1e3
+        if dt_blocks is not None:
+            result["value_blocks_means"] = n_total / (dt_blocks / args.steps)
+            result["ms_per_step_blocks_means"] = dt_blocks / args.steps * 1e3
         result["forms"] = {
-            "value": ("reference means in the reference's own evaluation order WITHOUT the ranks taking turns: the float32 "
-                      "chain by integer blocks (dist.reference_means_blocks: every rank adds float64 totals and forms "
-                      "its block records concurrently, one all-gather, a scan over the records travels rank to rank): "
-                      "X_cnv bit-identical to the one-GPU public call for any number of ranks"
+            "value": ("reference means in the reference's own evaluation order, X_cnv bit-identical to the one-GPU public "
+                      "call for any number of ranks; the FASTER of the two exact forms at this rank count (both timed: "
+                      "value_blocks_means, value_chained_means) = " +
+                      ("value_blocks_means: the float32 chain by integer blocks WITHOUT the ranks taking turns "
+                       "(dist.reference_means_blocks: every rank adds float64 totals and forms its block records "
+                       "concurrently, one all-gather, a scan over the records travels rank to rank)"
+                       if value_form == "blocks" else
+                       "value_chained_means (the chain by integer blocks -- value_blocks_means -- pays two passes over a "
+                       "rank's rows and wins from ~4 ranks on)")
                       if args.format == "dense" else
                       "CSR shards: the chained accumulators (value = value_chained_means)"),
+            "value_blocks_means": "the float32 chain by integer blocks (dist.reference_means_blocks), dense shards",
             "value_chained_means": "the same bits with the icv_colchain accumulators handed from rank to rank, pipelined "
                                    "over 2 column groups (dist.reference_means_chained; rounds 4-5: the ranks take turns)",
             "value_allreduce_means": "float64 column sums + one all-reduce (dist.reference_means): correctly rounded "

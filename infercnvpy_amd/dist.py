@@ -265,6 +265,24 @@ def reference_means_blocks(dm_local, n_total, group=None, n_col_groups=4, stats=
     return means
 
 
+def reference_means_exact(dm_local, n_total, group=None, stats=None):
+    """The all-cell reference profile in the reference's own evaluation order (numpy's / scipy's bits) over a row-sharded
+    matrix, by whichever exact form is faster at this group size: the chain by integer blocks
+    (:func:`reference_means_blocks`: two concurrent passes + a scan that travels) from 4 ranks on for dense float32 shards,
+    the chained accumulators (:func:`reference_means_chained`: one pass, the ranks take turns, pipelined over two column
+    groups) below that and for every other input.  With R ranks and T = 2 column groups the chained form costs
+    (T + R - 1) / T passes of one rank's rows -- 1.5 at R = 2, 2.5 at R = 4, 4.5 at R = 8 -- against ~2.2 for the blocks
+    (DESIGN.md 6).  Same bits either way; returns ``[1, G]`` means of the matrix's dtype on every rank."""
+    import torch
+
+    from . import _lib
+
+    _, size, _ = _group_ranks(group)
+    if size >= 4 and dm_local.format == _lib.ICV_DENSE and dm_local.dtype == torch.float32:
+        return reference_means_blocks(dm_local, n_total, group=group, stats=stats)
+    return reference_means_chained(dm_local, [n_total], group=group)
+
+
 def chunk_moments(cell_stats, global_row0: int, chunksize: int, n_chunks_global: int):
     """Per global chunk (rows, sum x, sum x^2) contributed by this rank's rows.
 

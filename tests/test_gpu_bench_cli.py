@@ -34,8 +34,11 @@ def test_n_rank_command_line_dry_run(n_ranks):
     assert rec["n_gpus"] == n_ranks and rec["steps"] == 2 and rec["warmup"] == 1
     assert rec["unit"] == "cells/s" and rec["higher_is_better"] is True
     assert rec["value"] > 0 and rec["value_allreduce_means"] > 0 and rec["value_chained_means"] > 0
-    assert set(rec["forms"]) >= {"value", "value_allreduce_means", "value_chained_means"}
+    assert rec["value_blocks_means"] > 0
+    assert set(rec["forms"]) >= {"value", "value_allreduce_means", "value_chained_means", "value_blocks_means"}
     assert "integer blocks" in rec["forms"]["value"]
+    # `value` is the faster of the two exact forms of the means
+    assert rec["value"] == pytest.approx(max(rec["value_blocks_means"], rec["value_chained_means"]), rel=1e-9)
     per_gpu = rec["config"]["cells_per_gpu"]
     assert len(per_gpu) == n_ranks and sum(per_gpu) == rec["config"]["cells_total"]
     assert all(c % 5000 == 0 for c in per_gpu[:-1])  # chunk-aligned shards

@@ -218,7 +218,9 @@ def _hp_run(icd, _engine, plan, X, labels, rank, world, align, cats, window, geo
         # (a rank that continues running chains replays a few per cent of its blocks at this depth, far less at config 3's
         # 125 000 rows per rank: tests/test_gpu_refmean.py::test_chain_by_blocks_replays_little_at_config3_geometry)
         assert rank == 0 or r1 == r0 or geom != "cfg3" or st["replayed"] < 0.2 * st["blocks"], st
-    elif means in ("chain", "blocks"):
+    elif means == "auto" and cats is None:
+        ref = icd.reference_means_exact(dm, n_all)  # blocks from 4 ranks on (dense float32), else the chained form
+    elif means in ("chain", "blocks", "auto"):
         if cats is None:
             ref = icd.reference_means_chained(dm, [n_all])
         else:
@@ -286,7 +288,8 @@ def _hp_worker(rank, world, port, fmt, window, geom, means, q):
     (2, "dense", 100, "small", "allreduce"), (3, "dense", 100, "small", "allreduce"), (2, "csr", 100, "small", "allreduce"),
     (3, "csr", 250, "small", "allreduce"), (3, "dense", 100, "small", "chain"), (2, "csr", 250, "small", "chain"),
     (3, "dense", 100, "cfg3", "allreduce"), (3, "dense", 100, "cfg3", "chain"), (2, "csr", 100, "cfg3", "chain"),
-    (2, "dense", 100, "small", "blocks"), (3, "dense", 100, "cfg3", "blocks"), (3, "dense", 100, "tiny", "blocks")])
+    (2, "dense", 100, "small", "blocks"), (3, "dense", 100, "cfg3", "blocks"), (3, "dense", 100, "tiny", "blocks"),
+    (4, "dense", 100, "small", "auto"), (2, "csr", 100, "small", "auto")])
 def test_hot_path_ranks_on_one_gpu(world, fmt, window, geom, means):
     """BASELINE config 3's code path (row shards, ONE all-reduce of the reference sums -- or the reference-order chains
     handed from rank to rank --, chunk-aligned and unaligned thresholds) with 2-3 ranks sharing cuda:0, at a small
@@ -318,7 +321,7 @@ def test_hot_path_ranks_on_one_gpu(world, fmt, window, geom, means):
     dm = _engine.to_device_matrix(X, torch.float32)
     for (align, allmean), _ in results[0][2].items():
         cats = None if allmean else ["n1", "n2"]
-        if means in ("chain", "blocks"):
+        if means in ("chain", "blocks", "auto"):
             ref_np = np.asarray(O.reference_profile(X, labels if cats else None, cats, None, X.shape[1]))
             ref = torch.from_numpy(np.ascontiguousarray(ref_np)).cuda()
         elif allmean:
@@ -338,7 +341,7 @@ def test_hot_path_ranks_on_one_gpu(world, fmt, window, geom, means):
         for a, b in zip(parts[:-1], parts[1:]):
             assert a[1] == b[0]
             np.testing.assert_array_equal(a[3], b[3])  # all ranks hold the same means
-        if means in ("chain", "blocks"):  # the reference's own bits, on every rank
+        if means in ("chain", "blocks", "auto"):  # the reference's own bits, on every rank
             np.testing.assert_array_equal(parts[0][3], ref.cpu().numpy())
         np.testing.assert_allclose(parts[0][3], ref.cpu().numpy(), rtol=1e-6, atol=1e-12)
         same_ref = np.array_equal(parts[0][3], ref.cpu().numpy())
