@@ -3,7 +3,9 @@
 Every seed draws a shape (1 .. 6000 rows, 1 .. 70 000 columns: one tile of one line up to more tiles than CUs, and now
 and then more than 65 535 columns = the round-4 kernels), a density (1e-4 .. 1), a dtype, a storage (CSR, C-ordered dense,
 column-major dense), row categories and a number of row pieces, and compares ``icv_colchain`` / ``icv_colsum_pairwise``
-with numpy / scipy through the oracle: array_equal.  Prints the failing seeds; exit status 1 if any."""
+with numpy / scipy through the oracle: array_equal.  C-ordered dense float32 cases also go through the chain by integer
+blocks (``ChainBlocks``: the row pieces as ranks, start estimates of random quality, scans in column ranges).  Prints the
+failing seeds; exit status 1 if any."""
 import os
 import sys
 import time
@@ -25,6 +27,8 @@ def case(seed):
     dens = float(10 ** rs.uniform(-4, 0)) if rs.rand() < 0.8 else 1.0
     dtype = [np.float32, np.float64][rs.randint(2)]
     kind = rs.choice(["csr", "csr", "csr", "dense", "densef"])
+    if seed >= 100000:  # seeds from 100 000 on: C-ordered dense float32 only = every case also runs the chain by blocks
+        dtype, kind = np.float32, "dense"
     if kind != "csr" and g == 1:
         g = 2  # (numpy sees a single-column dense matrix as a 1-D contiguous reduction: not reproduced)
     X = rs.gamma(0.3, 1.0, (n, g)).astype(dtype)
@@ -35,7 +39,7 @@ def case(seed):
         X[:, rs.randint(g)] = rs.gamma(0.3, 1.0, n) + 0.1  # a full column: 64 LDS rows a round
     labels = np.array(["a", "b", "c"])[rs.randint(0, 3, n)]
     cats = None if rs.rand() < 0.5 or kind == "densef" else [["a"], ["b", "a"], ["c", "a", "b"]][rs.randint(3)]
-    if cats is not None and not all((labels == c).any() for c in cats):
+    if (cats is not None and not all((labels == c).any() for c in cats)) or seed >= 100000:
         cats = None
     pieces = int(rs.choice([1, 1, 2, 5]))
     Xin = sp.csr_matrix(X) if kind == "csr" else (np.asfortranarray(X) if kind == "densef" else X)
@@ -71,6 +75,40 @@ def run(seed):
                 acc = _engine.column_chain(dm, acc, rows, count, int(r0), int(r1))
             out.append(_engine.chain_mean(acc, count, sp.issparse(Xin)).cpu().numpy())
         got = np.vstack(out)
+        if kind == "dense" and Xin.dtype == np.float32 and cats is None:
+            # the same chain BY BLOCKS (icv_colchain_blocks_*: what row-sharded ranks run concurrently), the row pieces as
+            # ranks; the start estimates of a random quality -- exact float64 totals, a few per cent off, off by orders of
+            # magnitude, none: a wrong estimate may only cost replays, never a bit
+            import torch
+
+            rs = np.random.RandomState(seed + 7)
+            acc = torch.zeros(Xin.shape[1], dtype=torch.float32, device="cuda")
+            est = np.zeros(Xin.shape[1], dtype=np.float64)
+            for r0, r1 in zip(bounds[:-1], bounds[1:]):
+                if r1 == r0:
+                    continue
+                cb = _engine.ChainBlocks(dm, int(r0), int(r1))
+                tot = cb.sums().cpu().numpy()
+                if not np.array_equal(tot, Xin[r0:r1].sum(axis=0, dtype=np.float64)) and \
+                        not np.allclose(tot, Xin[r0:r1].sum(axis=0, dtype=np.float64), rtol=1e-12, atol=0):
+                    return desc, False
+                q = rs.randint(4)
+                e = [est, est * rs.uniform(0.9, 1.1, est.shape), est * 10.0 ** rs.uniform(-3, 3, est.shape), None][q]
+                cb.records(None if e is None else torch.from_numpy(np.ascontiguousarray(e)).cuda())
+                if rs.rand() < 0.5 and Xin.shape[1] > 64:  # in column ranges, as the pipelined hand-over scans
+                    cut = int(rs.randint(1, Xin.shape[1] // 32 + 1)) * 32
+                    cut = min(cut, Xin.shape[1])
+                    cb.scan(acc, cols=(0, cut))
+                    if cut < Xin.shape[1]:
+                        cb.scan(acc, cols=(cut, Xin.shape[1]))
+                else:
+                    cb.scan(acc)
+                est = est + tot
+            got_b = _engine.chain_mean(acc, n, False).cpu().numpy()[None, :]
+            desc["blocks"] = True
+            if not np.array_equal(got_b, exp, equal_nan=True):
+                desc["blocks"] = "MISMATCH"
+                return desc, False
     return desc, got.dtype == exp.dtype and np.array_equal(got, exp, equal_nan=True)
 
 

@@ -75,7 +75,9 @@ timeout 300 python tools/bench_host_pack.py 50000 > $O/host_pack.txt 2>&1; tail 
 if [ "${1:-}" != "quick" ]; then
   (echo "== tests/fuzz_gpu.py 11000 600"; timeout 900 python tests/fuzz_gpu.py 11000 600 2>&1 | tail -2
    echo "== tests/fuzz_gpu_big.py 600 120"; timeout 600 python tests/fuzz_gpu_big.py 600 120 2>&1 | tail -2
-   echo "== tests/fuzz_gpu_ward.py 100 40"; timeout 300 python tests/fuzz_gpu_ward.py 100 40 2>&1 | tail -2) | tee $O/fuzz_gpu.txt
+   echo "== tests/fuzz_gpu_ward.py 100 40"; timeout 300 python tests/fuzz_gpu_ward.py 100 40 2>&1 | tail -2
+   echo "== tests/fuzz_gpu_means.py 7000 300"; timeout 900 python tests/fuzz_gpu_means.py 7000 300 2>&1 | tail -3
+   echo "== tests/fuzz_gpu_means.py 100000 200 (dense float32: every case also through the chain by blocks)"; timeout 900 python tests/fuzz_gpu_means.py 100000 200 2>&1 | tail -3) | tee $O/fuzz_gpu.txt
   timeout 600 python tests/soak_gpu.py 200 2>&1 | tail -6 | tee $O/soak_public_api.txt
 fi
 find $O -name "*.db" -delete 2>/dev/null
