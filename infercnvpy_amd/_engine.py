@@ -395,14 +395,19 @@ def _usable_cpus():
 
 
 def _default_pack_threads():
-    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): the usable logical CPUs (affinity mask and
-    cgroup quota), at most 32.  Measured on the GPU pool's box (2 x 64 cores, but a cgroup quota of 16 CPUs:
+    """Host threads that pack a dense piece (ICV_PACK_THREADS overrides): three quarters of the usable logical CPUs
+    (affinity mask and cgroup quota), at most 32.  Measured on the GPU pool's box (2 x 64 cores, but a cgroup quota of 16 CPUs:
     tools/bench_host_pack.py, profiles/r05_host_pack.txt): 124 GB/s of input with 8 threads, 162 with 16, 173 with 32,
     then a collapse (46 GB/s with 64, 20 with 128: the threads are throttled and wait on each other's block tickets)."""
     env = os.environ.get("ICV_PACK_THREADS")
     if env:
         return max(1, int(env))
-    return int(max(1, min(32, _usable_cpus())))
+    # three quarters of the usable CPUs: the packing is bound by host memory, not by the cores (12 threads pack as fast
+    # as 16 on a 16-CPU quota: 0.107 / 0.109 s per 16 GB), and the copier, the drain and the page-fault helpers run beside
+    # it -- a process that asks for more CPU time than its cgroup grants is stopped for the rest of the 100 ms period
+    # (the 0.19 s repeats between 0.14 s ones in profiles/r06_bench_n1.json; 24 / 32 threads: 0.16-0.26 s per call)
+    n = _usable_cpus()
+    return int(max(1, min(32, n - n // 4)))
 
 
 # Host buffers of the sparse upload, kept between calls (first-touch page faults of a few GB of fresh pages cost as much as

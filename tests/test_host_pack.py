@@ -120,6 +120,9 @@ def test_usable_cpus_and_thread_default(monkeypatch):
     n = _engine._usable_cpus()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert 1 <= _engine._default_pack_threads() <= 32
+    assert _engine._default_pack_threads() == max(1, min(32, n - n // 4))  # headroom for the copier / drain threads
+    monkeypatch.setattr(_engine, "_usable_cpus", lambda: 16)
+    assert _engine._default_pack_threads() == 12
     monkeypatch.setenv("ICV_PACK_THREADS", "5")
     assert _engine._default_pack_threads() == 5
 
