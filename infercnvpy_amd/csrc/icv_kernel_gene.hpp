@@ -77,8 +77,9 @@ __device__ __forceinline__ double gv_numpy_sum(const double* a, int n) {
     return __builtin_nan("");  // (never reached: gv_fused_ok)
 }
 
-// run_pk[r] = first window | #windows << 16 of run r; col_run16[c] = run of input column c or -1 (padded to a multiple of
-// 8 columns with -1).  Global loads are issued in batches before the dependent LDS work.
+// run_pk[r] = first window | #windows << 16 of run r; col_run16[c] = run of input column c, or R -- the NaN slot val[R] --
+// where the gene has no value (padded to a multiple of 8 columns with R).  Global loads are issued in batches before the
+// dependent LDS work.
 __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
     const double* __restrict__ win, int64_t ldw, int64_t n_rows, int W, const uint32_t* __restrict__ run_pk,
     const int32_t* __restrict__ run_mult, int R, int n_cov, const uint16_t* __restrict__ col_run16, int n_cols,
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(kGvThreads) k_gene_fused(
         if (vec2) {
             // a lane = two adjacent columns, the lanes of a wavefront = 1 KB of the row: every store instruction writes
             // whole lines (eight columns per lane -- 64-byte runs, lane stride 64 B -- measured 2.4 x slower: partial lines)
-            const int n2 = (n_cols + 1) / 2;  // pairs (the table is padded with -1)
+            const int n2 = (n_cols + 1) / 2;  // pairs (the table is padded with R)
             const uint32_t* cr2 = reinterpret_cast<const uint32_t*>(col_run16);
             for (int g0 = t; g0 < n2; g0 += UC * kGvThreads) {
                 uint32_t rr[UC];
