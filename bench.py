@@ -869,6 +869,7 @@ def _summary(result):
     if "value_allreduce_means" in result:
         out["value_allreduce_means"] = r(result["value_allreduce_means"], 0)
         out["value_chained_means"] = r(result.get("value_chained_means"), 0)
+        out["value_blocks_means"] = r(result.get("value_blocks_means"), 0)
     ex = result.get("extra") or {}
     c4 = ex.get("config4_csr_w250") or {}
     if "ms_per_step" in c4:
